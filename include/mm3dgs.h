@@ -1,0 +1,118 @@
+/*
+ * mm3dgs.h -- C ABI of libmm3dgs_hip.so: the MI355X (gfx950) differentiable 3D-Gaussian tile rasterizer that
+ * sits behind MM3DGS-SLAM's render boundary.
+ *
+ * What this boundary replaces in the reference (/root/reference):
+ *   - the un-vendored CUDA extension `diff_gaussian_rasterization` (.gitmodules:1-3; imported only at
+ *     slam/renderer.py:15-18).  Its Python surface -- GaussianRasterizationSettings (slam/renderer.py:125-138)
+ *     and GaussianRasterizer.__call__ (slam/renderer.py:140,196-214) plus the autograd backward driven by
+ *     slam/tracker.py:157 and slam/mapper.py:875 -- is rebuilt in mm3dgs_slam_amd/rasterizer.py on top of the
+ *     entry points below through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with `host_`; all buffers are caller-owned
+ *     (torch allocations); the library never allocates device memory.
+ *   - float32 everywhere, row-major; matrices use the reference's row-vector convention
+ *     (p_view = [p,1] * viewmatrix, slam/renderer.py:117-124).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no entry point synchronises the
+ *     host except mm3dgs_forward_exact(), which reads one int back (documented there).
+ *   - return value: 0 on success, negative on error; mm3dgs_last_error() returns a thread-local message.
+ */
+#ifndef MM3DGS_H
+#define MM3DGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM3DGS_TILE 16
+#define MM3DGS_MAX_CHANNELS 6
+#define MM3DGS_SPLAT_FLOATS 12 /* packed per-Gaussian screen-space record: xy, conic(3), opacity, 6 colours */
+
+/* Per-call camera / configuration bundle == GaussianRasterizationSettings (slam/renderer.py:125-138). */
+typedef struct Mm3dgsCamera {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;          /* W / (2 fx), slam/renderer.py:61 */
+  float tanfovy;          /* H / (2 fy), slam/renderer.py:62 */
+  float scale_modifier;
+  int32_t sh_degree;      /* active degree, 0..3 */
+  int32_t prefiltered;
+  int32_t debug;
+  const float* bg;         /* [3]   background, added as T_final * bg (slam/renderer.py:80-83,130) */
+  const float* viewmatrix; /* [4,4] row-vector convention (w2c^T), or identity in transform_means_python mode */
+  const float* projmatrix; /* [4,4] viewmatrix @ P^T (slam/renderer.py:121-123) */
+  const float* campos;     /* [3] */
+} Mm3dgsCamera;
+
+/* Header at offset 0 of the image-state buffer; counters are written by the device. */
+typedef struct Mm3dgsHeader {
+  uint32_t num_rendered; /* N = sum of tiles touched (the reference lineage's `num_rendered`) */
+  uint32_t overflow;     /* 1 if N exceeded the binning capacity of the call (output then incomplete) */
+  uint32_t max_tile_len; /* longest per-tile list */
+  uint32_t num_visible;  /* Gaussians with radii > 0 */
+} Mm3dgsHeader;
+
+/* ---- buffer sizing (pure host arithmetic) ------------------------------------------------------------- */
+size_t mm3dgs_geom_bytes(int P);                       /* per-Gaussian screen-space state               */
+size_t mm3dgs_image_bytes(int H, int W);               /* header + per-tile counters/ranges + per-pixel */
+size_t mm3dgs_binning_bytes(size_t N_capacity);        /* (depth,id) keys + sorted id list              */
+size_t mm3dgs_backward_scratch_bytes(int P);           /* per-Gaussian gradient accumulators + camera   */
+
+/* ---- forward ------------------------------------------------------------------------------------------
+ * Channels: C = n_sh_channels + n_extra.  If `shs` != NULL the first 3 channels are SH colour evaluated at
+ * cam->sh_degree with M coefficients per Gaussian ([P,M,3], slam/renderer.py:191) and `colors_precomp`
+ * (may be NULL) supplies `C-3` extra channels [P,C-3]; otherwise `colors_precomp` supplies all C channels
+ * [P,C] (slam/renderer.py:207-214 passes [z,1,z^2]).  C in {1..6}.  Extra channels beyond 3 use bg = 0.
+ * Exactly one of (scales,rotations) / cov3D_precomp ([P,6]) must be non-NULL.
+ *
+ * Stage 1: project, cull, EWA-splat to 2D conics, colour, count per-tile overlaps, scan tile counts.
+ *          Writes radii[P] (int32, 0 == culled) and the header (num_rendered).  If host_num_rendered is
+ *          non-NULL (must be pinned host memory) N is also copied there asynchronously. */
+int mm3dgs_forward_geom(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
+                        void* image_state, uint32_t* host_num_rendered, void* stream);
+
+/* Stage 2: scatter (depth,id) keys into per-tile bins, sort every tile's bin in LDS, composite front to back.
+ *          Writes out_color[C,H,W].  N_capacity is the number of (tile,Gaussian) pairs `binning_state` was
+ *          sized for; on overflow header.overflow is set and the image is incomplete (never out of bounds). */
+int mm3dgs_forward_raster(const Mm3dgsCamera* cam, int P, int C, const void* geom_state, void* image_state,
+                          void* binning_state, size_t N_capacity, float* out_color, void* stream);
+
+/* Both stages back to back, no host synchronisation (capacity-bounded binning). */
+int mm3dgs_forward(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                   const float* colors_precomp, const float* opacities, const float* scales,
+                   const float* rotations, const float* cov3D_precomp, float* out_color, int32_t* radii,
+                   void* geom_state, void* image_state, void* binning_state, size_t N_capacity, void* stream);
+
+/* ---- backward -----------------------------------------------------------------------------------------
+ * dL_dout [C,H,W] -> gradients of every tensor input of the forward.  Output pointers may be NULL when that
+ * gradient is not wanted.  dL_dmeans2D is [P,3] with (x,y) = dL/d(ndc-scaled screen position), z = 0, which
+ * is what slam/gaussian_model.py:594-598 consumes.  Camera gradients dL_dview[16], dL_dproj[16],
+ * dL_dcampos[3] (row-vector layout, same as the inputs) are produced when non-NULL ("-w-pose" behaviour,
+ * slam/renderer.py:115-124).  flags: see MM3DGS_BWD_*. */
+#define MM3DGS_BWD_SKIP_GAUSSIAN_GRADS 1 /* tracker mode: only dL_dmeans3D / dL_dcolors_precomp / camera */
+
+int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* opacities, const float* scales,
+                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                    const void* geom_state, const void* image_state, const void* binning_state,
+                    size_t N_capacity, const float* dL_dout, void* backward_scratch, float* dL_dmeans3D,
+                    float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities,
+                    float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dview, float* dL_dproj,
+                    float* dL_dcampos, int flags, void* stream);
+
+/* visible[P] (uint8) = z_view > 0.2 -- the lineage's markVisible. */
+int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream);
+
+const char* mm3dgs_last_error(void);
+int mm3dgs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM3DGS_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of libmm3dgs_hip.so (C ABI declared in include/mm3dgs.h).  No torch types cross this boundary:
+only raw device pointers, sizes and the HIP stream handle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmm3dgs_hip.so")
+
+
+class Mm3dgsCamera(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class Mm3dgsHeader(C.Structure):
+    _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("max_tile_len", C.c_uint32),
+                ("num_visible", C.c_uint32)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "mm3dgs_geom_bytes": (C.c_size_t, [C.c_int]),
+    "mm3dgs_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mm3dgs_binning_bytes": (C.c_size_t, [C.c_size_t]),
+    "mm3dgs_backward_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "mm3dgs_forward_geom": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 12),
+    "mm3dgs_forward_raster": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P, _P]),
+    "mm3dgs_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 12 + [C.c_size_t, _P]),
+    "mm3dgs_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 11 + [C.c_size_t]
+                        + [_P] * 13 + [C.c_int, _P]),
+    "mm3dgs_mark_visible": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, _P, _P, _P]),
+    "mm3dgs_last_error": (C.c_char_p, []),
+    "mm3dgs_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libmm3dgs_hip.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C {os.path.dirname(LIB_PATH)}`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().mm3dgs_last_error()
+        raise RuntimeError(f"mm3dgs error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,131 @@
+// C-ABI entry points of libmm3dgs_hip.so (declared in include/mm3dgs.h).  Plain pointers and sizes only; every
+// launch goes to the caller's stream; no device allocation, no host synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "mm3dgs_common.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-10, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" {
+
+const char* mm3dgs_last_error(void) { return g_err; }
+int mm3dgs_version(void) { return 100; }
+
+size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
+size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
+size_t mm3dgs_binning_bytes(size_t N) { return binning_bytes_impl(N); }
+size_t mm3dgs_backward_scratch_bytes(int P) { return bwd_bytes_impl(P); }
+
+static int check_common(const Mm3dgsCamera* cam, int P, int M, int C, const float* shs, const float* colors,
+                        const float* scales, const float* rots, const float* cov3d) {
+  if (!cam) return fail(-1, "camera is NULL");
+  if (cam->image_height <= 0 || cam->image_width <= 0) return fail(-1, "bad image size %dx%d", cam->image_height, cam->image_width);
+  if (cam->image_height > 16 * 65535 || cam->image_width > 16 * 65535) return fail(-1, "image too large for 16-bit tile coordinates");
+  if (P < 0) return fail(-1, "P < 0");
+  if (C < 1 || C > MM3DGS_MAX_CHANNELS) return fail(-1, "C=%d outside 1..%d", C, MM3DGS_MAX_CHANNELS);
+  if (P == 0) return 0;  // nothing to validate: empty tensors arrive as NULL pointers
+  if (!shs && !colors) return fail(-2, "Please provide excatly one of either SHs or precomputed colors!");
+  if (shs) {
+    if (C < 3) return fail(-2, "SH colour needs C >= 3");
+    if (C > 3 && !colors) return fail(-2, "C=%d with SHs needs %d extra precomputed channels", C, C - 3);
+    if (cam->sh_degree < 0 || cam->sh_degree > 3) return fail(-2, "sh_degree %d outside 0..3", cam->sh_degree);
+    if (M < (cam->sh_degree + 1) * (cam->sh_degree + 1)) return fail(-2, "M=%d too small for sh_degree %d", M, cam->sh_degree);
+  }
+  if ((scales == nullptr || rots == nullptr) == (cov3d == nullptr))
+    return fail(-2, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  if (!cam->bg || !cam->viewmatrix || !cam->projmatrix || !cam->campos) return fail(-1, "camera device pointers missing");
+  return 0;
+}
+
+int mm3dgs_forward_geom(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_state,
+                        void* image_state, uint32_t* host_num_rendered, void* stream) {
+  int rc = check_common(cam, P, M, C, shs, colors_precomp, scales, rotations, cov3D_precomp);
+  if (rc) return rc;
+  if (!geom_state || !image_state || (P > 0 && (!means3D || !opacities || !radii))) return fail(-1, "NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view(geom_state, P > 0 ? P : 1);
+  ImageView iv = image_view(image_state, cd.H, cd.W);
+  if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
+  launch_preprocess_fwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, iv, s);
+  launch_scan_tiles(cd.gx * cd.gy, iv, s);
+  if (host_num_rendered)
+    if (hipMemcpyAsync(host_num_rendered, &iv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+      return fail(-10, "num_rendered copy failed");
+  return check_launch("forward_geom");
+}
+
+int mm3dgs_forward_raster(const Mm3dgsCamera* cam, int P, int C, const void* geom_state, void* image_state,
+                          void* binning_state, size_t N_capacity, float* out_color, void* stream) {
+  if (!cam || !geom_state || !image_state || !binning_state || !out_color) return fail(-1, "NULL buffer");
+  if (C < 1 || C > MM3DGS_MAX_CHANNELS) return fail(-1, "C=%d outside 1..%d", C, MM3DGS_MAX_CHANNELS);
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view((void*)geom_state, P > 0 ? P : 1);
+  ImageView iv = image_view(image_state, cd.H, cd.W);
+  BinView b = bin_view(binning_state, N_capacity);
+  launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s);
+  launch_composite_fwd(cd, C, g, iv, b, N_capacity, out_color, s);
+  return check_launch("forward_raster");
+}
+
+int mm3dgs_forward(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                   const float* colors_precomp, const float* opacities, const float* scales,
+                   const float* rotations, const float* cov3D_precomp, float* out_color, int32_t* radii,
+                   void* geom_state, void* image_state, void* binning_state, size_t N_capacity, void* stream) {
+  int rc = mm3dgs_forward_geom(cam, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                               radii, geom_state, image_state, nullptr, stream);
+  if (rc) return rc;
+  return mm3dgs_forward_raster(cam, P, C, geom_state, image_state, binning_state, N_capacity, out_color, stream);
+}
+
+int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* means3D, const float* shs,
+                    const float* colors_precomp, const float* opacities, const float* scales,
+                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                    const void* geom_state, const void* image_state, const void* binning_state,
+                    size_t N_capacity, const float* dL_dout, void* backward_scratch, float* dL_dmeans3D,
+                    float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities,
+                    float* dL_dscales, float* dL_drotations, float* dL_dcov3D, float* dL_dview, float* dL_dproj,
+                    float* dL_dcampos, int flags, void* stream) {
+  int rc = check_common(cam, P, M, C, shs, colors_precomp, scales, rotations, cov3D_precomp);
+  if (rc) return rc;
+  if (!geom_state || !image_state || !binning_state || !dL_dout || !backward_scratch || (P > 0 && !radii))
+    return fail(-1, "NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view((void*)geom_state, P > 0 ? P : 1);
+  ImageView iv = image_view((void*)image_state, cd.H, cd.W);
+  BinView b = bin_view((void*)binning_state, N_capacity);
+  BwdView bw = bwd_view(backward_scratch, P);
+  if (hipMemsetAsync(bw.dsplat, 0, (size_t)(P > 0 ? P : 1) * SPLAT_F * 4, s) != hipSuccess) return fail(-10, "memset failed");
+  launch_composite_bwd(cd, C, g, iv, b, N_capacity, dL_dout, bw.dsplat, s);
+  bool want_cam = dL_dview || dL_dproj || dL_dcampos;
+  launch_preprocess_bwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, bw,
+                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,
+                        dL_dcov3D, want_cam, flags, s);
+  if (want_cam) launch_camgrad_finish(bw, dL_dview, dL_dproj, dL_dcampos, s);
+  return check_launch("backward");
+}
+
+int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream) {
+  if (!cam || !cam->viewmatrix || (P > 0 && (!means3D || !visible))) return fail(-1, "NULL buffer");
+  launch_mark_visible(cam_dev(cam), P, means3D, visible, (hipStream_t)stream);
+  return check_launch("mark_visible");
+}
+
+}  // extern "C"

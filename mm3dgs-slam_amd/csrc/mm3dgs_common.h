@@ -1,0 +1,168 @@
+// Internal definitions shared by the gfx950 kernels of libmm3dgs_hip.so.
+// Data layout in HBM (all caller-owned):
+//   geom_state   : Splat[P] (48 B packed AoS record, gathered by id in the compositor) | depth[P] | rect[P] (2x u32)
+//                  | clamped[P] (u8, SH clamp bits)
+//   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | final_T[H*W] | n_contrib[H*W]
+//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | point_list[N_cap] (u32)
+//   bwd scratch  : dsplat[P] (12 floats: dxy(2) dconic(3) dopacity(1) dcolor(6)) | campartial[ceil(P/256)][32]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mm3dgs.h"
+
+#define TILE 16
+#define TILE_PIX 256
+#define SPLAT_F MM3DGS_SPLAT_FLOATS
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GeomView {
+  float* splat;       // [P][12]
+  float* depth;       // [P]
+  uint32_t* rect;     // [P][2]  (minx | miny<<16), (maxx | maxy<<16)
+  uint8_t* clamped;   // [P]
+};
+static inline size_t geom_bytes_impl(int P) {
+  size_t p = (size_t)P;
+  return align_up(p * SPLAT_F * 4, 256) + align_up(p * 4, 256) + align_up(p * 8, 256) + align_up(p, 256);
+}
+static inline GeomView geom_view(void* base, int P) {
+  size_t p = (size_t)P;
+  char* c = (char*)base;
+  GeomView g;
+  g.splat = (float*)c;      c += align_up(p * SPLAT_F * 4, 256);
+  g.depth = (float*)c;      c += align_up(p * 4, 256);
+  g.rect = (uint32_t*)c;    c += align_up(p * 8, 256);
+  g.clamped = (uint8_t*)c;
+  return g;
+}
+
+struct ImageView {
+  Mm3dgsHeader* hdr;
+  uint32_t* tile_count;  // [T]
+  uint32_t* ranges;      // [T+1]
+  uint32_t* cursor;      // [T]
+  float* final_T;        // [H*W]
+  uint32_t* n_contrib;   // [H*W]
+  size_t zero_bytes;     // hdr + tile_count: cleared at the start of every forward
+};
+static inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
+static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+static inline size_t image_bytes_impl(int H, int W) {
+  size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
+  return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(px * 4, 256) +
+         align_up(px * 4, 256);
+}
+static inline ImageView image_view(void* base, int H, int W) {
+  size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
+  char* c = (char*)base;
+  ImageView v;
+  v.hdr = (Mm3dgsHeader*)c;     c += 256;
+  v.tile_count = (uint32_t*)c;  c += align_up(T * 4, 256);
+  v.zero_bytes = (size_t)(c - (char*)base);
+  v.ranges = (uint32_t*)c;      c += align_up((T + 1) * 4, 256);
+  v.cursor = (uint32_t*)c;      c += align_up(T * 4, 256);
+  v.final_T = (float*)c;        c += align_up(px * 4, 256);
+  v.n_contrib = (uint32_t*)c;
+  return v;
+}
+
+struct BinView {
+  unsigned long long* keys;  // [N_cap]
+  uint32_t* point_list;      // [N_cap]
+};
+static inline size_t binning_bytes_impl(size_t N) {
+  if (N < 1) N = 1;
+  return align_up(N * 8, 256) + align_up(N * 4, 256);
+}
+static inline BinView bin_view(void* base, size_t N) {
+  if (N < 1) N = 1;
+  char* c = (char*)base;
+  BinView b;
+  b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
+  b.point_list = (uint32_t*)c;
+  return b;
+}
+
+struct BwdView {
+  float* dsplat;      // [P][12] screen-space gradient accumulators (zeroed at the start of every backward)
+  float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums
+  int nrows;
+};
+static inline int bwd_rows(int P) { return (P + 255) / 256; }
+static inline size_t bwd_bytes_impl(int P) {
+  return align_up((size_t)(P > 0 ? P : 1) * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
+}
+static inline BwdView bwd_view(void* base, int P) {
+  char* c = (char*)base;
+  BwdView b;
+  b.dsplat = (float*)c;  c += align_up((size_t)(P > 0 ? P : 1) * SPLAT_F * 4, 256);
+  b.campartial = (float*)c;
+  b.nrows = bwd_rows(P);
+  return b;
+}
+
+// Camera constants copied by value into kernel arguments (matrices stay device pointers: they are torch
+// tensors computed differentiably on the device, slam/renderer.py:117-124, and must not cost a host sync).
+struct CamDev {
+  int H, W, gx, gy;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int sh_degree;
+  const float* bg;
+  const float* view;
+  const float* proj;
+  const float* campos;
+};
+static inline CamDev cam_dev(const Mm3dgsCamera* c) {
+  CamDev d;
+  d.H = c->image_height; d.W = c->image_width;
+  d.gx = tiles_x(d.W); d.gy = tiles_y(d.H);
+  d.tanfovx = c->tanfovx; d.tanfovy = c->tanfovy;
+  d.focal_x = d.W / (2.0f * c->tanfovx);
+  d.focal_y = d.H / (2.0f * c->tanfovy);
+  d.scale_modifier = c->scale_modifier;
+  d.sh_degree = c->sh_degree;
+  d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
+  return d;
+}
+
+// ---- launchers implemented in the individual .hip files ----------------------------------------------------
+void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
+                           const float* colors, const float* opac, const float* scales, const float* rots,
+                           const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
+void launch_scan_tiles(int T, ImageView iv, hipStream_t s);
+void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
+                         const int32_t* radii_or_null, hipStream_t s);
+void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
+                          float* out_color, hipStream_t s);
+void launch_composite_bwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
+                          const float* dL_dout, float* dsplat, hipStream_t s);
+void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
+                           const float* colors, const float* opac, const float* scales, const float* rots,
+                           const float* cov3d, const int32_t* radii, GeomView g, BwdView bw, float* dmeans3D,
+                           float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
+                           float* drots, float* dcov3d, bool want_cam, int flags, hipStream_t s);
+void launch_camgrad_finish(BwdView bw, float* dview, float* dproj, float* dcampos, hipStream_t s);
+void launch_mark_visible(const CamDev& cam, int P, const float* means3D, uint8_t* visible, hipStream_t s);
+
+#ifdef __HIPCC__
+// ---- wave64 helpers ------------------------------------------------------------------------------------------
+// Sum across the 64 lanes with DPP row shifts + row broadcasts (6 VALU adds, no LDS); total lands in lane 63.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v += dpp_f<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v += dpp_f<0x114, 0xf, 0xf>(v);  // row_shr:4
+  v += dpp_f<0x118, 0xf, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
+  v += dpp_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1,3
+  v += dpp_f<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2,3
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = wave_sum_to_lane63(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#endif

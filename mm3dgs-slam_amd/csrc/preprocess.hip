@@ -1,0 +1,489 @@
+// Per-Gaussian stages of the rasterizer for gfx950: forward projection / EWA splat / SH colour / tile counting,
+// and the backward chain rule from screen-space gradients to the Gaussian parameters and the camera.
+// One lane per Gaussian, 256-lane workgroups (4 waves); inputs are the caller's torch layouts ([P,3], [P,4],
+// [P,M,3] ...), a wave reads each of them as one contiguous span so every fetched line is fully used.
+//
+// Maths: SURVEY.md Appendix A.  Conventions pinned by the reference: quaternion (w,x,y,z) and R(q)
+// (utils/general_utils.py:78-99), cov3D = (RS)(RS)^T (utils/general_utils.py:101-110), SH basis
+// (utils/sh_utils.py:57-112, +0.5 and clamp at slam/renderer.py:188-189), row-vector matrices
+// (slam/renderer.py:117-124).
+#include "mm3dgs_common.h"
+
+#define PP_BLOCK 256
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 -1.0925484305920792f
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 -1.0925484305920792f
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 -0.5900435899266435f
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 -0.4570457994644658f
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 -0.4570457994644658f
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 -0.5900435899266435f
+
+// Real SH basis values b[0..(deg+1)^2) at unit direction (x,y,z).
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b) {
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+      b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+      if (deg > 2) {
+        b[9] = SH_C3_0 * y * (3.f * xx - yy);
+        b[10] = SH_C3_1 * xy * z;
+        b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+        b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+        b[14] = SH_C3_5 * z * (xx - yy);
+        b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+// d b[k] / d(x,y,z)
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float* gx, float* gy, float* gz) {
+  gx[0] = gy[0] = gz[0] = 0.f;
+  if (deg > 0) {
+    gx[1] = 0.f; gy[1] = -SH_C1; gz[1] = 0.f;
+    gx[2] = 0.f; gy[2] = 0.f; gz[2] = SH_C1;
+    gx[3] = -SH_C1; gy[3] = 0.f; gz[3] = 0.f;
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      gx[4] = SH_C2_0 * y; gy[4] = SH_C2_0 * x; gz[4] = 0.f;
+      gx[5] = 0.f; gy[5] = SH_C2_1 * z; gz[5] = SH_C2_1 * y;
+      gx[6] = SH_C2_2 * -2.f * x; gy[6] = SH_C2_2 * -2.f * y; gz[6] = SH_C2_2 * 4.f * z;
+      gx[7] = SH_C2_3 * z; gy[7] = 0.f; gz[7] = SH_C2_3 * x;
+      gx[8] = SH_C2_4 * 2.f * x; gy[8] = SH_C2_4 * -2.f * y; gz[8] = 0.f;
+      if (deg > 2) {
+        gx[9] = SH_C3_0 * 6.f * xy; gy[9] = SH_C3_0 * (3.f * xx - 3.f * yy); gz[9] = 0.f;
+        gx[10] = SH_C3_1 * yz; gy[10] = SH_C3_1 * xz; gz[10] = SH_C3_1 * xy;
+        gx[11] = SH_C3_2 * -2.f * xy; gy[11] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); gz[11] = SH_C3_2 * 8.f * yz;
+        gx[12] = SH_C3_3 * -6.f * xz; gy[12] = SH_C3_3 * -6.f * yz; gz[12] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+        gx[13] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); gy[13] = SH_C3_4 * -2.f * xy; gz[13] = SH_C3_4 * 8.f * xz;
+        gx[14] = SH_C3_5 * 2.f * xz; gy[14] = SH_C3_5 * -2.f * yz; gz[14] = SH_C3_5 * (xx - yy);
+        gx[15] = SH_C3_6 * (3.f * xx - 3.f * yy); gy[15] = SH_C3_6 * -6.f * xy; gz[15] = 0.f;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void quat_to_R(const float* q, float R[3][3]) {
+  float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+  R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+  R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma3 (symmetric, full 3x3) from scale/rotation or from the 6 upper-triangular values.
+__device__ __forceinline__ void load_cov3d(int idx, const float* scales, const float* rots, const float* cov3d,
+                                           float mod, float S3[3][3], float R[3][3], float sm[3]) {
+  if (cov3d) {
+    const float* c = cov3d + (size_t)idx * 6;
+    S3[0][0] = c[0]; S3[0][1] = c[1]; S3[0][2] = c[2];
+    S3[1][0] = c[1]; S3[1][1] = c[3]; S3[1][2] = c[4];
+    S3[2][0] = c[2]; S3[2][1] = c[4]; S3[2][2] = c[5];
+  } else {
+    float q[4] = {rots[(size_t)idx * 4], rots[(size_t)idx * 4 + 1], rots[(size_t)idx * 4 + 2], rots[(size_t)idx * 4 + 3]};
+    quat_to_R(q, R);
+    sm[0] = mod * scales[(size_t)idx * 3]; sm[1] = mod * scales[(size_t)idx * 3 + 1]; sm[2] = mod * scales[(size_t)idx * 3 + 2];
+    float Mx[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) Mx[i][k] = R[i][k] * sm[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) S3[i][j] = Mx[i][0] * Mx[j][0] + Mx[i][1] * Mx[j][1] + Mx[i][2] * Mx[j][2];
+  }
+}
+
+struct Ewa {
+  float t[3];      // view-space mean
+  float txc, tyc;  // clamped-frustum x,y used inside the Jacobian
+  bool in_x, in_y;
+  float A[2][3];   // J * Wr
+  float J00, J02, J11, J12;
+  float a, b, c;   // 2D covariance (+0.3 on the diagonal)
+};
+
+__device__ __forceinline__ void ewa_project(const CamDev& cam, const float* V, const float p[3], const float S3[3][3], Ewa& e) {
+#pragma unroll
+  for (int j = 0; j < 3; j++) e.t[j] = p[0] * V[0 * 4 + j] + p[1] * V[1 * 4 + j] + p[2] * V[2 * 4 + j] + V[3 * 4 + j];
+  float tz = e.t[2];
+  float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+  float txtz = e.t[0] / tz, tytz = e.t[1] / tz;
+  e.in_x = (txtz >= -limx) && (txtz <= limx);
+  e.in_y = (tytz >= -limy) && (tytz <= limy);
+  e.txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  e.tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  if (e.in_x) e.txc = e.t[0];
+  if (e.in_y) e.tyc = e.t[1];
+  float itz = 1.f / tz, itz2 = itz * itz;
+  e.J00 = cam.focal_x * itz; e.J02 = -cam.focal_x * e.txc * itz2;
+  e.J11 = cam.focal_y * itz; e.J12 = -cam.focal_y * e.tyc * itz2;
+  // Wr[j][i] = V[i][j]  (world->view rotation for column vectors);  A = J * Wr
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    e.A[0][i] = e.J00 * V[i * 4 + 0] + e.J02 * V[i * 4 + 2];
+    e.A[1][i] = e.J11 * V[i * 4 + 1] + e.J12 * V[i * 4 + 2];
+  }
+  float AS[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) AS[r][j] = e.A[r][0] * S3[0][j] + e.A[r][1] * S3[1][j] + e.A[r][2] * S3[2][j];
+  e.a = AS[0][0] * e.A[0][0] + AS[0][1] * e.A[0][1] + AS[0][2] * e.A[0][2] + 0.3f;
+  e.b = AS[0][0] * e.A[1][0] + AS[0][1] * e.A[1][1] + AS[0][2] * e.A[1][2];
+  e.c = AS[1][0] * e.A[1][0] + AS[1][1] * e.A[1][1] + AS[1][2] * e.A[1][2] + 0.3f;
+}
+
+__global__ void __launch_bounds__(PP_BLOCK)
+preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
+                      const float* __restrict__ shs, const float* __restrict__ colors,
+                      const float* __restrict__ opac, const float* __restrict__ scales,
+                      const float* __restrict__ rots, const float* __restrict__ cov3d, int32_t* __restrict__ radii,
+                      GeomView g, ImageView iv) {
+  int idx = blockIdx.x * PP_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  const float* V = cam.view;
+  const float* PV = cam.proj;
+  float p[3] = {means3D[(size_t)idx * 3], means3D[(size_t)idx * 3 + 1], means3D[(size_t)idx * 3 + 2]};
+  float tz = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
+  int32_t rad = 0;
+  uint32_t r0 = 0, r1 = 0;
+  if (tz > 0.2f) {
+    float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
+    float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
+    float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
+    float pw = 1.f / (hw + 1e-7f);
+    float S3[3][3], R[3][3], sm[3];
+    load_cov3d(idx, scales, rots, cov3d, cam.scale_modifier, S3, R, sm);
+    Ewa e;
+    ewa_project(cam, V, p, S3, e);
+    float det = e.a * e.c - e.b * e.b;
+    float px = ((hx * pw + 1.f) * cam.W - 1.f) * 0.5f;
+    float py = ((hy * pw + 1.f) * cam.H - 1.f) * 0.5f;
+    if (det != 0.f && isfinite(px) && isfinite(py)) {
+      float dinv = 1.f / det;
+      float mid = 0.5f * (e.a + e.c);
+      float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      float rf = ceilf(3.f * sqrtf(lam));
+      float gxf = (float)cam.gx + 1.f, gyf = (float)cam.gy + 1.f;
+      int minx = min(cam.gx, max(0, (int)fminf(fmaxf((px - rf) / TILE, -1.f), gxf)));
+      int miny = min(cam.gy, max(0, (int)fminf(fmaxf((py - rf) / TILE, -1.f), gyf)));
+      int maxx = min(cam.gx, max(0, (int)fminf(fmaxf((px + rf + (TILE - 1)) / TILE, -1.f), gxf)));
+      int maxy = min(cam.gy, max(0, (int)fminf(fmaxf((py + rf + (TILE - 1)) / TILE, -1.f), gyf)));
+      if ((maxx - minx) * (maxy - miny) > 0) {
+        rad = (int32_t)fminf(rf, 2.0e9f);
+        r0 = (uint32_t)minx | ((uint32_t)miny << 16);
+        r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
+        float col[MM3DGS_MAX_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int nsh = 0;
+        if (shs) {
+          nsh = 3;
+          float dx = p[0] - cam.campos[0], dy = p[1] - cam.campos[1], dz = p[2] - cam.campos[2];
+          float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+          float b[16];
+          sh_basis(cam.sh_degree, dx * inv, dy * inv, dz * inv, b);
+          int nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+          const float* sh = shs + (size_t)idx * M * 3;
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+          for (int k = 0; k < nb; k++) { c0 += b[k] * sh[k * 3]; c1 += b[k] * sh[k * 3 + 1]; c2 += b[k] * sh[k * 3 + 2]; }
+          c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+          uint8_t cl = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
+          g.clamped[idx] = cl;
+          col[0] = fmaxf(c0, 0.f); col[1] = fmaxf(c1, 0.f); col[2] = fmaxf(c2, 0.f);
+        }
+        if (colors) {
+          int ne = C - nsh;
+          for (int k = 0; k < ne; k++) col[nsh + k] = colors[(size_t)idx * ne + k];
+        }
+        float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
+        sp[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
+        sp[1] = make_float4(e.a * dinv, opac[idx], col[0], col[1]);
+        sp[2] = make_float4(col[2], col[3], col[4], col[5]);
+        g.depth[idx] = e.t[2];
+        for (int y = miny; y < maxy; y++)
+          for (int x = minx; x < maxx; x++) atomicAdd(&iv.tile_count[y * cam.gx + x], 1u);
+        atomicAdd(&iv.hdr->num_visible, 1u);
+      }
+    }
+  }
+  radii[idx] = rad;
+  g.rect[(size_t)idx * 2] = r0;
+  g.rect[(size_t)idx * 2 + 1] = r1;
+}
+
+void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
+                           const float* colors, const float* opac, const float* scales, const float* rots,
+                           const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
+                     means3D, shs, colors, opac, scales, rots, cov3d, radii, g, iv);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward: screen-space gradient record (dxy in pixel units, dconic, dopacity, dcolour[6]) -> parameter gradients.
+// Camera gradients: 27 values per Gaussian (view rows 0..3 x cols 0..2, proj rows 0..3 x cols {0,1,3}, campos)
+// are reduced wave -> workgroup in registers/LDS, one partial row per workgroup is written, and a single-wave
+// finishing kernel adds the rows in double precision in a fixed order (deterministic, no atomics).
+#define NCAM 27
+__global__ void __launch_bounds__(PP_BLOCK)
+preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
+                      const float* __restrict__ shs, const float* __restrict__ colors,
+                      const float* __restrict__ opac, const float* __restrict__ scales,
+                      const float* __restrict__ rots, const float* __restrict__ cov3d,
+                      const int32_t* __restrict__ radii, GeomView g, const float* __restrict__ dsplat,
+                      float* __restrict__ campartial, float* __restrict__ dmeans3D, float* __restrict__ dmeans2D,
+                      float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac,
+                      float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3d,
+                      int want_cam, int flags) {
+  int idx = blockIdx.x * PP_BLOCK + threadIdx.x;
+  const float* V = cam.view;
+  const float* PV = cam.proj;
+  float cg[NCAM];
+#pragma unroll
+  for (int k = 0; k < NCAM; k++) cg[k] = 0.f;
+  const bool skip_g = (flags & MM3DGS_BWD_SKIP_GAUSSIAN_GRADS) != 0;
+  const int nsh = shs ? 3 : 0;
+  const int ne = C - nsh;
+  if (idx < P) {
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float gnx = 0.f, gny = 0.f;
+    float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f}, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f;
+    float dcol[MM3DGS_MAX_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool vis = radii[idx] > 0;
+    if (vis) {
+      const float4* dsp = (const float4*)(dsplat + (size_t)idx * SPLAT_F);
+      float4 d0 = dsp[0], d1 = dsp[1], d2 = dsp[2];
+      float gpx = d0.x, gpy = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
+      dop = d1.y;
+      dcol[0] = d1.z; dcol[1] = d1.w; dcol[2] = d2.x; dcol[3] = d2.y; dcol[4] = d2.z; dcol[5] = d2.w;
+      float p[3] = {means3D[(size_t)idx * 3], means3D[(size_t)idx * 3 + 1], means3D[(size_t)idx * 3 + 2]};
+      float S3[3][3], R[3][3], sm[3];
+      load_cov3d(idx, scales, rots, cov3d, cam.scale_modifier, S3, R, sm);
+      Ewa e;
+      ewa_project(cam, V, p, S3, e);
+      float a = e.a, b = e.b, c = e.c;
+      float det = a * c - b * b;
+      float id2 = 1.f / (det * det);
+      // conic = (c, -b, a)/det  ->  d/d(a,b,c)
+      float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
+      float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
+      float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+      float G2[2][2] = {{da, 0.5f * db}, {0.5f * db, dcc}};
+      // GA = G2 * A (2x3)
+      float GA[2][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        GA[0][i] = G2[0][0] * e.A[0][i] + G2[0][1] * e.A[1][i];
+        GA[1][i] = G2[1][0] * e.A[0][i] + G2[1][1] * e.A[1][i];
+      }
+      // dSigma3 = A^T G2 A (symmetric)
+      float dS[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dS[i][j] = e.A[0][i] * GA[0][j] + e.A[1][i] * GA[1][j];
+      // dA = 2 G2 A Sigma3
+      float dA[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dA[r][j] = 2.f * (GA[r][0] * S3[0][j] + GA[r][1] * S3[1][j] + GA[r][2] * S3[2][j]);
+      // dJ = dA Wr^T : dJ[r][k] = sum_i dA[r][i] * Wr[k][i] = sum_i dA[r][i] * V[i][k]
+      float dJ00 = dA[0][0] * V[0] + dA[0][1] * V[4] + dA[0][2] * V[8];
+      float dJ02 = dA[0][0] * V[2] + dA[0][1] * V[6] + dA[0][2] * V[10];
+      float dJ11 = dA[1][0] * V[1] + dA[1][1] * V[5] + dA[1][2] * V[9];
+      float dJ12 = dA[1][0] * V[2] + dA[1][1] * V[6] + dA[1][2] * V[10];
+      float tz = e.t[2], itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+      float dtxc = -cam.focal_x * itz2 * dJ02;
+      float dtyc = -cam.focal_y * itz2 * dJ12;
+      float dt[3];
+      dt[0] = e.in_x ? dtxc : 0.f;
+      dt[1] = e.in_y ? dtyc : 0.f;
+      dt[2] = -cam.focal_x * itz2 * dJ00 - cam.focal_y * itz2 * dJ11 + 2.f * cam.focal_x * e.txc * itz3 * dJ02 +
+              2.f * cam.focal_y * e.tyc * itz3 * dJ12;
+#pragma unroll
+      for (int i = 0; i < 3; i++) dmean[i] = V[i * 4 + 0] * dt[0] + V[i * 4 + 1] * dt[1] + V[i * 4 + 2] * dt[2];
+      // screen position: pix = ((ndc+1) S - 1)/2, ndc = hom.xy / (hom.w + 1e-7)
+      float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
+      float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
+      float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
+      float pw = 1.f / (hw + 1e-7f);
+      gnx = gpx * 0.5f * cam.W;
+      gny = gpy * 0.5f * cam.H;
+      float dhx = gnx * pw, dhy = gny * pw, dhw = -(gnx * hx + gny * hy) * pw * pw;
+#pragma unroll
+      for (int i = 0; i < 3; i++) dmean[i] += PV[i * 4 + 0] * dhx + PV[i * 4 + 1] * dhy + PV[i * 4 + 3] * dhw;
+      if (want_cam) {
+        // view: from t = [p,1] V  and from Wr inside A = J Wr  (dWr = J^T dA ; V[i][j] = Wr[j][i])
+        float ph[4] = {p[0], p[1], p[2], 1.f};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) cg[i * 3 + j] = ph[i] * dt[j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          cg[i * 3 + 0] += e.J00 * dA[0][i];
+          cg[i * 3 + 1] += e.J11 * dA[1][i];
+          cg[i * 3 + 2] += e.J02 * dA[0][i] + e.J12 * dA[1][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          cg[12 + i * 3 + 0] = ph[i] * dhx;
+          cg[12 + i * 3 + 1] = ph[i] * dhy;
+          cg[12 + i * 3 + 2] = ph[i] * dhw;
+        }
+      }
+      // colours
+      if (shs) {
+        uint8_t cl = g.clamped[idx];
+        float gc0 = (cl & 1) ? 0.f : dcol[0], gc1 = (cl & 2) ? 0.f : dcol[1], gc2 = (cl & 4) ? 0.f : dcol[2];
+        float vx = p[0] - cam.campos[0], vy = p[1] - cam.campos[1], vz = p[2] - cam.campos[2];
+        float inv = 1.f / sqrtf(vx * vx + vy * vy + vz * vz);
+        float ux = vx * inv, uy = vy * inv, uz = vz * inv;
+        int deg = cam.sh_degree;
+        int nb = (deg + 1) * (deg + 1);
+        if (!skip_g && dshs) {
+          float bb[16];
+          sh_basis(deg, ux, uy, uz, bb);
+          float* o = dshs + (size_t)idx * M * 3;
+          for (int k = 0; k < nb; k++) { o[k * 3] = bb[k] * gc0; o[k * 3 + 1] = bb[k] * gc1; o[k * 3 + 2] = bb[k] * gc2; }
+          for (int k = nb; k < M; k++) { o[k * 3] = 0.f; o[k * 3 + 1] = 0.f; o[k * 3 + 2] = 0.f; }
+        }
+        if (deg > 0) {
+          float bx[16], by[16], bz[16];
+          sh_basis_grad(deg, ux, uy, uz, bx, by, bz);
+          const float* sh = shs + (size_t)idx * M * 3;
+          float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+          for (int k = 1; k < nb; k++) {
+            float w = sh[k * 3] * gc0 + sh[k * 3 + 1] * gc1 + sh[k * 3 + 2] * gc2;
+            ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+          }
+          float dot = ux * ddx + uy * ddy + uz * ddz;
+          float mx = (ddx - ux * dot) * inv, my = (ddy - uy * dot) * inv, mz = (ddz - uz * dot) * inv;
+          dmean[0] += mx; dmean[1] += my; dmean[2] += mz;
+          if (want_cam) { cg[24] = -mx; cg[25] = -my; cg[26] = -mz; }
+        }
+      }
+      // covariance parameters
+      if (!skip_g) {
+        if (cov3d) {
+          dc6[0] = dS[0][0]; dc6[1] = 2.f * dS[0][1]; dc6[2] = 2.f * dS[0][2];
+          dc6[3] = dS[1][1]; dc6[4] = 2.f * dS[1][2]; dc6[5] = dS[2][2];
+        } else {
+          // Sigma3 = Mx Mx^T, Mx = R diag(sm):  dMx = 2 dS Mx
+          float dM[3][3];
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              dM[i][k] = 2.f * (dS[i][0] * R[0][k] + dS[i][1] * R[1][k] + dS[i][2] * R[2][k]) * sm[k];
+          float dR[3][3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            ds[k] = cam.scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+            for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * sm[k];
+          }
+          float r = rots[(size_t)idx * 4], x = rots[(size_t)idx * 4 + 1], y = rots[(size_t)idx * 4 + 2], z = rots[(size_t)idx * 4 + 3];
+          dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+          dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] +
+                         r * dR[2][1] - 2.f * x * dR[2][2]);
+          dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] +
+                         z * dR[2][1] - 2.f * y * dR[2][2]);
+          dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] +
+                         y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+      }
+    } else if (!skip_g && shs && dshs) {
+      float* o = dshs + (size_t)idx * M * 3;
+      for (int k = 0; k < M * 3; k++) o[k] = 0.f;
+    }
+    // every Gaussian writes its slots (culled ones write zeros): no memset of the outputs is needed
+    if (dmeans3D) { dmeans3D[(size_t)idx * 3] = dmean[0]; dmeans3D[(size_t)idx * 3 + 1] = dmean[1]; dmeans3D[(size_t)idx * 3 + 2] = dmean[2]; }
+    if (dmeans2D) { dmeans2D[(size_t)idx * 3] = gnx; dmeans2D[(size_t)idx * 3 + 1] = gny; dmeans2D[(size_t)idx * 3 + 2] = 0.f; }
+    if (dcolors) for (int k = 0; k < ne; k++) dcolors[(size_t)idx * ne + k] = dcol[nsh + k];
+    if (!skip_g) {
+      if (dopac) dopac[idx] = dop;
+      if (dscales && !cov3d) { dscales[(size_t)idx * 3] = ds[0]; dscales[(size_t)idx * 3 + 1] = ds[1]; dscales[(size_t)idx * 3 + 2] = ds[2]; }
+      if (drots && !cov3d) { drots[(size_t)idx * 4] = dq[0]; drots[(size_t)idx * 4 + 1] = dq[1]; drots[(size_t)idx * 4 + 2] = dq[2]; drots[(size_t)idx * 4 + 3] = dq[3]; }
+      if (dcov3d && cov3d) for (int k = 0; k < 6; k++) dcov3d[(size_t)idx * 6 + k] = dc6[k];
+    }
+  }
+  if (want_cam) {
+    __shared__ float red[4][NCAM];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NCAM; k++) {
+      float v = wave_sum_to_lane63(cg[k]);
+      if (lane == 63) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NCAM) {
+      int k = threadIdx.x;
+      campartial[(size_t)blockIdx.x * 32 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+  }
+}
+
+// one wave: lane k (< 27) walks all workgroup partial rows in order, accumulating in double.
+__global__ void camgrad_finish_kernel(const float* __restrict__ campartial, int nrows, float* __restrict__ dview,
+                                      float* __restrict__ dproj, float* __restrict__ dcampos) {
+  int k = threadIdx.x;
+  if (k >= NCAM) return;
+  double acc = 0.0;
+  for (int r = 0; r < nrows; r++) acc += (double)campartial[(size_t)r * 32 + k];
+  float v = (float)acc;
+  if (k < 12) {
+    int i = k / 3, j = k % 3;
+    if (dview) dview[i * 4 + j] = v;
+  } else if (k < 24) {
+    int i = (k - 12) / 3, j = (k - 12) % 3;
+    if (dproj) dproj[i * 4 + (j == 2 ? 3 : j)] = v;
+  } else if (dcampos) {
+    dcampos[k - 24] = v;
+  }
+  if (k < 4) {  // matrix entries that never receive gradient
+    if (dview) dview[k * 4 + 3] = 0.f;
+    if (dproj) dproj[k * 4 + 2] = 0.f;
+  }
+}
+
+void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
+                           const float* colors, const float* opac, const float* scales, const float* rots,
+                           const float* cov3d, const int32_t* radii, GeomView g, BwdView bw, float* dmeans3D,
+                           float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
+                           float* drots, float* dcov3d, bool want_cam, int flags, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
+                     means3D, shs, colors, opac, scales, rots, cov3d, radii, g, bw.dsplat, bw.campartial, dmeans3D,
+                     dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3d, want_cam ? 1 : 0, flags);
+}
+
+void launch_camgrad_finish(BwdView bw, float* dview, float* dproj, float* dcampos, hipStream_t s) {
+  hipLaunchKernelGGL(camgrad_finish_kernel, dim3(1), dim3(64), 0, s, bw.campartial, bw.nrows, dview,
+                     dproj, dcampos);
+}
+
+__global__ void mark_visible_kernel(CamDev cam, int P, const float* __restrict__ means3D, uint8_t* __restrict__ vis) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float* V = cam.view;
+  float tz = means3D[(size_t)idx * 3] * V[2] + means3D[(size_t)idx * 3 + 1] * V[6] + means3D[(size_t)idx * 3 + 2] * V[10] + V[14];
+  vis[idx] = tz > 0.2f ? 1 : 0;
+}
+void launch_mark_visible(const CamDev& cam, int P, const float* means3D, uint8_t* visible, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, cam, P, means3D, visible);
+}

