@@ -53,44 +53,64 @@ void launch_scan_tiles(int T, ImageView iv, hipStream_t s) {
 }
 
 // ---- 3. scatter -----------------------------------------------------------------------------------------------
-// One lane per Gaussian; a Gaussian whose rectangle covers more than 32 tiles is handed to the whole wave
-// (its rectangle is broadcast with readlane and the 64 lanes stride over the tiles) so that one huge splat
-// does not serialise a wave for thousands of iterations.
+// One lane per Gaussian, two sweeps over its tile rectangle around a per-workgroup LDS histogram:
+//   sweep 1 counts the workgroup's overlaps per tile in LDS; one returning global atomic per *touched tile* reserves
+//   a contiguous span in that tile's bin; sweep 2 hands out slots inside the spans with returning LDS atomics.
+// Spatially coherent Gaussian order (SLAM maps) turns ~2.3 global atomics per Gaussian into a few per workgroup.
+// A Gaussian whose rectangle covers more than 32 tiles is spread over the whole wave (rectangle broadcast with
+// readlane) so that one huge splat does not serialise a wave for thousands of iterations.
+template <bool WRITE>
+__device__ __forceinline__ void sweep_rect(uint32_t* cnt, int gx, int minx, int miny, int w, int area, unsigned long long key,
+                                           unsigned long long* keys, uint32_t N_cap, int lane) {
+  unsigned long long big = __ballot(area > 32);
+  if (area > 0 && area <= 32) {
+    for (int k = 0; k < area; k++) {
+      uint32_t slot = atomicAdd(&cnt[(miny + k / w) * gx + minx + k % w], 1u);
+      if (WRITE && slot < N_cap) keys[slot] = key;
+    }
+  }
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
+    const int sw = __builtin_amdgcn_readlane(w, src), sarea = __builtin_amdgcn_readlane(area, src);
+    const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)key, src), khi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+    const unsigned long long skey = ((unsigned long long)khi << 32) | klo;
+    for (int k = lane; k < sarea; k += 64) {
+      uint32_t slot = atomicAdd(&cnt[(sminy + k / sw) * gx + sminx + k % sw], 1u);
+      if (WRITE && slot < N_cap) keys[slot] = skey;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
-scatter_keys_kernel(int P, int gx, GeomView g, ImageView iv, BinView b, uint32_t N_cap) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
+scatter_keys_kernel(int P, int gx, int T, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int lds_tiles) {
+  extern __shared__ uint32_t hist[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int t = tid; t < lds_tiles; t += 256) hist[t] = 0;
+  int idx = blockIdx.x * 256 + tid;
   uint32_t r0 = 0, r1 = 0, dbits = 0;
   if (idx < P) {
     r0 = g.rect[(size_t)idx * 2];
     r1 = g.rect[(size_t)idx * 2 + 1];
-    if (r1 != r0 || r1 != 0) dbits = __float_as_uint(g.depth[idx]);
+    if (r1 != r0) dbits = __float_as_uint(g.depth[idx]);
   }
-  int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
-  int w = maxx - minx, h = maxy - miny;
-  int area = (w > 0 && h > 0) ? w * h : 0;
-  const int lane = threadIdx.x & 63;
-  unsigned long long big = __ballot(area > 32);
-  if (area > 0 && area <= 32) {
-    unsigned long long key = ((unsigned long long)dbits << 32) | (uint32_t)idx;
-    for (int y = miny; y < maxy; y++)
-      for (int x = minx; x < maxx; x++) {
-        uint32_t slot = atomicAdd(&iv.cursor[y * gx + x], 1u);
-        if (slot < N_cap) b.keys[slot] = key;
-      }
-  }
-  while (big) {
-    int src = __ffsll((long long)big) - 1;
-    big &= big - 1;
-    int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
-    int sw = __builtin_amdgcn_readlane(w, src), sarea = __builtin_amdgcn_readlane(area, src);
-    uint32_t sd = __builtin_amdgcn_readlane(dbits, src);
-    int sidx = __builtin_amdgcn_readlane(idx, src);
-    unsigned long long key = ((unsigned long long)sd << 32) | (uint32_t)sidx;
-    for (int k = lane; k < sarea; k += 64) {
-      int y = sminy + k / sw, x = sminx + k % sw;
-      uint32_t slot = atomicAdd(&iv.cursor[y * gx + x], 1u);
-      if (slot < N_cap) b.keys[slot] = key;
+  const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
+  const int w = maxx - minx, h = maxy - miny;
+  const int area = (w > 0 && h > 0) ? w * h : 0;
+  const unsigned long long key = ((unsigned long long)dbits << 32) | (uint32_t)idx;
+  if (lds_tiles) {
+    __syncthreads();
+    sweep_rect<false>(hist, gx, minx, miny, w, area, key, b.keys, N_cap, lane);
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+      uint32_t c = hist[t];
+      if (c) hist[t] = atomicAdd(&iv.cursor[t], c);
     }
+    __syncthreads();
+    sweep_rect<true>(hist, gx, minx, miny, w, area, key, b.keys, N_cap, lane);
+  } else {
+    sweep_rect<true>(iv.cursor, gx, minx, miny, w, area, key, b.keys, N_cap, lane);
   }
   if (idx == 0 && iv.hdr->num_rendered > N_cap) iv.hdr->overflow = 1;
 }
@@ -159,8 +179,10 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
                          const int32_t*, hipStream_t s) {
   int T = cam.gx * cam.gy;
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
   if (P > 0)
-    hipLaunchKernelGGL(scatter_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, cam.gx, g, iv, b, ncap);
+    hipLaunchKernelGGL(scatter_keys_kernel, dim3((P + 255) / 256), dim3(256), (size_t)lds_tiles * 4, s, P, cam.gx, T, g, iv, b,
+                       ncap, lds_tiles);
   hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, 0, iv, b, ncap);
   hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, SORT_CAP_SMALL, iv, b, ncap);
 }

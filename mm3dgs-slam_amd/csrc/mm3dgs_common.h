@@ -13,6 +13,7 @@
 #define TILE 16
 #define TILE_PIX 256
 #define SPLAT_F MM3DGS_SPLAT_FLOATS
+#define MAX_LDS_TILES 12288  // per-workgroup LDS tile histogram (48 KB) covers up to ~1920x1600
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -150,16 +150,24 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
                       const float* __restrict__ shs, const float* __restrict__ colors,
                       const float* __restrict__ opac, const float* __restrict__ scales,
                       const float* __restrict__ rots, const float* __restrict__ cov3d, int32_t* __restrict__ radii,
-                      GeomView g, ImageView iv) {
+                      GeomView g, ImageView iv, int lds_tiles) {
+  // Per-workgroup tile histogram in LDS (lds_tiles = T when it fits, else 0 -> direct global atomics): consecutive
+  // Gaussians are spatially coherent in SLAM maps (seeded in pixel raster order, slam/mapper.py:437-474), so a
+  // workgroup's ~2.3 overlaps per Gaussian collapse into a handful of global atomics.
+  extern __shared__ uint32_t hist[];
+  const int T = cam.gx * cam.gy;
+  for (int t = threadIdx.x; t < lds_tiles; t += PP_BLOCK) hist[t] = 0;
+  if (lds_tiles) __syncthreads();
   int idx = blockIdx.x * PP_BLOCK + threadIdx.x;
-  if (idx >= P) return;
+  const bool live = idx < P;
   const float* V = cam.view;
   const float* PV = cam.proj;
-  float p[3] = {means3D[(size_t)idx * 3], means3D[(size_t)idx * 3 + 1], means3D[(size_t)idx * 3 + 2]};
+  float p[3] = {0.f, 0.f, 0.f};
+  if (live) { p[0] = means3D[(size_t)idx * 3]; p[1] = means3D[(size_t)idx * 3 + 1]; p[2] = means3D[(size_t)idx * 3 + 2]; }
   float tz = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
   int32_t rad = 0;
   uint32_t r0 = 0, r1 = 0;
-  if (tz > 0.2f) {
+  if (live && tz > 0.2f) {
     float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
     float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
     float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
@@ -211,23 +219,49 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         sp[1] = make_float4(e.a * dinv, opac[idx], col[0], col[1]);
         sp[2] = make_float4(col[2], col[3], col[4], col[5]);
         g.depth[idx] = e.t[2];
-        for (int y = miny; y < maxy; y++)
-          for (int x = minx; x < maxx; x++) atomicAdd(&iv.tile_count[y * cam.gx + x], 1u);
-        atomicAdd(&iv.hdr->num_visible, 1u);
       }
     }
   }
-  radii[idx] = rad;
-  g.rect[(size_t)idx * 2] = r0;
-  g.rect[(size_t)idx * 2 + 1] = r1;
+  if (live) {
+    radii[idx] = rad;
+    g.rect[(size_t)idx * 2] = r0;
+    g.rect[(size_t)idx * 2 + 1] = r1;
+  }
+  // count overlaps per tile
+  {
+    const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
+    const int w = maxx - minx, area = w * (maxy - miny);
+    uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
+    const int lane = threadIdx.x & 63;
+    unsigned long long big = __ballot(area > 32);
+    if (area > 0 && area <= 32)
+      for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) atomicAdd(&cnt[y * cam.gx + x], 1u);
+    while (big) {  // a splat covering many tiles is spread over the whole wave
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
+      const int sw = __builtin_amdgcn_readlane(w, src), sarea = __builtin_amdgcn_readlane(area, src);
+      for (int k = lane; k < sarea; k += 64) atomicAdd(&cnt[(sminy + k / sw) * cam.gx + sminx + k % sw], 1u);
+    }
+  }
+  if (lds_tiles) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += PP_BLOCK) {
+      uint32_t c = hist[t];
+      if (c) atomicAdd(&iv.tile_count[t], c);
+    }
+  }
 }
 
 void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
                            const float* colors, const float* opac, const float* scales, const float* rots,
                            const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s) {
   if (P <= 0) return;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
-                     means3D, shs, colors, opac, scales, rots, cov3d, radii, g, iv);
+  const int T = cam.gx * cam.gy;
+  const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), (size_t)lds_tiles * 4, s, cam,
+                     P, M, C, means3D, shs, colors, opac, scales, rots, cov3d, radii, g, iv, lds_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

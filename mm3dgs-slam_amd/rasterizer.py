@@ -56,6 +56,18 @@ _capacity_cache = {}
 _pending = []  # [(event, pinned_hdr, capacity, key)]
 
 
+_last = {}
+
+
+def last_header():
+    """Counters of the most recent forward (synchronises): num_rendered, overflow, max_tile_len."""
+    img = _last.get("img")
+    if img is None:
+        return None
+    h = img[:16].view(torch.int32).cpu()
+    return dict(num_rendered=int(h[0]), overflow=int(h[1]), max_tile_len=int(h[2]))
+
+
 def set_binning_policy(mode: str = "exact", headroom: float = 1.5):
     if mode not in ("exact", "async"):
         raise ValueError("mode must be 'exact' or 'async'")
@@ -179,6 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 _pending.append((ev, hdr, n_cap, key))
+        _last["img"] = img
         ctx.rs = rs
         ctx.dims = (P, M, Cn, n_cap)
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj, cpos,

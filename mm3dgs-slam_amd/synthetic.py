@@ -64,3 +64,56 @@ def small_pose(seed=1, angle=0.08, trans=0.15):
     M[:3, :3] = R
     M[:3, 3] = torch.randn(3, generator=g, dtype=torch.float64) * trans
     return M
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SLAM-shaped scene
+def rgbd_frame(H, W, seed=0, n_boxes=6, invalid_frac=0.05, device="cpu"):
+    """Synthetic RGB-D frame: tilted plane at z in [1.5, 4] m plus axis-aligned boxes in front of it, smooth-noise
+    texture in [0,1], `invalid_frac` of the depth pixels set to 0 (sensor holes).  Returns color[3,H,W], depth[H,W]."""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    depth = 2.2 + 1.2 * xs + 0.6 * ys
+    for _ in range(n_boxes):
+        cx, cy = torch.rand(2, generator=g)
+        w, h = 0.08 + 0.2 * torch.rand(2, generator=g)
+        z = 1.5 + 1.0 * torch.rand(1, generator=g)
+        m = ((xs - cx).abs() < w / 2) & ((ys - cy).abs() < h / 2)
+        depth = torch.where(m, torch.minimum(depth, z.expand_as(depth)), depth)
+    depth = depth.clamp(1.5, 4.0)
+    low = torch.rand(1, 3, H // 16 + 2, W // 16 + 2, generator=g)
+    color = torch.nn.functional.interpolate(low, size=(H, W), mode="bicubic", align_corners=False)[0].clamp(0, 1)
+    color = (0.75 * color + 0.25 * torch.rand(3, H, W, generator=g)).clamp(0, 1)
+    holes = torch.rand(H, W, generator=g) < invalid_frac
+    depth = torch.where(holes, torch.zeros_like(depth), depth)
+    return color.to(device), depth.to(device)
+
+
+def seed_gaussians(color, depth, fx, fy, cx, cy, P, seed=0, isotropic=True, c2w=None):
+    """Gaussians seeded like the reference's first frame (slam/mapper.py:437-474,644-668): one per sampled valid-depth
+    pixel, xyz = back-projection, log-scale = log(z / ((fx+fy)/2)) on all three axes, opacity logit 0, identity
+    quaternion, f_dc = (rgb - 0.5)/C0.  Pixels are sub/over-sampled to reach exactly P Gaussians, with +-1/2 pixel
+    jitter and a U[0.7, 2] scale jitter (and per-axis U[0.5, 2] + random rotations when not `isotropic`)."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = depth.shape
+    dev = depth.device
+    valid = torch.nonzero(depth.reshape(-1).cpu() > 0).flatten()
+    pick = valid[torch.randint(0, valid.numel(), (P,), generator=g)] if P != valid.numel() else valid
+    pick = torch.sort(pick).values   # raster order, as `point_cld[mask]` yields in the reference (slam/mapper.py:487-490)
+    u = (pick % W).float() + (torch.rand(P, generator=g) - 0.5)
+    v = (pick // W).float() + (torch.rand(P, generator=g) - 0.5)
+    z = depth.reshape(-1).cpu()[pick]
+    xyz = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
+    if c2w is not None:
+        xyz = xyz @ c2w[:3, :3].t().cpu() + c2w[:3, 3].cpu()
+    rgb = color.reshape(3, -1).cpu()[:, pick].t().contiguous()
+    base = torch.log(z / ((fx + fy) / 2)) + torch.log(0.7 + 1.3 * torch.rand(P, generator=g))
+    scaling = base[:, None].repeat(1, 3)
+    rot = torch.zeros(P, 4)
+    rot[:, 0] = 1
+    if not isotropic:
+        scaling = scaling + torch.log(0.5 + 1.5 * torch.rand(P, 3, generator=g))
+        rot = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=1)
+    out = dict(xyz=xyz, f_dc=((rgb - 0.5) / 0.28209479177387814)[:, None, :], opacity=torch.zeros(P, 1), scaling=scaling,
+               rotation=rot, rgb=rgb)
+    return {k: t.float().contiguous().to(dev) for k, t in out.items()}
