@@ -53,14 +53,19 @@ typedef struct Mm3dgsHeader {
   uint32_t num_rendered; /* N = sum of tiles touched (the reference lineage's `num_rendered`) */
   uint32_t overflow;     /* 1 if N exceeded the binning capacity of the call (output then incomplete) */
   uint32_t max_tile_len; /* longest per-tile list */
-  uint32_t num_visible;  /* Gaussians with radii > 0 */
+  uint32_t reserved0;
+  /* diagnostics, only counted when the environment variable MM3DGS_STATS=1 (adds atomics; not for timing runs) */
+  uint32_t fwd_wave_iters; /* (wave, splat) evaluations executed by the forward compositor  */
+  uint32_t bwd_wave_iters; /* (wave, splat) evaluations that reached the gradient reduction */
+  uint32_t bwd_wave_visits;/* (wave, splat) evaluations executed by the backward compositor */
+  uint32_t reserved1;
 } Mm3dgsHeader;
 
 /* ---- buffer sizing (pure host arithmetic) ------------------------------------------------------------- */
 size_t mm3dgs_geom_bytes(int P);                       /* per-Gaussian screen-space state               */
 size_t mm3dgs_image_bytes(int H, int W);               /* header + per-tile counters/ranges + per-pixel */
-size_t mm3dgs_binning_bytes(size_t N_capacity);        /* (depth,id) keys + sorted id list              */
-size_t mm3dgs_backward_scratch_bytes(int P);           /* per-Gaussian gradient accumulators + camera   */
+size_t mm3dgs_binning_bytes(size_t N_capacity);        /* (depth,id) keys + sub-tile lists + slot maps  */
+size_t mm3dgs_backward_scratch_bytes(int P, size_t N_capacity); /* per-(sub-tile,splat) gradient records + camera */
 
 /* ---- forward ------------------------------------------------------------------------------------------
  * Channels: C = n_sh_channels + n_extra.  If `shs` != NULL the first 3 channels are SH colour evaluated at

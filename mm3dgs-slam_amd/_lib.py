@@ -20,7 +20,8 @@ class Mm3dgsCamera(C.Structure):
 
 class Mm3dgsHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("max_tile_len", C.c_uint32),
-                ("num_visible", C.c_uint32)]
+                ("reserved0", C.c_uint32), ("fwd_wave_iters", C.c_uint32), ("bwd_wave_iters", C.c_uint32),
+                ("bwd_wave_visits", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 _P = C.c_void_p
@@ -28,7 +29,7 @@ _SIGS = {
     "mm3dgs_geom_bytes": (C.c_size_t, [C.c_int]),
     "mm3dgs_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_binning_bytes": (C.c_size_t, [C.c_size_t]),
-    "mm3dgs_backward_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "mm3dgs_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
     "mm3dgs_forward_geom": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 12),
     "mm3dgs_forward_raster": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P, _P]),
     "mm3dgs_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 12 + [C.c_size_t, _P]),

@@ -27,7 +27,7 @@ int mm3dgs_version(void) { return 100; }
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
 size_t mm3dgs_binning_bytes(size_t N) { return binning_bytes_impl(N); }
-size_t mm3dgs_backward_scratch_bytes(int P) { return bwd_bytes_impl(P); }
+size_t mm3dgs_backward_scratch_bytes(int P, size_t N) { return bwd_bytes_impl(P, N); }
 
 static int check_common(const Mm3dgsCamera* cam, int P, int M, int C, const float* shs, const float* colors,
                         const float* scales, const float* rots, const float* cov3d) {
@@ -63,7 +63,7 @@ int mm3dgs_forward_geom(const Mm3dgsCamera* cam, int P, int M, int C, const floa
   ImageView iv = image_view(image_state, cd.H, cd.W);
   if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
   launch_preprocess_fwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, iv, s);
-  launch_scan_tiles(cd.gx * cd.gy, iv, s);
+  launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s);
   if (host_num_rendered)
     if (hipMemcpyAsync(host_num_rendered, &iv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess)
       return fail(-10, "num_rendered copy failed");
@@ -111,12 +111,11 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
   GeomView g = geom_view((void*)geom_state, P > 0 ? P : 1);
   ImageView iv = image_view((void*)image_state, cd.H, cd.W);
   BinView b = bin_view((void*)binning_state, N_capacity);
-  BwdView bw = bwd_view(backward_scratch, P);
-  if (hipMemsetAsync(bw.dsplat, 0, (size_t)(P > 0 ? P : 1) * SPLAT_F * 4, s) != hipSuccess) return fail(-10, "memset failed");
-  launch_composite_bwd(cd, C, g, iv, b, N_capacity, dL_dout, bw.dsplat, s);
+  BwdView bw = bwd_view(backward_scratch, P, N_capacity);
+  launch_composite_bwd(cd, C, g, iv, b, N_capacity, dL_dout, bw.dsub, s);
   bool want_cam = dL_dview || dL_dproj || dL_dcampos;
-  launch_preprocess_bwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, bw,
-                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,
+  launch_preprocess_bwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, b,
+                        N_capacity, bw, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,
                         dL_dcov3D, want_cam, flags, s);
   if (want_cam) launch_camgrad_finish(bw, dL_dview, dL_dproj, dL_dcampos, s);
   return check_launch("backward");

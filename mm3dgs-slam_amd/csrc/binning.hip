@@ -3,28 +3,29 @@
 //   2. scan_tiles: one workgroup turns tile_count into ranges[T+1] (num_rendered = ranges[T]) and seeds cursor[T];
 //   3. scatter: every visible Gaussian drops a 64-bit key (depth_bits << 32 | id) into each overlapped tile's bin
 //      (slot = returning atomic on the tile cursor) -- order inside a bin is arbitrary at this point;
-//   4. sort_tiles: one workgroup per tile sorts its bin in LDS (bitonic, keys unique => deterministic) and writes
-//      the depth-ordered id list.  Ordering == (depth, Gaussian index), the order a stable sort on the lineage's
-//      (tile | depth) keys produces.
-// HBM traffic is 12 B/pair written + 12 B/pair read + 4 B/pair written, versus 24 B/pair x 6 radix passes.
+//   4. sort_tiles: one workgroup per tile sorts its bin in LDS (bitonic, keys unique => deterministic).  Ordering ==
+//      (depth, Gaussian index), the order a stable sort on the lineage's (tile | depth) keys produces.  The same
+//      workgroup then splits the tile's list into four depth-ordered 8x8 sub-tile lists: a splat is listed for a
+//      sub-tile only if the axis-aligned bound of { alpha >= 1/255 } reaches it (conservative, so compositing the
+//      sub-list equals compositing the full tile list), and records for every pair (Gaussian, tile) the slot the
+//      backward pass will find it under (gslot) plus which sub-tiles hold it (submask).
+// HBM traffic is ~45 B/pair, versus 24 B/pair x 6 passes for a global radix sort of 64-bit keys.
 #include "mm3dgs_common.h"
 
 // ---- 2. scan --------------------------------------------------------------------------------------------------
 #define SCAN_BLOCK 1024
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, ImageView iv) {
-  __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
-  __shared__ uint32_t carry_s;
-  __shared__ uint32_t maxlen_s;
+// exclusive scan of src[0..n) by one 1024-lane workgroup; returns the total (valid in every lane)
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t* src, uint32_t* dst0, uint32_t* dst1, int n,
+                                                    uint32_t* wave_tot, uint32_t* carry_s, uint32_t* maxv) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { carry_s = 0; maxlen_s = 0; }
+  if (tid == 0) *carry_s = 0;
   __syncthreads();
   uint32_t local_max = 0;
-  for (int base = 0; base < T; base += SCAN_BLOCK) {
+  for (int base = 0; base < n; base += SCAN_BLOCK) {
     int i = base + tid;
-    uint32_t v = (i < T) ? iv.tile_count[i] : 0u;
+    uint32_t v = (i < n) ? src[i] : 0u;
     local_max = max(local_max, v);
-    // inclusive scan inside the wave (Hillis-Steele over lanes)
-    uint32_t x = v;
+    uint32_t x = v;  // inclusive scan inside the wave
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       uint32_t y = __shfl_up(x, off, 64);
@@ -32,24 +33,37 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, ImageView
     }
     if (lane == 63) wave_tot[wv] = x;
     __syncthreads();
-    uint32_t prefix = carry_s;
+    uint32_t prefix = *carry_s;
     for (int w = 0; w < wv; w++) prefix += wave_tot[w];
     uint32_t excl = prefix + x - v;
-    if (i < T) { iv.ranges[i] = excl; iv.cursor[i] = excl; }
+    if (i < n) { dst0[i] = excl; if (dst1) dst1[i] = excl; }
     __syncthreads();
-    if (tid == SCAN_BLOCK - 1) carry_s = prefix + x;
+    if (tid == SCAN_BLOCK - 1) *carry_s = prefix + x;
     __syncthreads();
   }
-  atomicMax(&maxlen_s, local_max);
+  if (maxv) atomicMax(maxv, local_max);
   __syncthreads();
-  if (tid == 0) {
-    iv.ranges[T] = carry_s;
-    iv.hdr->num_rendered = carry_s;
+  return *carry_s;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nblocks, GeomView g, ImageView iv) {
+  __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
+  __shared__ uint32_t carry_s;
+  __shared__ uint32_t maxlen_s;
+  if (threadIdx.x == 0) maxlen_s = 0;
+  uint32_t total = block_excl_scan(iv.tile_count, iv.ranges, iv.cursor, T, wave_tot, &carry_s, &maxlen_s);
+  if (threadIdx.x == 0) {
+    iv.ranges[T] = total;
+    iv.hdr->num_rendered = total;
     iv.hdr->max_tile_len = maxlen_s;
   }
+  __syncthreads();
+  // tiles touched per preprocess workgroup -> exclusive prefix (start of each workgroup's span in gslot)
+  uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr);
+  if (threadIdx.x == 0) g.block_tiles[nblocks] = tot2;
 }
-void launch_scan_tiles(int T, ImageView iv, hipStream_t s) {
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, iv);
+void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s) {
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, (P + 255) / 256, g, iv);
 }
 
 // ---- 3. scatter -----------------------------------------------------------------------------------------------
@@ -147,29 +161,94 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 }
 
 // Tier kernel: handles tiles with lo < len <= CAP in LDS; when GLOBAL_TAIL it also sorts len > CAP in place in
-// global memory (rare: > 16 K splats on one tile).
+// global memory (rare: > 16 K splats on one tile).  After sorting it emits the four sub-tile lists.
 template <int CAP, bool GLOBAL_TAIL>
-__global__ void __launch_bounds__(256) sort_tiles_kernel(int T, int lo, ImageView iv, BinView b, uint32_t N_cap) {
+__global__ void __launch_bounds__(256)
+sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap) {
   __shared__ unsigned long long sk[CAP];
-  // XCD-aware tile order is not needed here: a tile's bin is private to its workgroup.
-  int tile = blockIdx.x;
+  __shared__ uint32_t wcnt[4][4];
+  __shared__ uint32_t run[4];
+  const int tile = blockIdx.x;
   if (tile >= T) return;
-  uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
-  int len = (int)(end - start);
+  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
+  const int len = (int)(end - start);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (lo == 0 && len == 0) {
+    if (tid < 4) iv.subcount[4 * tile + tid] = 0;
+    return;
+  }
   if (len <= lo) return;
-  const int tid = threadIdx.x;
+  if (!GLOBAL_TAIL && len > CAP) return;
   unsigned long long* gk = b.keys + start;
-  uint32_t* pl = b.point_list + start;
-  if (len <= CAP) {
+  const bool in_lds = len <= CAP;
+  if (in_lds) {
     for (int i = tid; i < len; i += 256) sk[i] = gk[i];
     __syncthreads();
     if (len > 1) bitonic_any_len([&](int i) -> unsigned long long& { return sk[i]; }, len, tid, 256);
-    for (int i = tid; i < len; i += 256) pl[i] = (uint32_t)sk[i];
-  } else if (GLOBAL_TAIL) {
+  } else {
     __syncthreads();
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
-    for (int i = tid; i < len; i += 256) pl[i] = (uint32_t)gk[i];
   }
+  // ---- emit sub-tile lists (order preserving) ----
+  const int ttx = tile % gx, tty = tile / gx;
+  const float tx0 = (float)(ttx * TILE), ty0 = (float)(tty * TILE);
+  if (tid < 4) run[tid] = 0;
+  __syncthreads();
+  uint2* sub = b.sublist + (size_t)4 * start;
+  for (int base = 0; base < len; base += 256) {
+    const int i = base + tid;
+    const bool have = i < len;
+    uint32_t id = 0;
+    bool ov0 = false, ov1 = false, ov2 = false, ov3 = false;
+    if (have) {
+      id = (uint32_t)(in_lds ? sk[i] : gk[i]);
+      const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
+      const float4 A = sp[0], B = sp[1];
+      // alpha >= 1/255  <=>  d^T Q d <= 2 tau, tau = ln(255 o), Q = [[A.z, A.w],[A.w, B.x]]
+      const float tau = __logf(255.f * B.y);
+      const float det = A.z * B.x - A.w * A.w;
+      bool ovx0, ovx1, ovy0, ovy1;
+      if (det > 0.f) {
+        const float k = 2.f * fmaxf(tau, 0.f) / det;
+        const float hx = sqrtf(k * B.x) * 1.0002f + 0.002f;
+        const float hy = sqrtf(k * A.z) * 1.0002f + 0.002f;
+        const float xl = A.x - hx - tx0, xh = A.x + hx - tx0;
+        const float yl = A.y - hy - ty0, yh = A.y + hy - ty0;
+        const bool live = tau > 0.f;
+        ovx0 = live && (xl <= 7.f) && (xh >= 0.f);
+        ovx1 = live && (xl <= 15.f) && (xh >= 8.f);
+        ovy0 = live && (yl <= 7.f) && (yh >= 0.f);
+        ovy1 = live && (yl <= 15.f) && (yh >= 8.f);
+      } else {
+        ovx0 = ovx1 = ovy0 = ovy1 = true;  // degenerate conic: no culling, the exact per-pixel rule decides
+      }
+      ov0 = ovx0 && ovy0; ov1 = ovx1 && ovy0; ov2 = ovx0 && ovy1; ov3 = ovx1 && ovy1;
+      // where the backward pass finds this (Gaussian, tile) pair
+      const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
+      const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
+      const uint32_t local = (uint32_t)((tty - miny) * rw + (ttx - minx));
+      const uint32_t goff = g.block_tiles[id >> 8] + g.tileoff[id];
+      if (goff + local < N_cap) b.gslot[goff + local] = start + (uint32_t)i;
+      b.submask[start + i] = (uint8_t)((ov0 ? 1 : 0) | (ov1 ? 2 : 0) | (ov2 ? 4 : 0) | (ov3 ? 8 : 0));
+    }
+    const unsigned long long m0 = __ballot(ov0), m1 = __ballot(ov1), m2 = __ballot(ov2), m3 = __ballot(ov3);
+    if (lane == 0) {
+      wcnt[wv][0] = __popcll(m0); wcnt[wv][1] = __popcll(m1); wcnt[wv][2] = __popcll(m2); wcnt[wv][3] = __popcll(m3);
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t pre[4] = {run[0], run[1], run[2], run[3]};
+    for (int w2 = 0; w2 < wv; w2++) { pre[0] += wcnt[w2][0]; pre[1] += wcnt[w2][1]; pre[2] += wcnt[w2][2]; pre[3] += wcnt[w2][3]; }
+    const uint2 ent = make_uint2(id, (uint32_t)i);
+    if (ov0) sub[0 * len + pre[0] + __popcll(m0 & lt)] = ent;
+    if (ov1) sub[(size_t)1 * len + pre[1] + __popcll(m1 & lt)] = ent;
+    if (ov2) sub[(size_t)2 * len + pre[2] + __popcll(m2 & lt)] = ent;
+    if (ov3) sub[(size_t)3 * len + pre[3] + __popcll(m3 & lt)] = ent;
+    __syncthreads();
+    if (tid < 4) run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    __syncthreads();
+  }
+  if (tid < 4) iv.subcount[4 * tile + tid] = run[tid];
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)
@@ -183,6 +262,6 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
   if (P > 0)
     hipLaunchKernelGGL(scatter_keys_kernel, dim3((P + 255) / 256), dim3(256), (size_t)lds_tiles * 4, s, P, cam.gx, T, g, iv, b,
                        ncap, lds_tiles);
-  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, 0, iv, b, ncap);
-  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, SORT_CAP_SMALL, iv, b, ncap);
+  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap);
+  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap);
 }

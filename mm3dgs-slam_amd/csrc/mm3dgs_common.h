@@ -1,13 +1,19 @@
 // Internal definitions shared by the gfx950 kernels of libmm3dgs_hip.so.
 // Data layout in HBM (all caller-owned):
 //   geom_state   : Splat[P] (48 B packed AoS record, gathered by id in the compositor) | depth[P] | rect[P] (2x u32)
-//                  | clamped[P] (u8, SH clamp bits)
-//   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | final_T[H*W] | n_contrib[H*W]
-//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | point_list[N_cap] (u32)
-//   bwd scratch  : dsplat[P] (12 floats: dxy(2) dconic(3) dopacity(1) dcolor(6)) | campartial[ceil(P/256)][32]
+//                  | clamped[P] (u8, SH clamp bits) | tileoff[P] (u32, workgroup-local exclusive scan of tiles touched)
+//                  | block_tiles[ceil(P/256)+1] (u32, tiles touched per preprocess workgroup -> exclusive prefix)
+//   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | subcount[4T] | final_T[H*W] | n_contrib[H*W]
+//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | gslot[N_cap] (u32: for
+//                  Gaussian g's k-th tile, the slot of that pair in the tile bins) | sublist[4*N_cap] (uint2 {id, i}:
+//                  depth-ordered list of each 8x8 sub-tile; sub-tile w of a tile with bin [start,end) owns
+//                  [4*start + w*len, +subcount)) | submask[N_cap] (u8: which sub-tiles list the pair)
+//   bwd scratch  : dsub[4*N_cap] (12 floats: dxy(2) dconic(3) dopacity(1) dcolor(6); one record per (sub-tile, splat),
+//                  written once by the owning wave -- no atomics) | campartial[ceil(P/256)][32]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mm3dgs.h"
 
 #define TILE 16
@@ -22,10 +28,13 @@ struct GeomView {
   float* depth;       // [P]
   uint32_t* rect;     // [P][2]  (minx | miny<<16), (maxx | maxy<<16)
   uint8_t* clamped;   // [P]
+  uint32_t* tileoff;  // [P]
+  uint32_t* block_tiles;  // [ceil(P/256)+1]
 };
 static inline size_t geom_bytes_impl(int P) {
   size_t p = (size_t)P;
-  return align_up(p * SPLAT_F * 4, 256) + align_up(p * 4, 256) + align_up(p * 8, 256) + align_up(p, 256);
+  return align_up(p * SPLAT_F * 4, 256) + align_up(p * 4, 256) + align_up(p * 8, 256) + align_up(p, 256) +
+         align_up(p * 4, 256) + align_up(((p + 255) / 256 + 1) * 4, 256);
 }
 static inline GeomView geom_view(void* base, int P) {
   size_t p = (size_t)P;
@@ -34,7 +43,9 @@ static inline GeomView geom_view(void* base, int P) {
   g.splat = (float*)c;      c += align_up(p * SPLAT_F * 4, 256);
   g.depth = (float*)c;      c += align_up(p * 4, 256);
   g.rect = (uint32_t*)c;    c += align_up(p * 8, 256);
-  g.clamped = (uint8_t*)c;
+  g.clamped = (uint8_t*)c;  c += align_up(p, 256);
+  g.tileoff = (uint32_t*)c; c += align_up(p * 4, 256);
+  g.block_tiles = (uint32_t*)c;
   return g;
 }
 
@@ -43,6 +54,7 @@ struct ImageView {
   uint32_t* tile_count;  // [T]
   uint32_t* ranges;      // [T+1]
   uint32_t* cursor;      // [T]
+  uint32_t* subcount;    // [4T]
   float* final_T;        // [H*W]
   uint32_t* n_contrib;   // [H*W]
   size_t zero_bytes;     // hdr + tile_count: cleared at the start of every forward
@@ -51,8 +63,8 @@ static inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
-  return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(px * 4, 256) +
-         align_up(px * 4, 256);
+  return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * 16, 256) +
+         align_up(px * 4, 256) + align_up(px * 4, 256);
 }
 static inline ImageView image_view(void* base, int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
@@ -63,6 +75,7 @@ static inline ImageView image_view(void* base, int H, int W) {
   v.zero_bytes = (size_t)(c - (char*)base);
   v.ranges = (uint32_t*)c;      c += align_up((T + 1) * 4, 256);
   v.cursor = (uint32_t*)c;      c += align_up(T * 4, 256);
+  v.subcount = (uint32_t*)c;    c += align_up(T * 16, 256);
   v.final_T = (float*)c;        c += align_up(px * 4, 256);
   v.n_contrib = (uint32_t*)c;
   return v;
@@ -70,34 +83,40 @@ static inline ImageView image_view(void* base, int H, int W) {
 
 struct BinView {
   unsigned long long* keys;  // [N_cap]
-  uint32_t* point_list;      // [N_cap]
+  uint32_t* gslot;           // [N_cap]
+  uint2* sublist;            // [4*N_cap]
+  uint8_t* submask;          // [N_cap]
 };
 static inline size_t binning_bytes_impl(size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 8, 256) + align_up(N * 4, 256);
+  return align_up(N * 8, 256) + align_up(N * 4, 256) + align_up(N * 32, 256) + align_up(N, 256);
 }
 static inline BinView bin_view(void* base, size_t N) {
   if (N < 1) N = 1;
   char* c = (char*)base;
   BinView b;
   b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
-  b.point_list = (uint32_t*)c;
+  b.gslot = (uint32_t*)c;           c += align_up(N * 4, 256);
+  b.sublist = (uint2*)c;            c += align_up(N * 32, 256);
+  b.submask = (uint8_t*)c;
   return b;
 }
 
 struct BwdView {
-  float* dsplat;      // [P][12] screen-space gradient accumulators (zeroed at the start of every backward)
+  float* dsub;        // [4*N_cap][12] per-(sub-tile, splat) screen-space gradient records
   float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums
   int nrows;
 };
 static inline int bwd_rows(int P) { return (P + 255) / 256; }
-static inline size_t bwd_bytes_impl(int P) {
-  return align_up((size_t)(P > 0 ? P : 1) * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
+static inline size_t bwd_bytes_impl(int P, size_t N) {
+  if (N < 1) N = 1;
+  return align_up(N * 4 * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
 }
-static inline BwdView bwd_view(void* base, int P) {
+static inline BwdView bwd_view(void* base, int P, size_t N) {
+  if (N < 1) N = 1;
   char* c = (char*)base;
   BwdView b;
-  b.dsplat = (float*)c;  c += align_up((size_t)(P > 0 ? P : 1) * SPLAT_F * 4, 256);
+  b.dsub = (float*)c;  c += align_up(N * 4 * SPLAT_F * 4, 256);
   b.campartial = (float*)c;
   b.nrows = bwd_rows(P);
   return b;
@@ -109,11 +128,17 @@ struct CamDev {
   int H, W, gx, gy;
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int sh_degree;
+  int tilemap;  // 0: tile = workgroup id; 1: contiguous tile span per XCD
+  int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
   const float* bg;
   const float* view;
   const float* proj;
   const float* campos;
 };
+static inline int env_flag(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   CamDev d;
   d.H = c->image_height; d.W = c->image_width;
@@ -123,6 +148,8 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.focal_y = d.H / (2.0f * c->tanfovy);
   d.scale_modifier = c->scale_modifier;
   d.sh_degree = c->sh_degree;
+  d.tilemap = env_flag("MM3DGS_TILEMAP", 0);
+  d.stats = env_flag("MM3DGS_STATS", 0);
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
   return d;
 }
@@ -131,16 +158,17 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
 void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
                            const float* colors, const float* opac, const float* scales, const float* rots,
                            const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
-void launch_scan_tiles(int T, ImageView iv, hipStream_t s);
+void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s);
 void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
                          const int32_t* radii_or_null, hipStream_t s);
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
                           float* out_color, hipStream_t s);
 void launch_composite_bwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
-                          const float* dL_dout, float* dsplat, hipStream_t s);
+                          const float* dL_dout, float* dsub, hipStream_t s);
 void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
                            const float* colors, const float* opac, const float* scales, const float* rots,
-                           const float* cov3d, const int32_t* radii, GeomView g, BwdView bw, float* dmeans3D,
+                           const float* cov3d, const int32_t* radii, GeomView g, BinView b, size_t N_cap, BwdView bw,
+                           float* dmeans3D,
                            float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
                            float* drots, float* dcov3d, bool want_cam, int flags, hipStream_t s);
 void launch_camgrad_finish(BwdView bw, float* dview, float* dproj, float* dcampos, hipStream_t s);

@@ -231,6 +231,22 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   {
     const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
     const int w = maxx - minx, area = w * (maxy - miny);
+    {  // workgroup-local exclusive scan of tiles touched (start of this Gaussian's span in gslot)
+      __shared__ uint32_t wtot[PP_BLOCK / 64];
+      const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+      uint32_t x = (uint32_t)area;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (ln >= off) x += y;
+      }
+      if (ln == 63) wtot[wvi] = x;
+      __syncthreads();
+      uint32_t pre = 0;
+      for (int q = 0; q < wvi; q++) pre += wtot[q];
+      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
+      if (threadIdx.x == PP_BLOCK - 1) g.block_tiles[blockIdx.x] = pre + x;
+    }
     uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
     const int lane = threadIdx.x & 63;
     unsigned long long big = __ballot(area > 32);
@@ -275,8 +291,8 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
                       const float* __restrict__ shs, const float* __restrict__ colors,
                       const float* __restrict__ opac, const float* __restrict__ scales,
                       const float* __restrict__ rots, const float* __restrict__ cov3d,
-                      const int32_t* __restrict__ radii, GeomView g, const float* __restrict__ dsplat,
-                      float* __restrict__ campartial, float* __restrict__ dmeans3D, float* __restrict__ dmeans2D,
+                      const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
+                      const float* __restrict__ dsub, float* __restrict__ campartial, float* __restrict__ dmeans3D, float* __restrict__ dmeans2D,
                       float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac,
                       float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3d,
                       int want_cam, int flags) {
@@ -289,6 +305,56 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   const bool skip_g = (flags & MM3DGS_BWD_SKIP_GAUSSIAN_GRADS) != 0;
   const int nsh = shs ? 3 : 0;
   const int ne = C - nsh;
+  // ---- gather this Gaussian's screen-space gradient: sum of the records its (sub-tile, splat) pairs wrote, in a
+  // fixed order (deterministic).  A Gaussian covering more than 32 tiles is summed by the whole wave.
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
+  {
+    uint32_t goff = 0;
+    int area = 0;
+    if (idx < P && radii[idx] > 0) {
+      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+      area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
+      goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
+    }
+    auto add_pair = [&](uint32_t gi) {
+      if (gi >= N_cap) return;
+      const uint32_t slot = bn.gslot[gi];
+      if (slot >= N_cap) return;
+      const uint32_t m = bn.submask[slot];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        if (m & (1u << w)) {
+          const float4* r = (const float4*)(dsub + ((size_t)slot * 4 + w) * SPLAT_F);
+          const float4 a = r[0], b = r[1], c = r[2];
+          acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
+          acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
+          acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
+        }
+      }
+    };
+    if (area <= 32)
+      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k);
+    unsigned long long big = __ballot(area > 32);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int sarea = __builtin_amdgcn_readlane(area, src);
+      const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
+      const float4 k0 = acc0, k1 = acc1, k2 = acc2;  // keep this lane's own sum
+      acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
+      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k);
+      float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
+#pragma unroll
+      for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
+      if (lane == src) {
+        acc0 = make_float4(v[0], v[1], v[2], v[3]); acc1 = make_float4(v[4], v[5], v[6], v[7]);
+        acc2 = make_float4(v[8], v[9], v[10], v[11]);
+      } else {
+        acc0 = k0; acc1 = k1; acc2 = k2;
+      }
+    }
+  }
   if (idx < P) {
     float dmean[3] = {0.f, 0.f, 0.f};
     float gnx = 0.f, gny = 0.f;
@@ -297,8 +363,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     float dcol[MM3DGS_MAX_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool vis = radii[idx] > 0;
     if (vis) {
-      const float4* dsp = (const float4*)(dsplat + (size_t)idx * SPLAT_F);
-      float4 d0 = dsp[0], d1 = dsp[1], d2 = dsp[2];
+      float4 d0 = acc0, d1 = acc1, d2 = acc2;
       float gpx = d0.x, gpy = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
       dop = d1.y;
       dcol[0] = d1.z; dcol[1] = d1.w; dcol[2] = d2.x; dcol[3] = d2.y; dcol[4] = d2.z; dcol[5] = d2.w;
@@ -496,12 +561,13 @@ __global__ void camgrad_finish_kernel(const float* __restrict__ campartial, int 
 
 void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
                            const float* colors, const float* opac, const float* scales, const float* rots,
-                           const float* cov3d, const int32_t* radii, GeomView g, BwdView bw, float* dmeans3D,
-                           float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
+                           const float* cov3d, const int32_t* radii, GeomView g, BinView b, size_t N_cap, BwdView bw,
+                           float* dmeans3D, float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
                            float* drots, float* dcov3d, bool want_cam, int flags, hipStream_t s) {
   if (P <= 0) return;
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
-                     means3D, shs, colors, opac, scales, rots, cov3d, radii, g, bw.dsplat, bw.campartial, dmeans3D,
+                     means3D, shs, colors, opac, scales, rots, cov3d, radii, g, b,
+                     (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap), bw.dsub, bw.campartial, dmeans3D,
                      dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3d, want_cam ? 1 : 0, flags);
 }
 

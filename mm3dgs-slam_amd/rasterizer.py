@@ -64,8 +64,9 @@ def last_header():
     img = _last.get("img")
     if img is None:
         return None
-    h = img[:16].view(torch.int32).cpu()
-    return dict(num_rendered=int(h[0]), overflow=int(h[1]), max_tile_len=int(h[2]))
+    h = img[:32].view(torch.int32).cpu()
+    return dict(num_rendered=int(h[0]), overflow=int(h[1]), max_tile_len=int(h[2]), fwd_wave_iters=int(h[4]),
+                bwd_wave_iters=int(h[5]), bwd_wave_visits=int(h[6]))
 
 
 def set_binning_policy(mode: str = "exact", headroom: float = 1.5):
@@ -224,7 +225,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_view = torch.empty((4, 4), **f32) if need[8] else None
         d_proj = torch.empty((4, 4), **f32) if need[9] else None
         d_cpos = torch.empty((3,), **f32) if need[10] else None
-        scratch = torch.empty((lib.mm3dgs_backward_scratch_bytes(P),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((lib.mm3dgs_backward_scratch_bytes(P, n_cap),), dtype=torch.uint8, device=dev)
         flags = 0 if gaussian_side else 1
         with torch.cuda.device(dev):
             _lib.check(lib.mm3dgs_backward(

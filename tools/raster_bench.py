@@ -56,6 +56,8 @@ def f_only():
     with torch.no_grad(): fwd()
 def f_b():
     i, _ = fwd(); (i * w).sum().backward()
+if os.environ.get("MM3DGS_STATS"):
+    f_b(); torch.cuda.synchronize(); print("STATS", R.last_header()); sys.exit(0)
 tf = timeit(f_only, a.iters)
 tfb = timeit(f_b, a.iters)
 print(json.dumps(dict(P=a.P, H=a.H, W=a.W, C=a.C, policy=a.policy, fwd_ms=tf[0], fwd_wall_ms=tf[1], fwdbwd_ms=tfb[0], fwdbwd_wall_ms=tfb[1])))
