@@ -62,15 +62,13 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const float pxf = (float)px, pyf = (float)py;
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
   const uint32_t len = end - start;
-  const uint32_t count = len ? min(iv.subcount[4 * tile + wv], len) : 0u;
+  const uint32_t count = __builtin_amdgcn_readfirstlane(len ? min(iv.subcount[4 * tile + wv], len) : 0u);
   const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
 
-  __shared__ float4 sA[4][64];
-  __shared__ float4 sB[4][64];
-  __shared__ float4 sC[4][64];
-  float4* wA = sA[wv];
-  float4* wB = sB[wv];
-  float4* wC = sC[wv];
+  // wave-private, double-buffered staging: [buffer][wave][entry]
+  __shared__ float4 sA[2][4][64];
+  __shared__ float4 sB[2][4][64];
+  __shared__ float4 sC[2][4][64];
 
   float Tr = 1.f;
   float acc[C];
@@ -80,20 +78,26 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   bool done = !inside;
   uint32_t n_iter = 0;
 
-  // pipeline prologue: ids of chunks 0 and 1, records of chunk 0
-  uint32_t id_cur = lane < count ? list[lane].x : 0u;
+  // pipeline prologue: chunk 0 parked in LDS buffer 0, ids of chunk 1 in registers
+  {
+    const uint32_t id0 = lane < count ? list[lane].x : 0u;
+    const SplatRec r0 = load_rec<C>(g.splat, id0, lane < count);
+    sA[0][wv][lane] = r0.A;
+    sB[0][wv][lane] = r0.B;
+    if (C > 2) sC[0][wv][lane] = r0.C;
+  }
   uint32_t id_nxt = 64u + lane < count ? list[64u + lane].x : 0u;
-  SplatRec rec = load_rec<C>(g.splat, id_cur, lane < count);
+  int cur = 0;
 
-  for (uint32_t base = 0; base < count; base += 64) {
-    // issue the gathers for the following chunks before touching this one
+  for (uint32_t base = 0; base < count; base += 64, cur ^= 1) {
+    // issue the gathers for the following chunks before touching this one; they land while it is composited
     const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + 64u + lane < count);
     const uint32_t id_nn = base + 128u + lane < count ? list[base + 128u + lane].x : 0u;
-    wA[lane] = rec.A;
-    wB[lane] = rec.B;
-    if (C > 2) wC[lane] = rec.C;
+    const float4* wA = sA[cur][wv];
+    const float4* wB = sB[cur][wv];
+    const float4* wC = sC[cur][wv];
     __builtin_amdgcn_wave_barrier();
-    const int cnt = (int)min(64u, count - base);
+    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, count - base));
     float4 A = wA[0], B = wB[0], Cc = wC[0];
     for (int j = 0; j < cnt; j++) {
       const int jn = j + 1 < cnt ? j + 1 : j;
@@ -119,8 +123,9 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       A = nA; B = nB; Cc = nC;
     }
     if (__ballot(!done) == 0ull) break;
-    __builtin_amdgcn_wave_barrier();
-    rec = rec_n;
+    sA[cur ^ 1][wv][lane] = rec_n.A;
+    sB[cur ^ 1][wv][lane] = rec_n.B;
+    if (C > 2) sC[cur ^ 1][wv][lane] = rec_n.C;
     id_nxt = id_nn;
   }
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
@@ -136,7 +141,7 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 // ---- multi-value wave reduction ---------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_all(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 #define QP_XOR1 0xB1   // quad_perm:[1,0,3,2]
 #define QP_XOR2 0x4E   // quad_perm:[2,3,0,1]
@@ -217,19 +222,15 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const float pxf = (float)px, pyf = (float)py;
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
   const uint32_t len = end - start;
-  const uint32_t count = len ? min(iv.subcount[4 * tile + wv], len) : 0u;
+  const uint32_t count = __builtin_amdgcn_readfirstlane(len ? min(iv.subcount[4 * tile + wv], len) : 0u);
   if (count == 0) return;  // wave-uniform
   const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
 
   constexpr int NV = 6 + C;
-  __shared__ float4 sA[4][64];
-  __shared__ float4 sB[4][64];
-  __shared__ float4 sC[4][64];
-  __shared__ uint32_t sI[4][64];
-  float4* wA = sA[wv];
-  float4* wB = sB[wv];
-  float4* wC = sC[wv];
-  uint32_t* wI = sI[wv];
+  __shared__ float4 sA[2][4][64];
+  __shared__ float4 sB[2][4][64];
+  __shared__ float4 sC[2][4][64];
+  __shared__ uint32_t sI[2][4][64];
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   const float T_final = inside ? iv.final_T[pix] : 0.f;
@@ -262,22 +263,31 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   if (todo == 0) return;
 
   const int my_slot = (lane < 16) ? WaveReduce<NV>::slot(lane) : -1;
+  // this lane's component of record 0 of this sub-tile; record of tile-list entry i is 192 B further per i
+  float* const my_rec = dsub + ((size_t)start * 4 + wv) * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
 
   // chunk c holds list entries todo-1-(64c+lane): lane order == traversal order (back to front)
-  uint2 ent_cur = lane < todo ? list[todo - 1u - lane] : make_uint2(0u, 0u);
+  {
+    const uint2 e0 = lane < todo ? list[todo - 1u - lane] : make_uint2(0u, 0u);
+    const SplatRec r0 = load_rec<C>(g.splat, e0.x, lane < todo);
+    sA[0][wv][lane] = r0.A;
+    sB[0][wv][lane] = r0.B;
+    if (C > 2) sC[0][wv][lane] = r0.C;
+    sI[0][wv][lane] = e0.y;
+  }
   uint2 ent_nxt = 64u + lane < todo ? list[todo - 1u - (64u + lane)] : make_uint2(0u, 0u);
-  SplatRec rec = load_rec<C>(g.splat, ent_cur.x, lane < todo);
+  int cur = 0;
 
-  for (uint32_t base = 0; base < todo; base += 64) {
+  for (uint32_t base = 0; base < todo; base += 64, cur ^= 1) {
     const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + 64u + lane < todo);
     const uint2 ent_nn = base + 128u + lane < todo ? list[todo - 1u - (base + 128u + lane)] : make_uint2(0u, 0u);
-    wA[lane] = rec.A;
-    wB[lane] = rec.B;
-    if (C > 2) wC[lane] = rec.C;
-    wI[lane] = ent_cur.y;
+    const float4* wA = sA[cur][wv];
+    const float4* wB = sB[cur][wv];
+    const float4* wC = sC[cur][wv];
+    const uint32_t* wI = sI[cur][wv];
     __builtin_amdgcn_wave_barrier();
-    const int cnt = (int)min(64u, todo - base);
+    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, todo - base));
     float4 A = wA[0], B = wB[0], Cc = wC[0];
     uint32_t ti = wI[0];
     for (int j = 0; j < cnt; j++) {
@@ -327,12 +337,13 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
       }
       // this wave is the only writer of the (sub-tile, splat) record: 12 lanes store 48 contiguous bytes
-      if (my_slot >= 0) dsub[(((size_t)start + ti) * 4 + wv) * SPLAT_F + my_slot] = tot;
+      if (my_slot >= 0) my_rec[(size_t)ti * (4 * SPLAT_F)] = tot;
       A = nA; B = nB; Cc = nC; ti = nti;
     }
-    __builtin_amdgcn_wave_barrier();
-    rec = rec_n;
-    ent_cur = ent_nxt;
+    sA[cur ^ 1][wv][lane] = rec_n.A;
+    sB[cur ^ 1][wv][lane] = rec_n.B;
+    if (C > 2) sC[cur ^ 1][wv][lane] = rec_n.C;
+    sI[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   if (cam.stats && lane == 0) {
