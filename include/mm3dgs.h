@@ -15,7 +15,8 @@
  *   - float32 everywhere, row-major; matrices use the reference's row-vector convention
  *     (p_view = [p,1] * viewmatrix, slam/renderer.py:117-124).
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no entry point synchronises the
- *     host except mm3dgs_forward_exact(), which reads one int back (documented there).
+ *     host.  A caller that wants an exactly-sized binning buffer runs stage 1, waits for `host_num_rendered`
+ *     itself, then runs stage 2 (this is what the Python shim's "exact" policy does).
  *   - return value: 0 on success, negative on error; mm3dgs_last_error() returns a thread-local message.
  */
 #ifndef MM3DGS_H
@@ -113,6 +114,19 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
 
 /* visible[P] (uint8) = z_view > 0.2 -- the lineage's markVisible. */
 int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream);
+
+/* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
+ * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
+ * launches and their summed duration since the previous read, and resets the counters. */
+#define MM3DGS_PROF_PREPROCESS_FWD 0
+#define MM3DGS_PROF_SCAN 1
+#define MM3DGS_PROF_BIN_SORT 2
+#define MM3DGS_PROF_COMPOSITE_FWD 3
+#define MM3DGS_PROF_COMPOSITE_BWD 4
+#define MM3DGS_PROF_PREPROCESS_BWD 5
+#define MM3DGS_PROF_KERNELS 6
+void mm3dgs_profile_enable(int on);
+int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 
 const char* mm3dgs_last_error(void);
 int mm3dgs_version(void);

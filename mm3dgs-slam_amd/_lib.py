@@ -36,6 +36,8 @@ _SIGS = {
     "mm3dgs_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 11 + [C.c_size_t]
                         + [_P] * 13 + [C.c_int, _P]),
     "mm3dgs_mark_visible": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, _P, _P, _P]),
+    "mm3dgs_profile_enable": (None, [C.c_int]),
+    "mm3dgs_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "mm3dgs_last_error": (C.c_char_p, []),
     "mm3dgs_version": (C.c_int, []),
 }
@@ -63,6 +65,24 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
+
+
+def profile_enable(on: bool):
+    load().mm3dgs_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{kernel: (launches, total_ms)} since the previous read (waits for the recorded events)."""
+    lib = load()
+    out = {}
+    for k, name in enumerate(PROF_KERNELS):
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        check(lib.mm3dgs_profile_read(k, C.byref(n), C.byref(ms)))
+        out[name] = (int(n.value), float(ms.value))
+    return out
 
 
 def check(rc: int):

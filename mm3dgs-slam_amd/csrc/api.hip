@@ -19,7 +19,52 @@ static int check_launch(const char* what) {
   return 0;
 }
 
+// ---- optional per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg) -------------------
+#include <mutex>
+#include <vector>
+struct KernelProfile {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  unsigned long long launches = 0;
+  double total_ms = 0.0;
+};
+static KernelProfile g_prof[MM3DGS_PROF_KERNELS];
+static std::mutex g_prof_mu;
+static int g_prof_on = 0;
+struct ProfScope {
+  int k; hipStream_t s; hipEvent_t e1 = nullptr; bool on;
+  ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on != 0) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!g_prof[k].pool.empty()) { ev = g_prof[k].pool.back(); g_prof[k].pool.pop_back(); }
+    else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+    g_prof[k].pending.push_back(ev);
+    e1 = ev.second;
+    (void)hipEventRecord(ev.first, s);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(e1, s); }
+};
+
 extern "C" {
+
+void mm3dgs_profile_enable(int on) { g_prof_on = on; }
+int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
+  if (kernel < 0 || kernel >= MM3DGS_PROF_KERNELS) return fail(-1, "bad kernel id %d", kernel);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  KernelProfile& p = g_prof[kernel];
+  for (auto& ev : p.pending) {
+    if (hipEventSynchronize(ev.second) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { p.total_ms += ms; p.launches++; }
+    }
+    p.pool.push_back(ev);
+  }
+  p.pending.clear();
+  if (launches) *launches = p.launches;
+  if (total_ms) *total_ms = p.total_ms;
+  p.launches = 0; p.total_ms = 0.0;
+  return 0;
+}
 
 const char* mm3dgs_last_error(void) { return g_err; }
 int mm3dgs_version(void) { return 100; }
@@ -62,8 +107,9 @@ int mm3dgs_forward_geom(const Mm3dgsCamera* cam, int P, int M, int C, const floa
   GeomView g = geom_view(geom_state, P > 0 ? P : 1);
   ImageView iv = image_view(image_state, cd.H, cd.W);
   if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
-  launch_preprocess_fwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, iv, s);
-  launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s);
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s);
+    launch_preprocess_fwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, iv, s); }
+  { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
   if (host_num_rendered)
     if (hipMemcpyAsync(host_num_rendered, &iv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess)
       return fail(-10, "num_rendered copy failed");
@@ -79,8 +125,8 @@ int mm3dgs_forward_raster(const Mm3dgsCamera* cam, int P, int C, const void* geo
   GeomView g = geom_view((void*)geom_state, P > 0 ? P : 1);
   ImageView iv = image_view(image_state, cd.H, cd.W);
   BinView b = bin_view(binning_state, N_capacity);
-  launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s);
-  launch_composite_fwd(cd, C, g, iv, b, N_capacity, out_color, s);
+  { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s); }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_composite_fwd(cd, C, g, iv, b, N_capacity, out_color, s); }
   return check_launch("forward_raster");
 }
 
@@ -112,7 +158,8 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
   ImageView iv = image_view((void*)image_state, cd.H, cd.W);
   BinView b = bin_view((void*)binning_state, N_capacity);
   BwdView bw = bwd_view(backward_scratch, P, N_capacity);
-  launch_composite_bwd(cd, C, g, iv, b, N_capacity, dL_dout, bw.dsub, s);
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd(cd, C, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
+  ProfScope ps_pb(MM3DGS_PROF_PREPROCESS_BWD, s);
   bool want_cam = dL_dview || dL_dproj || dL_dcampos;
   launch_preprocess_bwd(cd, P, M, C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g, b,
                         N_capacity, bw, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations,

@@ -48,10 +48,11 @@ class GaussianRasterizationSettings(NamedTuple):
 # ---------------------------------------------------------------------------------------------------------------------
 # binning capacity policy
 #   "exact": stage 1 -> read num_rendered back (one 4-byte D2H + stream sync, as the lineage does) -> exact buffer.
-#   "async": no host sync; capacity = headroom x the largest num_rendered seen so far for this (H, W, P-bucket); the
-#            count of every call lands in pinned memory asynchronously and is checked on the NEXT call.  An overflow
-#            raises then (the overflowing render itself was incomplete but memory-safe) and the capacity is grown.
-_policy = {"mode": "exact", "headroom": 1.5}
+#   "async": no host sync; capacity = headroom x P x the largest pairs-per-Gaussian ratio seen for this image size (the first
+#            call for a size is sized exactly); the count of every call lands in pinned memory asynchronously and is
+#            checked on the NEXT call.  An overflow raises then (the overflowing render itself was incomplete but
+#            memory-safe) and the capacity is grown.
+_policy = {"mode": "exact", "headroom": 2.0}
 _capacity_cache = {}
 _pending = []  # [(event, pinned_hdr, capacity, key)]
 
@@ -69,7 +70,7 @@ def last_header():
                 bwd_wave_iters=int(h[5]), bwd_wave_visits=int(h[6]))
 
 
-def set_binning_policy(mode: str = "exact", headroom: float = 1.5):
+def set_binning_policy(mode: str = "exact", headroom: float = 2.0):
     if mode not in ("exact", "async"):
         raise ValueError("mode must be 'exact' or 'async'")
     _policy["mode"] = mode
@@ -117,19 +118,19 @@ def _stream():
 
 def _drain_pending(block: bool = False):
     keep = []
-    for ev, hdr, cap, key in _pending:
+    for ev, hdr, cap, (key, npts) in _pending:
         if block:
             ev.synchronize()
         if ev.query():
             n = int(hdr[0])
-            _capacity_cache[key] = max(_capacity_cache.get(key, 0), n)
+            _capacity_cache[key] = max(_capacity_cache.get(key, 0.0), n / npts)
             if n > cap:
                 _pending.clear()
                 raise RuntimeError(
                     f"mm3dgs: an earlier async render overflowed its binning capacity ({n} > {cap}); that image was "
                     f"incomplete. Capacity has been raised; re-render, or use set_binning_policy('exact').")
         else:
-            keep.append((ev, hdr, cap, key))
+            keep.append((ev, hdr, cap, (key, npts)))
     _pending[:] = keep
 
 
@@ -167,23 +168,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (P, M, Cn, _ptr(means3D), _ptr(shs), _ptr(colors_precomp), _ptr(opacities), _ptr(scales), _ptr(rotations),
                 _ptr(cov3D_precomp))
         with torch.cuda.device(dev):
-            if _policy["mode"] == "exact":
+            key = (H, W)
+            if _policy["mode"] == "async":
+                _drain_pending()
+            seen = _capacity_cache.get(key)
+            if _policy["mode"] == "exact" or seen is None:
+                # exact sizing (also the first async call for an image size, to learn N): one 4-byte read-back
                 host_n = torch.empty((4,), dtype=torch.int32).pin_memory()
                 _lib.check(lib.mm3dgs_forward_geom(C.byref(cam), *args, _ptr(radii), _ptr(geom), _ptr(img),
                                                    C.c_void_p(host_n.data_ptr()), st))
                 torch.cuda.current_stream().synchronize()
                 n_cap = max(int(host_n[0]), 1)
+                _capacity_cache[key] = max(seen or 0.0, n_cap / max(P, 1))     # pairs per Gaussian
                 binning = torch.empty((lib.mm3dgs_binning_bytes(n_cap),), **u8)
                 _lib.check(lib.mm3dgs_forward_raster(C.byref(cam), P, Cn, _ptr(geom), _ptr(img), _ptr(binning), n_cap,
                                                      _ptr(out), st))
             else:
-                _drain_pending()
-                key = (H, W, P >> 12)
-                seen = _capacity_cache.get(key)
-                if seen is None:
-                    n_cap = max(64 * P, 1 << 20)          # first call for this shape: generous, then it adapts
-                else:
-                    n_cap = max(int(seen * _policy["headroom"]) + 4096, 1)
+                n_cap = int(seen * max(P, 1) * _policy["headroom"]) + 65536
                 binning = torch.empty((lib.mm3dgs_binning_bytes(n_cap),), **u8)
                 _lib.check(lib.mm3dgs_forward(C.byref(cam), *args, _ptr(out), _ptr(radii), _ptr(geom), _ptr(img),
                                               _ptr(binning), n_cap, st))
@@ -191,7 +192,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 hdr.copy_(img[:16].view(torch.int32), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                _pending.append((ev, hdr, n_cap, key))
+                _pending.append((ev, hdr, n_cap, (key, max(P, 1))))
         _last["img"] = img
         ctx.rs = rs
         ctx.dims = (P, M, Cn, n_cap)

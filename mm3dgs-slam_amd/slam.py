@@ -1,0 +1,119 @@
+"""Frame loop: load -> track -> map (reference ``slam/SLAM.py:375-493``), over an in-memory RGB-D sequence.
+
+Only the hot-path part of the reference's orchestrator is mirrored: frame 0 takes the ground-truth pose
+(``SLAM.py:399-401``), later frames are tracked, ``camera_extent = max(depth) / scene_radius_depth_ratio`` is fixed on
+frame 0 (``:456-463``), then the mapper runs.  Dataset loaders, MiDaS depth alignment, video/checkpoint output and the
+evaluation metrics are out of scope."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import synthetic
+from .gaussian_model import GaussianModel
+from .mapper import Mapper
+from .pose_utils import get_camera_from_tensor, get_tensor_from_camera
+from .renderer import Renderer
+from .tracker import Tracker
+
+
+def trajectory(n, step_t=0.01, step_r=0.008):
+    """Smooth 6-DoF sinusoid, <= ~2 cm / 1 degree per frame.  Returns n 4x4 world->camera matrices."""
+    out = []
+    for i in range(n):
+        a = i / 7.0
+        rx, ry, rz = step_r * 2 * math.sin(a), step_r * 3 * math.sin(0.7 * a + 0.3), step_r * math.sin(1.3 * a)
+        M = torch.eye(4)
+        cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+        Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        M[:3, :3] = Rz @ Ry @ Rx
+        M[:3, 3] = torch.tensor([step_t * 3 * math.sin(0.9 * a), step_t * 2 * math.sin(0.5 * a + 1.0), step_t * 2 * (1 - math.cos(0.6 * a))])
+        out.append(M)
+    return out
+
+
+class SyntheticSequence:
+    """RGB-D frames rendered from a fixed ground-truth Gaussian map along ``trajectory`` (built once, untimed).
+    The ground-truth map is the seeded first frame of ``synthetic.rgbd_frame``."""
+
+    def __init__(self, cfg, n_frames, n_gaussians, seed=0, renderer=None):
+        dev = cfg["device"]
+        H, W = int(cfg["desired_height"]), int(cfg["desired_width"])
+        c = cfg["cam"]
+        color, depth = synthetic.rgbd_frame(H, W, seed=seed)
+        G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], n_gaussians, seed=seed)
+        self.seed_params = {k: v.to(dev) for k, v in G.items()}
+        self.poses = [get_tensor_from_camera(M).to(dev) for M in trajectory(n_frames)]
+        self.frames = []
+        renderer = renderer or Renderer(cfg)
+        gt = _FixedMap(self.seed_params, cfg, opaque=True)
+        with torch.no_grad():
+            for p in self.poses:
+                r = renderer.render(gt, p)
+                sil = r["depth"][1]
+                d = torch.where(sil > 0.5, r["depth"][0] / sil.clamp_min(1e-6), torch.zeros_like(sil))
+                self.frames.append((r["render"].clamp(0, 1).contiguous(), d.contiguous()))
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        color, depth = self.frames[i]
+        return color, depth, self.poses[i]
+
+
+class _FixedMap:
+    """Minimal GaussianModel-shaped holder for rendering a parameter dict."""
+
+    def __init__(self, G, cfg, opaque=False):
+        self.active_sh_degree = 0
+        self.max_sh_degree = cfg["mapping"]["sh_degree"]
+        self._xyz, self._scaling, self._rotation = G["xyz"], G["scaling"], G["rotation"]
+        self.get_xyz = G["xyz"]
+        self.get_opacity = torch.full_like(G["opacity"], 0.98) if opaque else torch.sigmoid(G["opacity"])
+        self.get_scaling = torch.exp(G["scaling"])
+        self.get_rotation = torch.nn.functional.normalize(G["rotation"])
+        n_rest = (self.max_sh_degree + 1) ** 2 - 1
+        self.get_features = torch.cat([G["f_dc"], torch.zeros(G["f_dc"].shape[0], n_rest, 3, device=G["f_dc"].device)], 1)
+
+
+class SLAM:
+    def __init__(self, cfg, sequence, rasterizer_cls=None, settings_cls=None, render_mode="fused", window=None):
+        self.cfg = cfg
+        self.seq = sequence
+        self.gaussians = GaussianModel(cfg)
+        self.gaussians.training_setup()
+        self.renderer = Renderer(cfg, rasterizer_cls=rasterizer_cls, settings_cls=settings_cls, mode=render_mode)
+        n = len(sequence)
+        self.estimate_pose_list = [None] * n
+        self.tracker = Tracker(cfg, self.gaussians, self.renderer, self.estimate_pose_list)
+        self.mapper = Mapper(cfg, self.gaussians, self.renderer, self.estimate_pose_list, n_img=n, window=window)
+
+    def step(self, idx):
+        """Track + map one frame (the unit the headline metric counts)."""
+        color, depth, gt_pose = self.seq[idx]
+        if idx == 0 or self.cfg["tracking"]["use_gt_pose"]:
+            self.estimate_pose_list[idx] = gt_pose.clone()
+        else:
+            self.tracker.run_frame(idx, color, depth, depth)
+        if idx == 0:
+            self.mapper.camera_extent = float(depth.max()) / self.cfg["scene_radius_depth_ratio"]
+        self.mapper.run_frame(idx, color, depth, depth)
+
+    def run(self):
+        for idx in range(len(self.seq)):
+            self.step(idx)
+
+    def pose_errors(self):
+        """Translation error (m) of every estimated pose against the sequence's ground truth."""
+        errs = []
+        for est, gt in zip(self.estimate_pose_list, self.seq.poses):
+            if est is None:
+                continue
+            a = torch.linalg.inv(get_camera_from_tensor(est))[:3, 3]
+            b = torch.linalg.inv(get_camera_from_tensor(gt))[:3, 3]
+            errs.append(float((a - b).norm()))
+        return errs

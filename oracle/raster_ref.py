@@ -302,7 +302,9 @@ class RefRasterizer(torch.nn.Module):
         return z > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, extra_channels=None):
+        if extra_channels is not None:
+            colors_precomp = extra_channels if colors_precomp is None else torch.cat([colors_precomp, extra_channels], 1)
         rs = self.raster_settings
         s = RefSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), rs.bg,
                         float(rs.scale_modifier), rs.viewmatrix, rs.projmatrix, int(rs.sh_degree), rs.campos,

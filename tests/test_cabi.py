@@ -1,0 +1,48 @@
+"""The C-ABI library: every symbol include/mm3dgs.h declares is exported, sizes are sane.  No compute (no GPU here)."""
+import os
+import re
+
+import pytest
+
+from mm3dgs_slam_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "mm3dgs.h")).read()
+    return sorted(set(re.findall(r"\b(mm3dgs_[a-z_]+)\s*\(", h)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = _lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.mm3dgs_version() >= 100
+    assert lib.mm3dgs_geom_bytes(1000) >= 1000 * 48
+    assert lib.mm3dgs_image_bytes(480, 640) >= 480 * 640 * 8
+    assert lib.mm3dgs_binning_bytes(1000) >= 1000 * 45
+    assert lib.mm3dgs_backward_scratch_bytes(1000, 5000) >= 5000 * 4 * 48
+    assert lib.mm3dgs_last_error() is not None
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from mm3dgs_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    z = torch.zeros(4, 3)
+    rs = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="no CPU rasterizer"):
+        GaussianRasterizer(rs)(means3D=z, means2D=z, opacities=z[:, :1], colors_precomp=z, scales=z, rotations=torch.zeros(4, 4))
+
+
+def test_drop_in_module_name():
+    import diff_gaussian_rasterization as d
+    assert d.GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
+                                                       "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")

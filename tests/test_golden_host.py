@@ -1,0 +1,116 @@
+"""Host-side mirrors vs fixtures produced by the reference's own helpers (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mm3dgs_slam_amd import general_utils, graphics_utils, pose_utils, sh_utils
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) if v.dtype != object else v for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def close(a, b, tol=1e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
+
+
+def test_g1_pose_algebra():
+    d = load("g1_pose.npz")
+    poses = d["poses"]
+    close(torch.stack([pose_utils.get_camera_from_tensor(p) for p in poses]), d["w2c"])
+    close(torch.stack([pose_utils.get_tensor_from_camera(m) for m in d["w2c"]]), d["back"])
+    close(pose_utils.quadmultiply(poses[:32, :4], poses[32:, :4]), d["qmul"])
+    close(torch.stack([pose_utils.propagate_const_vel(poses[i], poses[i + 1]) for i in range(32)]), d["const_vel"], 2e-5)
+    grads = []
+    for p in poses[:16]:
+        q = p.clone().requires_grad_(True)
+        (pose_utils.get_camera_from_tensor(q) * torch.arange(16.0).reshape(4, 4)).sum().backward()
+        grads.append(q.grad)
+    close(torch.stack(grads), d["dpose"], 2e-5)
+
+
+def test_g2_imu_propagation_and_euler():
+    d = load("g2_imu.npz")
+    close(torch.stack([pose_utils.euler_matrix(*a) for a in d["euler_in"]]), d["euler_out"])
+    out = pose_utils.propagate_imu(d["camm1"], d["camm2"], d["imu"].clone(), d["c2i"], 1.0 / 30.0, 1.0 / 100.0)
+    close(out, d["out"], 2e-5)
+
+
+def test_g3_spherical_harmonics():
+    d = load("g3_sh.npz")
+    for deg in range(5):
+        close(sh_utils.eval_sh(deg, d["sh"], d["dirs"]), d[f"deg{deg}"])
+    close(sh_utils.RGB2SH(d["rgb"]), d["rgb2sh"])
+    close(sh_utils.SH2RGB(d["rgb"]), d["sh2rgb"])
+
+
+def test_g4_projection_matrix():
+    d = load("g4_proj.npz")
+    for row, P in zip(d["intr"], d["P"]):
+        close(graphics_utils.getProjectionMatrix2(0.01, 100.0, *[float(v) for v in row[:4]], int(row[4]), int(row[5])), P)
+
+
+def test_g5_covariance_helpers():
+    d = load("g5_cov.npz")
+    L = general_utils.build_scaling_rotation(d["s"], d["r"])
+    close(L, d["L"])
+    close(general_utils.strip_symmetric(L @ L.transpose(1, 2)), d["cov6"])
+    close(general_utils.build_rotation(d["r"]), d["R"])
+    close(general_utils.inverse_sigmoid(d["inv_sig_in"]), d["inv_sig"])
+
+
+class _Recorder:
+    calls = []
+
+    def __init__(self, raster_settings):
+        self.rs = raster_settings
+
+    def __call__(self, **kw):
+        _Recorder.calls.append((self.rs, kw))
+        P = kw["means3D"].shape[0]
+        return torch.zeros(3, self.rs.image_height, self.rs.image_width), torch.ones(P, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("tm", [True, False])
+@pytest.mark.parametrize("iso", [True, False])
+def test_g6_renderer_glue_feeds_the_rasterizer_what_the_reference_does(tm, iso):
+    """Our Renderer (reference two-pass mode) must hand the rasterizer the same matrices and tensors as
+    slam/renderer.py does for the same model and pose."""
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    from mm3dgs_slam_amd.renderer import Renderer
+    d = load("g6_glue.npz")
+    cfg = {"device": "cpu", "desired_height": 48, "desired_width": 64, "white_background": False,
+           "cam": {"fx": 51.73, "fy": 51.65, "cx": 31.86, "cy": 25.53}, "mapping": {"sh_degree": 0},
+           "pipeline": {"convert_SHs_python": False, "compute_cov3D_python": False, "transform_means_python": tm,
+                        "force_isotropic": iso}}
+    pc = GaussianModel(cfg)
+    pc._xyz, pc._features_dc, pc._opacity = d["xyz"], d["f_dc"], d["opacity"]
+    pc._features_rest = torch.zeros(d["xyz"].shape[0], 0, 3)
+    pc._scaling, pc._rotation = d["scaling"], d["rotation"]
+    _Recorder.calls = []
+    Renderer(cfg, rasterizer_cls=_Recorder, mode="reference").render(pc, d["pose"])
+    (rs, kw1), (_, kw2) = _Recorder.calls
+    tag = f"tm{int(tm)}_iso{int(iso)}"
+    close(rs.viewmatrix, d[f"{tag}_view"]); close(rs.projmatrix, d[f"{tag}_proj"]); close(rs.campos, d[f"{tag}_campos"], 1e-4)
+    close(torch.tensor([rs.tanfovx, rs.tanfovy]), d[f"{tag}_tanfov"])
+    close(kw1["means3D"], d[f"{tag}_means3D"]); close(kw1["scales"], d[f"{tag}_scales"])
+    close(kw1["rotations"], d[f"{tag}_rotations"]); close(kw1["opacities"], d[f"{tag}_opacities"])
+    close(kw1["shs"], d[f"{tag}_shs"]); close(kw2["colors_precomp"], d[f"{tag}_depthsil"], 2e-5)
+    assert kw2.get("shs") is None
+
+
+def test_g7_seeding_pointcloud():
+    from mm3dgs_slam_amd.mapper import Mapper
+    d = load("g7_seed.npz")
+    fx, fy, cx, cy = [float(v) for v in d["intr"]]
+    m = Mapper.__new__(Mapper)
+    m.cfg = {"cam": {"fx": fx, "fy": fy, "cx": cx, "cy": cy}}
+    mask = (d["depth"] > 0).reshape(-1)
+    cld, msd = m.get_pointcloud(d["color"], d["depth"], pose_utils.get_camera_from_tensor(d["pose"]), mask=mask)
+    close(cld, d["cld"], 2e-5); close(msd, d["msd"]); close(torch.log(torch.sqrt(msd)), d["log_scale"])

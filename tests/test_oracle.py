@@ -1,0 +1,96 @@
+"""The CPU oracle itself: second statement of the compositing rule, finite-difference check of autograd, and the
+three straight-through conventions."""
+import torch
+
+from oracle.raster_ref import RefSettings, dense_render_ref, rasterize_ref
+from tests import parity_util as pu
+
+
+def _settings(case, dt=torch.float64):
+    return RefSettings(case["H"], case["W"], case["tanx"], case["tany"], case["bg"].to(dt), case["scale_modifier"],
+                       case["view"].to(dt), case["proj"].to(dt), case["sh_degree"], case["campos"].to(dt))
+
+
+def test_tiled_composite_equals_explicit_pixel_loop():
+    case = pu.make_case(P=250, H=40, W=56, seed=3, posed=True)
+    s = _settings(case)
+    img, _ = rasterize_ref(case["means3D"], None, case["opacities"], None, case["colors"], case["scales"], case["rotations"], None, s)
+    ref = dense_render_ref(case["means3D"], case["opacities"], case["colors"], case["scales"], case["rotations"], s)
+    assert (img - ref).abs().max() < 1e-12
+
+
+def test_autograd_matches_finite_differences():
+    # sparse scene: no pixel saturates, so the T<1e-4 stop (a genuine discontinuity) is not crossed by the probe
+    case = pu.make_case(P=40, H=32, W=32, seed=4, posed=True, log_scale=-2.8)
+    w = pu.loss_weights((3, 32, 32), 5)
+
+    def loss(means, scales, opac, view):
+        s = RefSettings(32, 32, case["tanx"], case["tany"], case["bg"], 1.0, view, view @ (torch.linalg.inv(case["view"]) @ case["proj"]), 0, case["campos"])
+        img, _ = rasterize_ref(means, None, opac, None, case["colors"], scales, case["rotations"], None, s)
+        return (img * w).sum()
+
+    args = [case["means3D"].clone().requires_grad_(True), case["scales"].clone().requires_grad_(True),
+            case["opacities"].clone().requires_grad_(True), case["view"].clone().requires_grad_(True)]
+    loss(*args).backward()
+    g = torch.Generator().manual_seed(0)
+    for i, a in enumerate(args):
+        d = torch.randn(a.shape, generator=g, dtype=torch.float64)
+        eps = 2e-7
+        with torch.no_grad():
+            plus = [x.detach() + (eps * d if j == i else 0) for j, x in enumerate(args)]
+            minus = [x.detach() - (eps * d if j == i else 0) for j, x in enumerate(args)]
+            fd = (loss(*plus) - loss(*minus)) / (2 * eps)
+        an = (a.grad * d).sum()
+        assert abs(fd - an) <= 2e-4 * max(1.0, abs(an)), (i, float(fd), float(an))
+
+
+def test_alpha_clamp_is_straight_through():
+    # one opaque splat in the middle of a 16x16 image: o*G > 0.99 at the centre, gradient wrt opacity must not vanish
+    dt = torch.float64
+    means = torch.tensor([[0.0, 0.0, 1.0]], dtype=dt)
+    view = torch.eye(4, dtype=dt)
+    from mm3dgs_slam_amd.synthetic import camera_matrices
+    v, p, c, tx, ty = camera_matrices(16, 16, 16.0, 16.0, cx=7.5, cy=7.5, dtype=dt)
+    s = RefSettings(16, 16, tx, ty, torch.zeros(3, dtype=dt), 1.0, v, p, 0, c)
+    op = torch.tensor([[0.999]], dtype=dt, requires_grad=True)
+    img, radii = rasterize_ref(means, None, op, None, torch.ones(1, 3, dtype=dt), torch.full((1, 3), 0.2, dtype=dt),
+                               torch.tensor([[1.0, 0, 0, 0]], dtype=dt), None, s)
+    assert abs(float(img.detach().max()) - 0.99) < 1e-9      # clamped at the centre pixel
+    img.max().backward()
+    assert op.grad.abs().item() > 0.5
+
+
+def test_frustum_clamp_treats_clamped_coordinate_as_constant():
+    dt = torch.float64
+    from mm3dgs_slam_amd.synthetic import camera_matrices
+    v, p, c, tx, ty = camera_matrices(32, 32, 16.0, 16.0, dtype=dt)
+    s = RefSettings(32, 32, tx, ty, torch.zeros(3, dtype=dt), 1.0, v, p, 0, c)
+    # far outside 1.3 * tanfov in x, but big enough to reach the image
+    means = torch.tensor([[2.0, 0.0, 1.0]], dtype=dt, requires_grad=True)
+    img, radii = rasterize_ref(means, None, torch.ones(1, 1, dtype=dt) * 0.9, None, torch.ones(1, 3, dtype=dt),
+                               torch.full((1, 3), 0.6, dtype=dt), torch.tensor([[1.0, 0, 0, 0]], dtype=dt), None, s)
+    assert int(radii[0]) > 0 and img.sum() > 0
+    img.sum().backward()
+    assert torch.isfinite(means.grad).all()
+
+
+def test_background_and_extra_channels():
+    case = pu.make_case(P=100, H=32, W=32, seed=6, extras=3, bg=(1.0, 1.0, 1.0))
+    s = _settings(case)
+    cp = torch.cat([case["colors"], case["extras"]], 1)
+    img, _ = rasterize_ref(case["means3D"], None, case["opacities"], None, cp, case["scales"], case["rotations"], None, s)
+    img3, _ = rasterize_ref(case["means3D"], None, case["opacities"], None, case["colors"], case["scales"], case["rotations"], None, s)
+    assert torch.allclose(img[:3], img3) and img.shape[0] == 6
+    zero_bg = s._replace(bg=torch.zeros(3, dtype=torch.float64))
+    ex, _ = rasterize_ref(case["means3D"], None, case["opacities"], None, case["extras"], case["scales"], case["rotations"], None, zero_bg)
+    assert torch.allclose(img[3:], ex)     # extra channels composite over a zero background
+
+
+def test_argument_validation():
+    import pytest
+    case = pu.make_case(P=10, H=16, W=16, seed=7)
+    s = _settings(case)
+    with pytest.raises(ValueError):
+        rasterize_ref(case["means3D"], None, case["opacities"], None, None, case["scales"], case["rotations"], None, s)
+    with pytest.raises(ValueError):
+        rasterize_ref(case["means3D"], None, case["opacities"], None, case["colors"], None, None, None, s)
