@@ -115,6 +115,62 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
 /* visible[P] (uint8) = z_view > 0.2 -- the lineage's markVisible. */
 int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream);
 
+/* =====================================================================================================
+ * Fused SLAM iteration (section 8f rows 1-2).
+ * One projection kernel folds in the pose transform of `transform_means_python` mode (slam/renderer.py:142-153),
+ * the [z,1,z^2] depth bundle (:26-43), the GaussianModel activations (slam/gaussian_model.py:108-137) and, in the
+ * backward, their chain rules, the pose gradient (P -> 12 float reduction -> (dq,dt)), the densification statistics
+ * (slam/mapper.py:887-899) and the pose Adam step (slam/tracker.py:233-246).  SH degree 0 only (both shipped configs).
+ * Output image has 6 channels: RGB, alpha-weighted z, silhouette, alpha-weighted z^2.
+ * ===================================================================================================== */
+typedef struct Mm3dgsSlamInputs {
+  const float* pose;      /* [7] (qw,qx,qy,qz,tx,ty,tz) world->camera, raw                              */
+  const float* xyz;       /* [P,3] GaussianModel._xyz                                                    */
+  const float* f_dc;      /* [P,3] GaussianModel._features_dc ([P,1,3])                                  */
+  const float* opacity;   /* [P]   logits (GaussianModel._opacity)                                       */
+  const float* scaling;   /* [P,3] log-scales                                                            */
+  const float* rotation;  /* [P,4] raw quaternions (w,x,y,z)                                             */
+  int32_t isotropic;      /* pipeline.force_isotropic (slam/renderer.py:167-168)                         */
+} Mm3dgsSlamInputs;
+
+typedef struct Mm3dgsSlamGrads {
+  float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation; /* all or none (tracking) */
+  float* max_radii2D; float* grad_accum; float* denom; /* [P] updated in place when max_radii2D != NULL          */
+} Mm3dgsSlamGrads;
+
+typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
+  float* pose; float* m; float* v; int32_t* step; float lr_q, lr_t, beta1, beta2, eps;
+} Mm3dgsPoseAdam;
+
+int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color /*[6,H,W]*/,
+                        int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity,
+                        void* stream);
+int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
+                         const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
+                         const float* dL_dout /*[6,H,W]*/, void* backward_scratch, const Mm3dgsSlamGrads* grads,
+                         float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, void* stream);
+
+/* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:856-873,
+ * utils/loss_utils.py): w_l1 * mean|rgb-gt| (optionally over silhouette > sil_thr) + w_ssim * (1 - SSIM 11x11)
+ * + w_pearson * (1 - rho(depth, ref)).  loss[4] = {total, l1, 1-ssim, 1-rho}.  work: mm3dgs_loss_work_bytes(). */
+typedef struct Mm3dgsLossConfig {
+  int32_t H, W;
+  float w_l1, w_ssim, w_pearson;
+  int32_t l1_mask;        /* 0 all pixels, 1 silhouette > sil_thr                                        */
+  int32_t pearson_mask;   /* bit0 silhouette > sil_thr, bit1 ref > 0                                     */
+  int32_t pearson_invert; /* 1: min over targets -ref and 1/(ref+200) (utils/loss_utils.py:53-57)        */
+  float sil_thr;
+  float window[11];       /* normalised 1-D Gaussian window (sigma 1.5), as utils/loss_utils.py:95-112    */
+} Mm3dgsLossConfig;
+size_t mm3dgs_loss_work_bytes(int H, int W);
+int mm3dgs_loss(const Mm3dgsLossConfig* cfg, const float* out6, const float* gt_color, const float* ref_depth_or_null,
+                void* work, float* dL_dout6, float* loss4, void* stream);
+
+/* Fused Adam over up to 8 parameter groups in one launch (slam/gaussian_model.py:143-195; torch.optim.Adam formula).
+ * step = 1-based step count used for the bias corrections. */
+typedef struct Mm3dgsAdamGroup { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; float lr; } Mm3dgsAdamGroup;
+int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float beta1, float beta2, float eps, void* stream);
+
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
  * launches and their summed duration since the previous read, and resets the counters. */
@@ -124,7 +180,9 @@ int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, ui
 #define MM3DGS_PROF_COMPOSITE_FWD 3
 #define MM3DGS_PROF_COMPOSITE_BWD 4
 #define MM3DGS_PROF_PREPROCESS_BWD 5
-#define MM3DGS_PROF_KERNELS 6
+#define MM3DGS_PROF_LOSS 6
+#define MM3DGS_PROF_ADAM 7
+#define MM3DGS_PROF_KERNELS 8
 void mm3dgs_profile_enable(int on);
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 

@@ -24,6 +24,32 @@ class Mm3dgsHeader(C.Structure):
                 ("bwd_wave_visits", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
+class Mm3dgsSlamInputs(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("xyz", C.c_void_p), ("f_dc", C.c_void_p), ("opacity", C.c_void_p),
+                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("isotropic", C.c_int32)]
+
+
+class Mm3dgsSlamGrads(C.Structure):
+    _fields_ = [("d_xyz", C.c_void_p), ("d_f_dc", C.c_void_p), ("d_opacity", C.c_void_p), ("d_scaling", C.c_void_p),
+                ("d_rotation", C.c_void_p), ("max_radii2D", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p)]
+
+
+class Mm3dgsPoseAdam(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_float),
+                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+class Mm3dgsLossConfig(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_pearson", C.c_float),
+                ("l1_mask", C.c_int32), ("pearson_mask", C.c_int32), ("pearson_invert", C.c_int32), ("sil_thr", C.c_float),
+                ("window", C.c_float * 11)]
+
+
+class Mm3dgsAdamGroup(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_uint64), ("lr", C.c_float)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "mm3dgs_geom_bytes": (C.c_size_t, [C.c_int]),
@@ -36,6 +62,12 @@ _SIGS = {
     "mm3dgs_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 11 + [C.c_size_t]
                         + [_P] * 13 + [C.c_int, _P]),
     "mm3dgs_mark_visible": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, _P, _P, _P]),
+    "mm3dgs_slam_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
+                                       C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), _P]),
+    "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mm3dgs_loss": (C.c_int, [C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, _P]),
+    "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "mm3dgs_profile_enable": (None, [C.c_int]),
     "mm3dgs_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "mm3dgs_last_error": (C.c_char_p, []),
@@ -67,7 +99,7 @@ def load():
     return lib
 
 
-PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
+PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam")
 
 
 def profile_enable(on: bool):

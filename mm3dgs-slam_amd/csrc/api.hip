@@ -1,9 +1,11 @@
 // C-ABI entry points of libmm3dgs_hip.so (declared in include/mm3dgs.h).  Plain pointers and sizes only; every
 // launch goes to the caller's stream; no device allocation, no host synchronisation.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 #include "mm3dgs_common.h"
+#include "fused_api.h"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -166,6 +168,109 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
                         dL_dcov3D, want_cam, flags, s);
   if (want_cam) launch_camgrad_finish(bw, dL_dview, dL_dproj, dL_dcampos, s);
   return check_launch("backward");
+}
+
+// ---- fused SLAM iteration ----------------------------------------------------------------------------------------
+static SlamIn slam_in(const Mm3dgsSlamInputs* in) {
+  SlamIn s;
+  s.pose = in->pose; s.xyz = in->xyz; s.f_dc = in->f_dc; s.opacity = in->opacity; s.scaling = in->scaling;
+  s.rotation = in->rotation; s.isotropic = in->isotropic;
+  return s;
+}
+static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in) {
+  if (!cam || !in) return fail(-1, "NULL argument");
+  if (cam->image_height <= 0 || cam->image_width <= 0) return fail(-1, "bad image size");
+  if (P < 0) return fail(-1, "P < 0");
+  if (!cam->bg || !cam->projmatrix) return fail(-1, "camera device pointers missing");
+  if (!in->pose) return fail(-1, "pose is NULL");
+  if (P > 0 && (!in->xyz || !in->f_dc || !in->opacity || !in->scaling || !in->rotation)) return fail(-1, "NULL Gaussian parameter");
+  return 0;
+}
+
+int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
+                        void* geom_state, void* image_state, void* binning_state, size_t N_capacity, void* stream) {
+  int rc = check_slam(cam, P, in);
+  if (rc) return rc;
+  if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view(geom_state, P > 0 ? P : 1);
+  ImageView iv = image_view(image_state, cd.H, cd.W);
+  BinView b = bin_view(binning_state, N_capacity);
+  if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
+  { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
+  { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s); }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
+  return check_launch("slam_forward");
+}
+
+int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
+                         const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
+                         const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
+                         const Mm3dgsPoseAdam* pose_adam, void* stream) {
+  int rc = check_slam(cam, P, in);
+  if (rc) return rc;
+  if (!geom_state || !image_state || !binning_state || !dL_dout || !backward_scratch || (P > 0 && !radii)) return fail(-1, "NULL buffer");
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view((void*)geom_state, P > 0 ? P : 1);
+  ImageView iv = image_view((void*)image_state, cd.H, cd.W);
+  BinView b = bin_view((void*)binning_state, N_capacity);
+  BwdView bw = bwd_view(backward_scratch, P, N_capacity);
+  SlamGrads sg = {};
+  if (grads) {
+    const bool any = grads->d_xyz || grads->d_f_dc || grads->d_opacity || grads->d_scaling || grads->d_rotation;
+    const bool all = grads->d_xyz && grads->d_f_dc && grads->d_opacity && grads->d_scaling && grads->d_rotation;
+    if (any && !all) return fail(-2, "Gaussian gradient outputs must be all set or all NULL");
+    if (grads->max_radii2D && (!grads->grad_accum || !grads->denom)) return fail(-2, "statistics outputs must be all set or all NULL");
+    sg.d_xyz = grads->d_xyz; sg.d_f_dc = grads->d_f_dc; sg.d_opacity = grads->d_opacity; sg.d_scaling = grads->d_scaling;
+    sg.d_rotation = grads->d_rotation; sg.max_radii2D = grads->max_radii2D; sg.grad_accum = grads->grad_accum; sg.denom = grads->denom;
+  }
+  PoseAdam pa = {};
+  if (pose_adam && pose_adam->pose) {
+    if (!pose_adam->m || !pose_adam->v || !pose_adam->step) return fail(-2, "pose Adam state missing");
+    pa.pose = pose_adam->pose; pa.m = pose_adam->m; pa.v = pose_adam->v; pa.step = pose_adam->step;
+    pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = pose_adam->eps;
+  }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd(cd, 6, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, s); }
+  return check_launch("slam_backward");
+}
+
+size_t mm3dgs_loss_work_bytes(int H, int W) { return 256 + align_up((size_t)9 * H * W * 4, 256); }
+
+int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_color, const float* ref, void* work, float* dL,
+                float* loss4, void* stream) {
+  if (!c || !out6 || !gt_color || !work || !dL) return fail(-1, "NULL argument");
+  if (c->H <= 0 || c->W <= 0) return fail(-1, "bad image size");
+  if (c->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
+  LossCfg lc;
+  lc.H = c->H; lc.W = c->W; lc.w_l1 = c->w_l1; lc.w_ssim = c->w_ssim; lc.w_pearson = c->w_pearson; lc.l1_mask = c->l1_mask;
+  lc.pearson_mask = c->pearson_mask; lc.pearson_invert = c->pearson_invert; lc.sil_thr = c->sil_thr;
+  for (int i = 0; i < 11; i++) lc.window[i] = c->window[i];
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MM3DGS_PROF_LOSS, s);
+  launch_loss(lc, out6, gt_color, ref, (float*)((char*)work + 256), (double*)work, dL, loss4, s);
+  return check_launch("loss");
+}
+
+int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float beta1, float beta2, float eps, void* stream) {
+  if (!groups || n_groups < 0 || n_groups > 8) return fail(-1, "bad group table");
+  if (step < 1) return fail(-1, "step must be >= 1");
+  AdamArgs a;
+  a.ngroups = n_groups; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = 1.f - powf(beta1, (float)step);
+  a.bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  for (int i = 0; i < n_groups; i++) {
+    if (groups[i].n && (!groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq)) return fail(-1, "NULL in group %d", i);
+    a.grp[i].p = groups[i].param; a.grp[i].g = groups[i].grad; a.grp[i].m = groups[i].exp_avg; a.grp[i].v = groups[i].exp_avg_sq;
+    a.grp[i].n = groups[i].n; a.grp[i].lr = groups[i].lr;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MM3DGS_PROF_ADAM, s);
+  launch_fused_adam(a, s);
+  return check_launch("adam");
 }
 
 int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream) {

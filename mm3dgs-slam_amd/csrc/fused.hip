@@ -1,0 +1,442 @@
+// Fused SLAM render path (section 7 step 6): one projection kernel that folds in
+//   * the pose transform the reference does in torch in `transform_means_python` mode (slam/renderer.py:142-153):
+//       means_cam = R(q/|q|) x + t, viewmatrix = I  -- and, in the backward, the P -> 12 float reduction that is the
+//       pose gradient (dR = sum dmeans_cam (x) x, dt = sum dmeans_cam) followed by the chain rule to (q, t);
+//   * the depth bundle [z, 1, z^2] of slam/renderer.py:26-43 (only z is stored; the compositor channels are derived);
+//   * the GaussianModel activations of slam/gaussian_model.py:108-137 (exp, normalize, sigmoid, SH degree 0 -> RGB
+//     with the +0.5 / clamp of renderer.py:188-189) and their chain rule in the backward;
+//   * in the backward: the densification statistics of slam/mapper.py:887-899 / gaussian_model.py:594-598.
+// Reference quirk kept: the Gaussians' rotations are NOT composed with the camera rotation in this mode
+// (slam/renderer.py:152,171-173), i.e. the covariance stays in world orientation while the mean is in camera space.
+// Everything downstream (scan, scatter, sort, compositors) is the generic pipeline with C = 6.
+#include "mm3dgs_math.h"
+#include "fused_api.h"
+
+#define FB 256
+#define SH_C0F 0.28209479177387814f
+
+struct PoseDev { float R[3][3]; float t[3]; float qn[4]; float inv_norm; };
+
+__device__ __forceinline__ PoseDev load_pose(const float* __restrict__ pose) {
+  PoseDev p;
+  float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+  float n = sqrtf(w * w + x * x + y * y + z * z);
+  p.inv_norm = 1.f / n;
+  p.qn[0] = w * p.inv_norm; p.qn[1] = x * p.inv_norm; p.qn[2] = y * p.inv_norm; p.qn[3] = z * p.inv_norm;
+  quat_to_R(p.qn, p.R);
+  p.t[0] = pose[4]; p.t[1] = pose[5]; p.t[2] = pose[6];
+  return p;
+}
+
+__device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod, float S3[3][3], float R[3][3], float sm[3],
+                                           float qn[4], float& qinv) {
+  const float* q = in.rotation + (size_t)idx * 4;
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  n = fmaxf(n, 1e-12f);  // torch.nn.functional.normalize eps
+  qinv = 1.f / n;
+  qn[0] = q[0] * qinv; qn[1] = q[1] * qinv; qn[2] = q[2] * qinv; qn[3] = q[3] * qinv;
+  quat_to_R(qn, R);
+  const float* ls = in.scaling + (size_t)idx * 3;
+  sm[0] = mod * __expf(ls[0]);
+  sm[1] = in.isotropic ? sm[0] : mod * __expf(ls[1]);
+  sm[2] = in.isotropic ? sm[0] : mod * __expf(ls[2]);
+  float Mx[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) Mx[i][k] = R[i][k] * sm[k];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) S3[i][j] = Mx[i][0] * Mx[j][0] + Mx[i][1] * Mx[j][1] + Mx[i][2] * Mx[j][2];
+}
+
+__global__ void __launch_bounds__(FB)
+slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles) {
+  extern __shared__ uint32_t hist[];
+  const int T = cam.gx * cam.gy;
+  for (int t = threadIdx.x; t < lds_tiles; t += FB) hist[t] = 0;
+  if (lds_tiles) __syncthreads();
+  const int idx = blockIdx.x * FB + threadIdx.x;
+  const bool live = idx < P;
+  const float* PV = cam.proj;
+  const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+  const PoseDev ps = load_pose(in.pose);
+  float p[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
+  }
+  int32_t rad = 0;
+  uint32_t r0 = 0, r1 = 0;
+  if (live && p[2] > 0.2f) {
+    float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
+    float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
+    float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
+    float pw = 1.f / (hw + 1e-7f);
+    float S3[3][3], R[3][3], sm[3], qn[4], qinv;
+    slam_cov3d(in, idx, cam.scale_modifier, S3, R, sm, qn, qinv);
+    Ewa e;
+    ewa_project(cam, Vi, p, S3, e);
+    float det = e.a * e.c - e.b * e.b;
+    float px = ((hx * pw + 1.f) * cam.W - 1.f) * 0.5f;
+    float py = ((hy * pw + 1.f) * cam.H - 1.f) * 0.5f;
+    if (det != 0.f && isfinite(px) && isfinite(py)) {
+      float dinv = 1.f / det;
+      float mid = 0.5f * (e.a + e.c);
+      float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      float rf = ceilf(3.f * sqrtf(lam));
+      float gxf = (float)cam.gx + 1.f, gyf = (float)cam.gy + 1.f;
+      int minx = min(cam.gx, max(0, (int)fminf(fmaxf((px - rf) / TILE, -1.f), gxf)));
+      int miny = min(cam.gy, max(0, (int)fminf(fmaxf((py - rf) / TILE, -1.f), gyf)));
+      int maxx = min(cam.gx, max(0, (int)fminf(fmaxf((px + rf + (TILE - 1)) / TILE, -1.f), gxf)));
+      int maxy = min(cam.gy, max(0, (int)fminf(fmaxf((py + rf + (TILE - 1)) / TILE, -1.f), gyf)));
+      if ((maxx - minx) * (maxy - miny) > 0) {
+        rad = (int32_t)fminf(rf, 2.0e9f);
+        r0 = (uint32_t)minx | ((uint32_t)miny << 16);
+        r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
+        const float* fd = in.f_dc + (size_t)idx * 3;
+        float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
+        g.clamped[idx] = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
+        const float z = p[2];
+        const float op = 1.f / (1.f + __expf(-in.opacity[idx]));
+        float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
+        sp[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
+        sp[1] = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
+        sp[2] = make_float4(fmaxf(c2, 0.f), z, 1.f, z * z);
+        g.depth[idx] = z;
+      }
+    }
+  }
+  if (live) {
+    radii[idx] = rad;
+    g.rect[(size_t)idx * 2] = r0;
+    g.rect[(size_t)idx * 2 + 1] = r1;
+  }
+  {
+    const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
+    const int w = maxx - minx, area = w * (maxy - miny);
+    {
+      __shared__ uint32_t wtot[FB / 64];
+      const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+      uint32_t x = (uint32_t)area;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (ln >= off) x += y;
+      }
+      if (ln == 63) wtot[wvi] = x;
+      __syncthreads();
+      uint32_t pre = 0;
+      for (int q = 0; q < wvi; q++) pre += wtot[q];
+      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
+      if (threadIdx.x == FB - 1) g.block_tiles[blockIdx.x] = pre + x;
+    }
+    uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
+    const int lane = threadIdx.x & 63;
+    unsigned long long big = __ballot(area > 32);
+    if (area > 0 && area <= 32)
+      for (int y = miny; y < maxy; y++)
+        for (int x = minx; x < maxx; x++) atomicAdd(&cnt[y * cam.gx + x], 1u);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
+      const int sw = __builtin_amdgcn_readlane(w, src), sarea = __builtin_amdgcn_readlane(area, src);
+      for (int k = lane; k < sarea; k += 64) atomicAdd(&cnt[(sminy + k / sw) * cam.gx + sminx + k % sw], 1u);
+    }
+  }
+  if (lds_tiles) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += FB) {
+      uint32_t c = hist[t];
+      if (c) atomicAdd(&iv.tile_count[t], c);
+    }
+  }
+}
+
+void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s) {
+  if (P <= 0) return;
+  const int T = cam.gx * cam.gy;
+  const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
+  hipLaunchKernelGGL(slam_preprocess_fwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
+                     iv, lds_tiles);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+#define NPOSE 12  // dR (9, row-major) | dt (3)
+__global__ void __launch_bounds__(FB)
+slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out) {
+  const int idx = blockIdx.x * FB + threadIdx.x;
+  const float* PV = cam.proj;
+  const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
+  const PoseDev ps = load_pose(in.pose);
+  float cg[NPOSE];
+#pragma unroll
+  for (int k = 0; k < NPOSE; k++) cg[k] = 0.f;
+  float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
+  int rad = 0;
+  {
+    uint32_t goff = 0;
+    int area = 0;
+    if (idx < P) rad = radii[idx];
+    if (rad > 0) {
+      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+      area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
+      goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
+    }
+    auto add_pair = [&](uint32_t gi) {
+      if (gi >= N_cap) return;
+      const uint32_t slot = bn.gslot[gi];
+      if (slot >= N_cap) return;
+      const uint32_t m = bn.submask[slot];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        if (m & (1u << w)) {
+          const float4* r = (const float4*)(dsub + ((size_t)slot * 4 + w) * SPLAT_F);
+          const float4 a = r[0], b = r[1], c = r[2];
+          acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
+          acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
+          acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
+        }
+      }
+    };
+    if (area <= 32)
+      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k);
+    unsigned long long big = __ballot(area > 32);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int sarea = __builtin_amdgcn_readlane(area, src);
+      const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
+      const float4 k0 = acc0, k1 = acc1, k2 = acc2;
+      acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
+      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k);
+      float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
+#pragma unroll
+      for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
+      if (lane == src) {
+        acc0 = make_float4(v[0], v[1], v[2], v[3]); acc1 = make_float4(v[4], v[5], v[6], v[7]);
+        acc2 = make_float4(v[8], v[9], v[10], v[11]);
+      } else {
+        acc0 = k0; acc1 = k1; acc2 = k2;
+      }
+    }
+  }
+  if (idx < P) {
+    float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
+    float dlogit = 0.f, gnorm = 0.f;
+    if (rad > 0) {
+      const float gpx = acc0.x, gpy = acc0.y, gA = acc0.z, gB = acc0.w, gC = acc1.x, dop = acc1.y;
+      const float dc0 = acc1.z, dc1 = acc1.w, dc2 = acc2.x, dz_ch = acc2.y, dz2_ch = acc2.w;
+      const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
+      float p[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
+      float S3[3][3], R[3][3], sm[3], qn[4], qinv;
+      slam_cov3d(in, idx, cam.scale_modifier, S3, R, sm, qn, qinv);
+      Ewa e;
+      ewa_project(cam, Vi, p, S3, e);
+      const float a = e.a, b = e.b, c = e.c;
+      const float det = a * c - b * b, id2 = 1.f / (det * det);
+      const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
+      const float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
+      const float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+      const float G2[2][2] = {{da, 0.5f * db}, {0.5f * db, dcc}};
+      float GA[2][3], dS[3][3], dA[2][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        GA[0][i] = G2[0][0] * e.A[0][i] + G2[0][1] * e.A[1][i];
+        GA[1][i] = G2[1][0] * e.A[0][i] + G2[1][1] * e.A[1][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dS[i][j] = e.A[0][i] * GA[0][j] + e.A[1][i] * GA[1][j];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dA[r][j] = 2.f * (GA[r][0] * S3[0][j] + GA[r][1] * S3[1][j] + GA[r][2] * S3[2][j]);
+      // view = identity: dJ[r][k] = dA[r][k]
+      const float dJ00 = dA[0][0], dJ02 = dA[0][2], dJ11 = dA[1][1], dJ12 = dA[1][2];
+      const float tz = e.t[2], itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+      float dm[3];
+      dm[0] = e.in_x ? -cam.focal_x * itz2 * dJ02 : 0.f;
+      dm[1] = e.in_y ? -cam.focal_y * itz2 * dJ12 : 0.f;
+      dm[2] = -cam.focal_x * itz2 * dJ00 - cam.focal_y * itz2 * dJ11 + 2.f * cam.focal_x * e.txc * itz3 * dJ02 +
+              2.f * cam.focal_y * e.tyc * itz3 * dJ12;
+      const float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
+      const float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
+      const float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
+      const float pw = 1.f / (hw + 1e-7f);
+      const float gnx = gpx * 0.5f * cam.W, gny = gpy * 0.5f * cam.H;
+      gnorm = sqrtf(gnx * gnx + gny * gny);
+      const float dhx = gnx * pw, dhy = gny * pw, dhw = -(gnx * hx + gny * hy) * pw * pw;
+#pragma unroll
+      for (int i = 0; i < 3; i++) dm[i] += PV[i * 4 + 0] * dhx + PV[i * 4 + 1] * dhy + PV[i * 4 + 3] * dhw;
+      dm[2] += dz_ch + 2.f * p[2] * dz2_ch;  // depth bundle [z, 1, z^2]
+      // pose: means_cam = R x + t
+      cg[0] = dm[0] * x0; cg[1] = dm[0] * x1; cg[2] = dm[0] * x2;
+      cg[3] = dm[1] * x0; cg[4] = dm[1] * x1; cg[5] = dm[1] * x2;
+      cg[6] = dm[2] * x0; cg[7] = dm[2] * x1; cg[8] = dm[2] * x2;
+      cg[9] = dm[0]; cg[10] = dm[1]; cg[11] = dm[2];
+      if (out.d_xyz) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2];
+        const uint8_t cl = g.clamped[idx];
+        dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;
+        dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
+        dfd[2] = (cl & 4) ? 0.f : SH_C0F * dc2;
+        const float o = 1.f / (1.f + __expf(-in.opacity[idx]));
+        dlogit = dop * o * (1.f - o);
+        float dM[3][3], dR[3][3], ds[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) dM[i][k] = 2.f * (dS[i][0] * R[0][k] + dS[i][1] * R[1][k] + dS[i][2] * R[2][k]) * sm[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          ds[k] = cam.scale_modifier * (dM[0][k] * R[0][k] + dM[1][k] * R[1][k] + dM[2][k] * R[2][k]);
+#pragma unroll
+          for (int i = 0; i < 3; i++) dR[i][k] = dM[i][k] * sm[k];
+        }
+        // scales = exp(log-scales): d/dlog = ds * s (sm already carries scale_modifier, ds carries the other factor)
+        const float inv_mod = 1.f / cam.scale_modifier;
+        if (in.isotropic) {
+          dls[0] = (ds[0] * sm[0] + ds[1] * sm[1] + ds[2] * sm[2]) * inv_mod;
+        } else {
+          dls[0] = ds[0] * sm[0] * inv_mod; dls[1] = ds[1] * sm[1] * inv_mod; dls[2] = ds[2] * sm[2] * inv_mod;
+        }
+        const float r = qn[0], x = qn[1], y = qn[2], z = qn[3];
+        float dq[4];
+        dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+        dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] +
+                       r * dR[2][1] - 2.f * x * dR[2][2]);
+        dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] +
+                       z * dR[2][1] - 2.f * y * dR[2][2]);
+        dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] +
+                       y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        const float dot = qn[0] * dq[0] + qn[1] * dq[1] + qn[2] * dq[2] + qn[3] * dq[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dqr[k] = (dq[k] - qn[k] * dot) * qinv;
+      }
+      if (out.max_radii2D) {
+        out.max_radii2D[idx] = fmaxf(out.max_radii2D[idx], (float)rad);
+        out.grad_accum[idx] += gnorm;
+        out.denom[idx] += 1.f;
+      }
+    }
+    if (out.d_xyz) {
+      out.d_xyz[(size_t)idx * 3] = dxyz[0]; out.d_xyz[(size_t)idx * 3 + 1] = dxyz[1]; out.d_xyz[(size_t)idx * 3 + 2] = dxyz[2];
+      out.d_f_dc[(size_t)idx * 3] = dfd[0]; out.d_f_dc[(size_t)idx * 3 + 1] = dfd[1]; out.d_f_dc[(size_t)idx * 3 + 2] = dfd[2];
+      out.d_opacity[idx] = dlogit;
+      out.d_scaling[(size_t)idx * 3] = dls[0]; out.d_scaling[(size_t)idx * 3 + 1] = dls[1]; out.d_scaling[(size_t)idx * 3 + 2] = dls[2];
+      out.d_rotation[(size_t)idx * 4] = dqr[0]; out.d_rotation[(size_t)idx * 4 + 1] = dqr[1];
+      out.d_rotation[(size_t)idx * 4 + 2] = dqr[2]; out.d_rotation[(size_t)idx * 4 + 3] = dqr[3];
+    }
+  }
+  {
+    __shared__ float red[4][NPOSE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NPOSE; k++) {
+      float v = wave_sum_to_lane63(cg[k]);
+      if (lane == 63) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NPOSE) {
+      const int k = threadIdx.x;
+      posepartial[(size_t)blockIdx.x * 32 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+  }
+}
+
+// One wave: fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through
+// R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
+// betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
+__global__ void slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
+                                        float* __restrict__ dpose, PoseAdam ad) {
+  __shared__ double tot[NPOSE];
+  const int k = threadIdx.x;
+  if (k < NPOSE) {
+    double acc = 0.0;
+    for (int r = 0; r < nrows; r++) acc += (double)posepartial[(size_t)r * 32 + k];
+    tot[k] = acc;
+  }
+  __syncthreads();
+  if (k == 0) {
+    const float w0 = pose_in[0], x0 = pose_in[1], y0 = pose_in[2], z0 = pose_in[3];
+    const float n = sqrtf(w0 * w0 + x0 * x0 + y0 * y0 + z0 * z0), inv = 1.f / n;
+    const float r = w0 * inv, x = x0 * inv, y = y0 * inv, z = z0 * inv;
+    float dR[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) dR[i][j] = (float)tot[i * 3 + j];
+    float dq[4];
+    dq[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+    dq[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] -
+                   2.f * x * dR[2][2]);
+    dq[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] -
+                   2.f * y * dR[2][2]);
+    dq[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] +
+                   x * dR[2][0] + y * dR[2][1]);
+    const float qn[4] = {r, x, y, z};
+    const float dot = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+    float grad[7];
+    for (int i = 0; i < 4; i++) grad[i] = (dq[i] - qn[i] * dot) * inv;
+    for (int i = 0; i < 3; i++) grad[4 + i] = (float)tot[9 + i];
+    if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
+    if (ad.pose) {
+      const int t = ++(*ad.step);
+      const float bc1 = 1.f - powf(ad.beta1, (float)t), bc2 = 1.f - powf(ad.beta2, (float)t);
+      const float bc2s = sqrtf(bc2);
+      for (int i = 0; i < 7; i++) {
+        const float lr = i < 4 ? ad.lr_q : ad.lr_t;
+        const float gi = grad[i];
+        const float mi = ad.m[i] + (gi - ad.m[i]) * (1.f - ad.beta1);      // lerp, as torch does
+        const float vi = ad.v[i] * ad.beta2 + gi * gi * (1.f - ad.beta2);
+        ad.m[i] = mi; ad.v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + ad.eps;
+        ad.pose[i] -= (lr / bc1) * (mi / denom);
+      }
+    }
+  }
+}
+
+void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
+                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, hipStream_t s) {
+  const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  if (P > 0)
+    hipLaunchKernelGGL(slam_preprocess_bwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub,
+                       bw.campartial, out);
+  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(64), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused Adam over the map's parameter groups (slam/gaussian_model.py:143-195: Adam(lr=0, eps=1e-15), one group per
+// parameter; same update formula as torch.optim.Adam).  One launch for all groups.
+__global__ void __launch_bounds__(256) fused_adam_kernel(AdamArgs a) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  for (int gi = 0; gi < a.ngroups; gi++) {
+    const AdamGroup G = a.grp[gi];
+    const float step = G.lr / a.bc1;
+    for (unsigned long long i = tid; i < G.n; i += stride) {
+      const float gr = G.g[i];
+      const float mi = G.m[i] + (gr - G.m[i]) * (1.f - a.beta1);
+      const float vi = G.v[i] * a.beta2 + gr * gr * (1.f - a.beta2);
+      G.m[i] = mi; G.v[i] = vi;
+      G.p[i] -= step * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+    }
+  }
+}
+void launch_fused_adam(const AdamArgs& a, hipStream_t s) {
+  unsigned long long tot = 0;
+  for (int i = 0; i < a.ngroups; i++) tot = tot > a.grp[i].n ? tot : a.grp[i].n;
+  if (!tot) return;
+  int blocks = (int)((tot + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fused_adam_kernel, dim3(blocks), dim3(256), 0, s, a);
+}

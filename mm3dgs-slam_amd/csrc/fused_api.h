@@ -1,0 +1,29 @@
+// Internal structs + launchers of the fused SLAM path (fused.hip, loss.hip), shared with api.hip.
+#pragma once
+#include "mm3dgs_common.h"
+
+struct SlamIn {
+  const float* pose; const float* xyz; const float* f_dc; const float* opacity; const float* scaling; const float* rotation;
+  int isotropic;
+};
+struct SlamGrads {
+  float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation;
+  float* max_radii2D; float* grad_accum; float* denom;
+};
+struct PoseAdam { float* pose; float* m; float* v; int* step; float lr_q, lr_t, beta1, beta2, eps; };
+struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float lr; };
+struct AdamArgs { AdamGroup grp[8]; int ngroups; float beta1, beta2, eps, bc1, bc2s; };
+struct LossCfg {
+  int H, W;
+  float w_l1, w_ssim, w_pearson;
+  int l1_mask, pearson_mask, pearson_invert;
+  float sil_thr;
+  float window[11];
+};
+
+void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
+void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
+                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, hipStream_t s);
+void launch_fused_adam(const AdamArgs& a, hipStream_t s);
+void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, float* dL,
+                 float* loss, hipStream_t s);

@@ -1,0 +1,249 @@
+"""Native (HIP) tracking / mapping iterations: the reference's per-iteration torch graph -- pose algebra, means
+transform, activations, two rasterizer passes, loss, backward, Adam (slam/tracker.py:94-177, slam/mapper.py:798-948) --
+collapsed into a handful of C-ABI calls with no host synchronisation inside the loop:
+
+    mm3dgs_slam_forward  ->  mm3dgs_loss  ->  mm3dgs_slam_backward ( -> pose Adam on device | mm3dgs_adam )
+
+``FusedTracker`` / ``FusedMapper`` subclass the torch-graph ``Tracker`` / ``Mapper`` and take over ``optimize_cam`` /
+``optimize_map`` when the configuration is the one both shipped configs use (``transform_means_python``, SH degree 0,
+no python SH / cov3D, method != splatam, no IMU loss term, no BA); anything else falls back to the torch-graph loop,
+which stays the parity reference for these kernels (tests/test_gpu_fused.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from random import randint
+
+import torch
+
+from . import _lib
+from .mapper import Mapper
+from .rasterizer import _camera, _stream
+from .tracker import Tracker
+
+
+def _gauss_window():
+    g = torch.tensor([math.exp(-((i - 5) ** 2) / (2 * 1.5 ** 2)) for i in range(11)])
+    return (g / g.sum()).float().tolist()
+
+
+_WINDOW = _gauss_window()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class FusedEngine:
+    """Owns the reusable device buffers of the fused render (state, output, gradients) for one Renderer."""
+
+    def __init__(self, renderer):
+        self.r = renderer
+        self.dev = torch.device(renderer.cfg["device"])
+        self.lib = _lib.load()
+        self.H, self.W = renderer.image_height, renderer.image_width
+        self.img_state = torch.empty(self.lib.mm3dgs_image_bytes(self.H, self.W), dtype=torch.uint8, device=self.dev)
+        self.out = torch.empty((6, self.H, self.W), device=self.dev)
+        self.dL = torch.empty((6, self.H, self.W), device=self.dev)
+        self.loss = torch.zeros(4, device=self.dev)
+        self.loss_work = torch.empty(self.lib.mm3dgs_loss_work_bytes(self.H, self.W), dtype=torch.uint8, device=self.dev)
+        self.dpose = torch.zeros(7, device=self.dev)
+        self.ratio = None            # pairs per Gaussian seen so far (binning capacity model)
+        self.P = -1
+        self.n_cap = 0
+        rs_cls = renderer.settings_cls
+        eye = torch.eye(4, device=self.dev)
+        self.settings = rs_cls(image_height=self.H, image_width=self.W, tanfovx=renderer.tanfovx, tanfovy=renderer.tanfovy,
+                               bg=renderer.background, scale_modifier=1.0, viewmatrix=eye, projmatrix=renderer.projection_matrix,
+                               sh_degree=0, campos=torch.zeros(3, device=self.dev), prefiltered=False, debug=False)
+        self._keep = (eye, self.settings.campos)
+        self.cam = _camera(self.settings, renderer.background, eye, renderer.projection_matrix.contiguous(), self.settings.campos)
+        self.isotropic = 1 if renderer.cfg["pipeline"]["force_isotropic"] else 0
+
+    @staticmethod
+    def eligible(cfg, gaussians):
+        pipe = cfg["pipeline"]
+        return (pipe["transform_means_python"] and not pipe["convert_SHs_python"] and not pipe["compute_cov3D_python"]
+                and gaussians.max_sh_degree == 0 and cfg["method"].lower() != "splatam" and str(cfg["device"]).startswith("cuda"))
+
+    def _ensure(self, P, need_grads):
+        if P != self.P:
+            u8 = dict(dtype=torch.uint8, device=self.dev)
+            self.geom = torch.empty(self.lib.mm3dgs_geom_bytes(P), **u8)
+            self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
+            self.P = P
+            self.n_cap = 0
+            self.grads = None
+        want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + 65536
+        if want > self.n_cap or (self.ratio is not None and self.n_cap > 4 * want):
+            u8 = dict(dtype=torch.uint8, device=self.dev)
+            self.n_cap = want
+            self.binning = torch.empty(self.lib.mm3dgs_binning_bytes(self.n_cap), **u8)
+            self.scratch = torch.empty(self.lib.mm3dgs_backward_scratch_bytes(P, self.n_cap), **u8)
+        if need_grads and self.grads is None:
+            f = dict(device=self.dev)
+            self.grads = dict(xyz=torch.empty(P, 3, **f), f_dc=torch.empty(P, 1, 3, **f), opacity=torch.empty(P, 1, **f),
+                              scaling=torch.empty(P, 3, **f), rotation=torch.empty(P, 4, **f))
+
+    def inputs(self, pose, g):
+        si = _lib.Mm3dgsSlamInputs()
+        si.pose = pose.data_ptr()
+        si.xyz, si.f_dc, si.opacity = g._xyz.data_ptr(), g._features_dc.data_ptr(), g._opacity.data_ptr()
+        si.scaling, si.rotation = g._scaling.data_ptr(), g._rotation.data_ptr()
+        si.isotropic = self.isotropic
+        return si
+
+    def forward(self, pose, g, need_grads=False):
+        P = int(g._xyz.shape[0])
+        self._ensure(P, need_grads)
+        si = self.inputs(pose, g)
+        _lib.check(self.lib.mm3dgs_slam_forward(C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
+                                                _p(self.img_state), _p(self.binning), self.n_cap, _stream()))
+        return si
+
+    def check_capacity(self):
+        """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
+        h = self.img_state[:16].view(torch.int32).cpu()
+        n, overflow = int(h[0]), int(h[1])
+        self.ratio = max(self.ratio or 0.0, n / max(self.P, 1))
+        if overflow:
+            raise RuntimeError(f"mm3dgs fused render overflowed its binning capacity ({n} > {self.n_cap}); results of the "
+                               f"last optimisation loop are invalid -- capacity raised, re-run the frame")
+        return n
+
+    def loss_call(self, cfg, gt_color, ref):
+        _lib.check(self.lib.mm3dgs_loss(C.byref(cfg), _p(self.out), _p(gt_color), _p(ref), _p(self.loss_work), _p(self.dL),
+                                        _p(self.loss), _stream()))
+
+    def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None):
+        sg = _lib.Mm3dgsSlamGrads()
+        if grads is not None:
+            sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
+            sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
+        if stats is not None:
+            sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
+        _lib.check(self.lib.mm3dgs_slam_backward(C.byref(self.cam), self.P, C.byref(si), _p(self.radii), _p(self.geom), _p(self.img_state),
+                                                 _p(self.binning), self.n_cap, _p(self.dL), _p(self.scratch), C.byref(sg), _p(dpose),
+                                                 C.byref(pose_adam) if pose_adam is not None else None, _stream()))
+
+
+def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr):
+    c = _lib.Mm3dgsLossConfig()
+    c.H, c.W, c.w_l1, c.w_ssim, c.w_pearson = H, W, w_l1, w_ssim, w_pearson
+    c.l1_mask, c.pearson_mask, c.pearson_invert, c.sil_thr = l1_mask, pearson_mask, invert, sil_thr
+    for i, v in enumerate(_WINDOW):
+        c.window[i] = v
+    return c
+
+
+def _engine(renderer):
+    eng = getattr(renderer, "_fused_engine", None)
+    if eng is None:
+        eng = renderer._fused_engine = FusedEngine(renderer)
+    return eng
+
+
+class FusedTracker(Tracker):
+    def optimize_cam(self, idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth=None, est_depth=None):
+        trk = self.cfg["tracking"]
+        if (num_iter == 0 or self.keep_best_candidate or trk["use_imu_loss"] or not FusedEngine.eligible(self.cfg, self.gaussians)):
+            return super().optimize_cam(idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth, est_depth)
+        eng = _engine(self.renderer)
+        dev = eng.dev
+        with torch.no_grad():
+            pose = torch.cat([camera_tensor_q.detach(), camera_tensor_T.detach()]).float().contiguous().clone()
+            m, v = torch.zeros(7, device=dev), torch.zeros(7, device=dev)
+            step = torch.zeros(1, dtype=torch.int32, device=dev)
+            w_p, pmask, ref = 0.0, 0, None
+            if trk["use_depth_estimate_loss"]:
+                w_p = float(trk["pearson_weight"])
+                pmask, ref = (1, est_depth) if not self.cfg["use_gt_depth"] else (3, gt_depth)
+            lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, w_p, 1, pmask, 1, 0.99)
+            ad = _lib.Mm3dgsPoseAdam()
+            ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
+            ad.lr_q, ad.lr_t = float(trk["rotation_lr"]), float(trk["position_lr"])
+            ad.beta1, ad.beta2, ad.eps = 0.9, 0.999, 1e-8
+            gt_color = gt_color.contiguous()
+            ref = None if ref is None else ref.contiguous()
+            g = self.gaussians
+            for _ in range(num_iter):
+                si = eng.forward(pose, g)
+                eng.loss_call(lcfg, gt_color, ref)
+                eng.backward(si, dpose=None, pose_adam=ad)
+            eng.check_capacity()
+            camera_tensor_q.data.copy_(pose[:4])
+            camera_tensor_T.data.copy_(pose[4:])
+            self.tracking_iter_count += num_iter
+            return eng.loss[0].clone(), eng.out[:3].clone()
+
+
+class FusedMapper(Mapper):
+    def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
+                     curr_gt_depth=None, curr_est_depth=None):
+        m = self.cfg["mapping"]
+        if (num_iter == 0 or (m["do_BA"] and idx > 0) or self.window is not None or not FusedEngine.eligible(self.cfg, self.gaussians)):
+            return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
+                                        curr_gt_depth, curr_est_depth)
+        eng = _engine(self.renderer)
+        g = self.gaussians
+        lam = float(m["lambda_dssim"])
+        w_p, pmask = 0.0, 0
+        if m["use_depth_estimate_loss"]:
+            w_p = float(m["pearson_weight"])
+            pmask = 0 if not self.cfg["use_gt_depth"] else 2
+        lcfg = _loss_cfg(eng.H, eng.W, 1.0 - lam, lam, w_p, 0, pmask, 0, 0.5)
+        stack = None
+        with torch.no_grad():
+            for iteration in range(num_iter):
+                if not stack:
+                    stack = list(keyframe_idx_list)
+                k = stack.pop(randint(0, len(stack) - 1))
+                if k == -1:
+                    pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
+                else:
+                    kf = self.keyframes[k]
+                    pose, gt_color, gt_depth, est_depth = kf.pose, kf.gt_color, kf.gt_depth, kf.est_depth
+                ref = None
+                if w_p:
+                    ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
+                pose = pose.detach().float().contiguous()
+                si = eng.forward(pose, g, need_grads=True)
+                eng.loss_call(lcfg, gt_color.contiguous(), ref)
+                densify = iteration <= m["densify_until_iter"]
+                stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
+                eng.backward(si, grads=eng.grads, stats=stats)
+                pruned_now = False
+                if densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0:
+                    g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    pruned_now = True      # the reference's Adam step is a no-op here (parameters were replaced)
+                if not pruned_now:
+                    self._adam_step(eng)
+            eng.check_capacity()
+        self.mapping_iter_count += num_iter
+
+    def _adam_step(self, eng):
+        g = self.gaussians
+        opt = g.optimizer
+        table = (_lib.Mm3dgsAdamGroup * 8)()
+        n = 0
+        step_val = None
+        for group in opt.param_groups:
+            name = group["name"]
+            if name not in eng.grads:
+                continue                     # f_rest (empty at SH degree 0) and rgb never receive a gradient
+            p = group["params"][0]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            step_val = int(st["step"].item()) if step_val is None else step_val
+            e = table[n]
+            e.param, e.grad = p.data_ptr(), eng.grads[name].data_ptr()
+            e.exp_avg, e.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            e.n, e.lr = p.numel(), float(group["lr"])
+            n += 1
+        b1, b2 = opt.param_groups[0]["betas"]
+        _lib.check(eng.lib.mm3dgs_adam(table, n, step_val, float(b1), float(b2), float(opt.param_groups[0]["eps"]), _stream()))

@@ -81,7 +81,7 @@ class _FixedMap:
 
 
 class SLAM:
-    def __init__(self, cfg, sequence, rasterizer_cls=None, settings_cls=None, render_mode="fused", window=None):
+    def __init__(self, cfg, sequence, rasterizer_cls=None, settings_cls=None, render_mode="fused", window=None, native_loops=None):
         self.cfg = cfg
         self.seq = sequence
         self.gaussians = GaussianModel(cfg)
@@ -89,8 +89,15 @@ class SLAM:
         self.renderer = Renderer(cfg, rasterizer_cls=rasterizer_cls, settings_cls=settings_cls, mode=render_mode)
         n = len(sequence)
         self.estimate_pose_list = [None] * n
-        self.tracker = Tracker(cfg, self.gaussians, self.renderer, self.estimate_pose_list)
-        self.mapper = Mapper(cfg, self.gaussians, self.renderer, self.estimate_pose_list, n_img=n, window=window)
+        # native (HIP) iteration loops by default on a GPU with the HIP rasterizer; the torch-graph loops otherwise
+        if native_loops is None:
+            native_loops = rasterizer_cls is None and str(cfg["device"]).startswith("cuda")
+        if native_loops:
+            from .fused import FusedMapper as MapperCls, FusedTracker as TrackerCls
+        else:
+            TrackerCls, MapperCls = Tracker, Mapper
+        self.tracker = TrackerCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list)
+        self.mapper = MapperCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list, n_img=n, window=window)
 
     def step(self, idx):
         """Track + map one frame (the unit the headline metric counts)."""
