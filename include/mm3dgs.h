@@ -142,9 +142,14 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
   float* pose; float* m; float* v; int32_t* step; float lr_q, lr_t, beta1, beta2, eps;
 } Mm3dgsPoseAdam;
 
+/* flags for mm3dgs_slam_forward */
+#define MM3DGS_FWD_STATE_CLEAN 1 /* image_state's header+tile counters are already zero (the library leaves them zero
+                                    after every forward), so the per-call memset is skipped: for persistent state buffers */
+#define MM3DGS_FWD_SHORT_LISTS 2 /* hint: no tile list exceeds 2048 splats -> one sort launch (longer lists stay correct
+                                    through the global-memory path, only slower)                                        */
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color /*[6,H,W]*/,
                         int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity,
-                        void* stream);
+                        int flags, void* stream);
 int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                          const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                          const float* dL_dout /*[6,H,W]*/, void* backward_scratch, const Mm3dgsSlamGrads* grads,

@@ -62,7 +62,8 @@ _SIGS = {
     "mm3dgs_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_int, C.c_int] + [_P] * 11 + [C.c_size_t]
                         + [_P] * 13 + [C.c_int, _P]),
     "mm3dgs_mark_visible": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, _P, _P, _P]),
-    "mm3dgs_slam_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "mm3dgs_slam_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
+                                      C.c_int, _P]),
     "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
                                        C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), _P]),
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),

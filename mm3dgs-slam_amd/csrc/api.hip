@@ -188,7 +188,7 @@ static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in
 }
 
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
-                        void* geom_state, void* image_state, void* binning_state, size_t N_capacity, void* stream) {
+                        void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -197,7 +197,9 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
   GeomView g = geom_view(geom_state, P > 0 ? P : 1);
   ImageView iv = image_view(image_state, cd.H, cd.W);
   BinView b = bin_view(binning_state, N_capacity);
-  if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
+  if (!(flags & MM3DGS_FWD_STATE_CLEAN))
+    if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
+  cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
   { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s); }
@@ -233,12 +235,15 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
     pa.pose = pose_adam->pose; pa.m = pose_adam->m; pa.v = pose_adam->v; pa.step = pose_adam->step;
     pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = pose_adam->eps;
   }
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd(cd, 6, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, sg.d_xyz == nullptr, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, s); }
   return check_launch("slam_backward");
 }
 
-size_t mm3dgs_loss_work_bytes(int H, int W) { return 256 + align_up((size_t)9 * H * W * 4, 256); }
+static size_t loss_rows(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
+size_t mm3dgs_loss_work_bytes(int H, int W) {
+  return 256 + align_up((size_t)9 * H * W * 4, 256) + align_up(loss_rows(H, W) * 12 * 8, 256);
+}
 
 int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_color, const float* ref, void* work, float* dL,
                 float* loss4, void* stream) {
@@ -251,7 +256,9 @@ int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_co
   for (int i = 0; i < 11; i++) lc.window[i] = c->window[i];
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MM3DGS_PROF_LOSS, s);
-  launch_loss(lc, out6, gt_color, ref, (float*)((char*)work + 256), (double*)work, dL, loss4, s);
+  char* w = (char*)work;
+  launch_loss(lc, out6, gt_color, ref, (float*)(w + 256), (double*)w, (double*)(w + 256 + align_up((size_t)9 * c->H * c->W * 4, 256)), dL,
+              loss4, s);
   return check_launch("loss");
 }
 

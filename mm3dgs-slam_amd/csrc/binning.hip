@@ -15,8 +15,8 @@
 // ---- 2. scan --------------------------------------------------------------------------------------------------
 #define SCAN_BLOCK 1024
 // exclusive scan of src[0..n) by one 1024-lane workgroup; returns the total (valid in every lane)
-__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t* src, uint32_t* dst0, uint32_t* dst1, int n,
-                                                    uint32_t* wave_tot, uint32_t* carry_s, uint32_t* maxv) {
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t* src, uint32_t* dst0, uint32_t* dst1, int n, uint32_t* wave_tot,
+                                                    uint32_t* carry_s, uint32_t* maxv, bool clear_src) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) *carry_s = 0;
   __syncthreads();
@@ -24,6 +24,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t* src, uint32_
   for (int base = 0; base < n; base += SCAN_BLOCK) {
     int i = base + tid;
     uint32_t v = (i < n) ? src[i] : 0u;
+    if (clear_src && i < n) src[i] = 0u;   // leave the counters zero for the next forward (persistent state buffers)
     local_max = max(local_max, v);
     uint32_t x = v;  // inclusive scan inside the wave
 #pragma unroll
@@ -51,15 +52,16 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
   __shared__ uint32_t carry_s;
   __shared__ uint32_t maxlen_s;
   if (threadIdx.x == 0) maxlen_s = 0;
-  uint32_t total = block_excl_scan(iv.tile_count, iv.ranges, iv.cursor, T, wave_tot, &carry_s, &maxlen_s);
+  uint32_t total = block_excl_scan(iv.tile_count, iv.ranges, iv.cursor, T, wave_tot, &carry_s, &maxlen_s, true);
   if (threadIdx.x == 0) {
     iv.ranges[T] = total;
     iv.hdr->num_rendered = total;
     iv.hdr->max_tile_len = maxlen_s;
+    iv.hdr->overflow = 0;
   }
   __syncthreads();
   // tiles touched per preprocess workgroup -> exclusive prefix (start of each workgroup's span in gslot)
-  uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr);
+  uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
   if (threadIdx.x == 0) g.block_tiles[nblocks] = tot2;
 }
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s) {
@@ -262,6 +264,10 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
   if (P > 0)
     hipLaunchKernelGGL(scatter_keys_kernel, dim3((P + 255) / 256), dim3(256), (size_t)lds_tiles * 4, s, P, cam.gx, T, g, iv, b,
                        ncap, lds_tiles);
-  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap);
-  hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap);
+  if (cam.sort_single) {
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, true>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap);
+  } else {
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap);
+  }
 }

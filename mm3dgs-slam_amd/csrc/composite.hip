@@ -208,7 +208,11 @@ __device__ __forceinline__ float xrow_sum(float v) {
   return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 
-template <int C>
+// MODE 0: generic, record = dxy(2) dconic(3) dopacity(1) dcolour(C).
+// MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): record = dxy dconic dopacity drgb(3) dz(1) with
+//         dz = sum w (dL_3 + 2 z dL_5) -- the chain rule of the depth bundle folded into the reduction (10 values, not 12).
+// MODE 2: SLAM tracking: record = dxy dconic dz (6 values): opacity / colour gradients are never consumed.
+template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
                      float* __restrict__ dsub) {
@@ -226,7 +230,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   if (count == 0) return;  // wave-uniform
   const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
 
-  constexpr int NV = 6 + C;
+  constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 6);
+  static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
+  constexpr int NF4 = (NV + 3) / 4;
   __shared__ float4 sA[2][4][64];
   __shared__ float4 sB[2][4][64];
   __shared__ float4 sC[2][4][64];
@@ -258,7 +264,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   for (uint32_t e = todo + lane; e < count; e += 64) {
     float4* r = (float4*)(dsub + (((size_t)start + list[e].y) * 4 + wv) * SPLAT_F);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    r[0] = z; r[1] = z; r[2] = z;
+#pragma unroll
+    for (int q = 0; q < NF4; q++) r[q] = z;
   }
   if (todo == 0) return;
 
@@ -323,8 +330,13 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
           const float diff = col[ch] - behind[ch];
           dLa = fmaf(diff, dL[ch], dLa);
           behind[ch] = fmaf(a_eff, diff, behind[ch]);
-          vals[6 + ch] = w * dL[ch];
+          if (MODE == 0) vals[6 + ch] = w * dL[ch];
         }
+        if (MODE == 1) {
+          vals[6] = w * dL[0]; vals[7] = w * dL[1]; vals[8] = w * dL[2];
+          vals[9] = w * fmaf(2.f * col[3], dL[5], dL[3]);
+        }
+        if (MODE == 2) vals[5] = w * fmaf(2.f * col[3], dL[5], dL[3]);
         dLa = dLa * Tr - Tf_bg * r;
         const float dL_dG = B.y * dLa;
         const float gdx = G_eff * dx, gdy = G_eff * dy;
@@ -333,7 +345,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         vals[2] = -0.5f * gdx * dx * dL_dG;
         vals[3] = -gdx * dy * dL_dG;
         vals[4] = -0.5f * gdy * dy * dL_dG;
-        vals[5] = G_eff * dLa;
+        if (MODE != 2) vals[5] = G_eff * dLa;
         tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
       }
       // this wave is the only writer of the (sub-tile, splat) record: 12 lanes store 48 contiguous bytes
@@ -363,7 +375,17 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
                          hipStream_t s) {
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL((composite_bwd_kernel<C>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+}
+void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
+                               float* dsub, hipStream_t s) {
+  uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  int T = cam.gx * cam.gy;
+  int grid = ((T + 7) / 8) * 8;
+  if (tracking)
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+  else
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,

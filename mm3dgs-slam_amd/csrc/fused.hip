@@ -166,6 +166,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
 
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
+template <bool TRACK>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out) {
@@ -195,11 +196,15 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         if (m & (1u << w)) {
+          // record layout (composite_bwd MODE 1 / 2): dxy dconic | dop drgb dz  or  dxy dconic dz
           const float4* r = (const float4*)(dsub + ((size_t)slot * 4 + w) * SPLAT_F);
-          const float4 a = r[0], b = r[1], c = r[2];
+          const float4 a = r[0], b = r[1];
           acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
           acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
-          acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
+          if (!TRACK) {
+            const float4 c = r[2];
+            acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
+          }
         }
       }
     };
@@ -230,8 +235,9 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
     float dlogit = 0.f, gnorm = 0.f;
     if (rad > 0) {
-      const float gpx = acc0.x, gpy = acc0.y, gA = acc0.z, gB = acc0.w, gC = acc1.x, dop = acc1.y;
-      const float dc0 = acc1.z, dc1 = acc1.w, dc2 = acc2.x, dz_ch = acc2.y, dz2_ch = acc2.w;
+      const float gpx = acc0.x, gpy = acc0.y, gA = acc0.z, gB = acc0.w, gC = acc1.x;
+      const float dop = TRACK ? 0.f : acc1.y, dc0 = acc1.z, dc1 = acc1.w, dc2 = acc2.x;
+      const float dz_tot = TRACK ? acc1.y : acc2.y;   // d/dz of the [z, 1, z^2] bundle, already chained by the compositor
       const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
       float p[3];
 #pragma unroll
@@ -277,7 +283,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const float dhx = gnx * pw, dhy = gny * pw, dhw = -(gnx * hx + gny * hy) * pw * pw;
 #pragma unroll
       for (int i = 0; i < 3; i++) dm[i] += PV[i * 4 + 0] * dhx + PV[i * 4 + 1] * dhy + PV[i * 4 + 3] * dhw;
-      dm[2] += dz_ch + 2.f * p[2] * dz2_ch;  // depth bundle [z, 1, z^2]
+      dm[2] += dz_tot;
       // pose: means_cam = R x + t
       cg[0] = dm[0] * x0; cg[1] = dm[0] * x1; cg[2] = dm[0] * x2;
       cg[3] = dm[1] * x0; cg[4] = dm[1] * x1; cg[5] = dm[1] * x2;
@@ -359,11 +365,22 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 // betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
 __global__ void slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
                                         float* __restrict__ dpose, PoseAdam ad) {
+  // 256 lanes: lane = 16 * rowgroup + column; every lane sums its strided rows, then the 16 row groups are added in a
+  // fixed order (deterministic, double precision)
+  __shared__ double part[16][16];
   __shared__ double tot[NPOSE];
   const int k = threadIdx.x;
+  {
+    const int col = k & 15, grp = k >> 4;
+    double acc = 0.0;
+    if (col < NPOSE)
+      for (int r = grp; r < nrows; r += 16) acc += (double)posepartial[(size_t)r * 32 + col];
+    part[grp][col] = acc;
+  }
+  __syncthreads();
   if (k < NPOSE) {
     double acc = 0.0;
-    for (int r = 0; r < nrows; r++) acc += (double)posepartial[(size_t)r * 32 + k];
+    for (int gq = 0; gq < 16; gq++) acc += part[gq][k];
     tot[k] = acc;
   }
   __syncthreads();
@@ -408,10 +425,15 @@ __global__ void slam_pose_finish_kernel(const float* __restrict__ posepartial, i
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, hipStream_t s) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
-  if (P > 0)
-    hipLaunchKernelGGL(slam_preprocess_bwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub,
-                       bw.campartial, out);
-  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(64), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
+  if (P > 0) {
+    if (out.d_xyz)
+      hipLaunchKernelGGL(slam_preprocess_bwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
+                         bw.dsub, bw.campartial, out);
+    else
+      hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
+                         bw.dsub, bw.campartial, out);
+  }
+  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(256), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ struct LossCfg {
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, hipStream_t s);
+void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
+                               float* dsub, hipStream_t s);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
-void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, float* dL,
-                 float* loss, hipStream_t s);
+void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
+                 float* dL, float* loss, hipStream_t s);

@@ -16,64 +16,71 @@
 #define LW (LT + 2 * HALO)  // 26
 #define NSUM 16
 
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-  // 256 lanes -> lane 0 (wave shuffle then LDS across the 4 waves)
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+// sum of NR per-lane doubles over the 256-lane workgroup: wave shuffle, then one LDS exchange for all values
+template <int NR>
+__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NR; k++) sh[wv][k] = v[k];
   __syncthreads();
-  if (lane == 0) sh[wv] = v;
-  __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < NR; k++) v[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
 }
 
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
-                   float* __restrict__ dmaps, double* __restrict__ sums) {
-  __shared__ float sI[LW][LW + 1], sG[LW][LW + 1];
-  __shared__ float hM1[LW][LT], hM2[LW][LT], hE11[LW][LT], hE22[LW][LT], hE12[LW][LT];
-  __shared__ double red[4];
+                   float* __restrict__ dmaps, double* __restrict__ partial) {
+  // all three colour channels are staged at once: 4 barriers per workgroup instead of ~40
+  __shared__ float sI[3][LW][LW + 1], sG[3][LW][LW + 1];
+  __shared__ float hM1[3][LW][LT], hM2[3][LW][LT], hE11[3][LW][LT], hE22[3][LW][LT], hE12[3][LW][LT];
+  __shared__ double red[4][12];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
   const int px = x0 + tx, py = y0 + ty;
   const bool inside = px < cfg.W && py < cfg.H;
   const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  double acc[NSUM];
+  double acc[12];
 #pragma unroll
-  for (int k = 0; k < NSUM; k++) acc[k] = 0.0;
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
   const float sil = inside ? out[4 * HW + pix] : 0.f;
   const bool smask = sil > cfg.sil_thr;
-  float l1 = 0.f;
-  for (int ch = 0; ch < 3; ch++) {
-    if (cfg.w_ssim != 0.f) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < LW * LW; i += 256) {
-        const int ly = i / LW, lx = i % LW;
-        const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-        const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-        sI[ly][lx] = in ? out[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
-        sG[ly][lx] = in ? gt[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
-      }
-      __syncthreads();
-      for (int i = threadIdx.x; i < LW * LT; i += 256) {
-        const int ly = i / LT, lx = i % LT;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  if (cfg.w_ssim != 0.f) {
+    for (int i = threadIdx.x; i < 3 * LW * LW; i += 256) {
+      const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+      const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+      sI[ch][ly][lx] = in ? out[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+      sG[ch][ly][lx] = in ? gt[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * LW * LT; i += 256) {
+      const int ch = i / (LW * LT), r = i % (LW * LT), ly = r / LT, lx = r % LT;
+      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-          const float a = sI[ly][lx + k], b = sG[ly][lx + k], w = cfg.window[k];
-          m1 += w * a; m2 += w * b; e11 += w * a * a; e22 += w * b * b; e12 += w * a * b;
-        }
-        hM1[ly][lx] = m1; hM2[ly][lx] = m2; hE11[ly][lx] = e11; hE22[ly][lx] = e22; hE12[ly][lx] = e12;
+      for (int k = 0; k < 11; k++) {
+        const float a = sI[ch][ly][lx + k], b = sG[ch][ly][lx + k], w = cfg.window[k];
+        m1 += w * a; m2 += w * b; e11 += w * a * a; e22 += w * b * b; e12 += w * a * b;
       }
-      __syncthreads();
+      hM1[ch][ly][lx] = m1; hM2[ch][ly][lx] = m2; hE11[ch][ly][lx] = e11; hE22[ch][ly][lx] = e22; hE12[ch][ly][lx] = e12;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
       float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; k++) {
         const float w = cfg.window[k];
-        m1 += w * hM1[ty + k][tx]; m2 += w * hM2[ty + k][tx]; e11 += w * hE11[ty + k][tx];
-        e22 += w * hE22[ty + k][tx]; e12 += w * hE12[ty + k][tx];
+        m1 += w * hM1[ch][ty + k][tx]; m2 += w * hM2[ch][ty + k][tx]; e11 += w * hE11[ch][ty + k][tx];
+        e22 += w * hE22[ch][ty + k][tx]; e12 += w * hE12[ch][ty + k][tx];
       }
       if (inside) {
         const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
@@ -89,9 +96,14 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
         dmaps[(ch * 3 + 2) * HW + pix] = df_ds12;                                    // d/d E[xy]
       }
     }
-    if (inside) l1 += fabsf(out[ch * HW + pix] - gt[ch * HW + pix]);
   }
-  if (inside && (cfg.l1_mask == 0 || smask)) { acc[0] = (double)l1; acc[1] = 1.0; }
+  if (inside && (cfg.l1_mask == 0 || smask)) {
+    float l1 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) l1 += fabsf(out[ch * HW + pix] - gt[ch * HW + pix]);
+    acc[0] = (double)l1;
+    acc[1] = 1.0;
+  }
   if (cfg.w_pearson != 0.f && inside) {
     const float r = ref[pix];
     bool m = true;
@@ -106,10 +118,28 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
       acc[9] = t2; acc[10] = t2 * t2; acc[11] = x * t2;
     }
   }
+  block_sums<12>(acc, red);
+  // one row of partial sums per workgroup (plain stores): 14k double atomics on two cache lines cost ~90 us
+  if (threadIdx.x == 0) {
+    double* row = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
 #pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const double s = block_sum(acc[k], red);
-    if (threadIdx.x == 0 && s != 0.0) atomicAdd(&sums[k], s);
+    for (int k = 0; k < 12; k++) row[k] = acc[k];
+  }
+}
+
+// one workgroup: fixed-order sum of the per-workgroup rows (deterministic)
+__global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restrict__ partial, int nrows, double* __restrict__ sums) {
+  __shared__ double part[16][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  double acc = 0.0;
+  if (col < 12)
+    for (int r = grp; r < nrows; r += 16) acc += partial[(size_t)r * 12 + col];
+  part[grp][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
+    for (int q = 0; q < 16; q++) t += part[q][threadIdx.x];
+    sums[threadIdx.x] = t;
   }
 }
 
@@ -124,8 +154,8 @@ __device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, d
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
                  const float* __restrict__ dmaps, const double* __restrict__ sums, float* __restrict__ dL, float* __restrict__ loss) {
-  __shared__ float sD[3][LW][LW + 1];
-  __shared__ float hD[3][LW][LT];
+  __shared__ float sD[9][LW][LW + 1];
+  __shared__ float hD[9][LW][LT];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
   const int px = x0 + tx, py = y0 + ty;
@@ -136,34 +166,38 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   const float ssim_scale = -cfg.w_ssim / (float)(3.0 * (double)HW);
   const float sil = inside ? out[4 * HW + pix] : 0.f;
   const bool smask = sil > cfg.sil_thr;
-  for (int ch = 0; ch < 3; ch++) {
-    float g = 0.f;
-    if (cfg.w_ssim != 0.f) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < 3 * LW * LW; i += 256) {
-        const int q = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
-        const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-        const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-        sD[q][ly][lx] = in ? dmaps[(ch * 3 + q) * HW + (size_t)gy * cfg.W + gx] : 0.f;
-      }
-      __syncthreads();
-      for (int i = threadIdx.x; i < 3 * LW * LT; i += 256) {
-        const int q = i / (LW * LT), r = i % (LW * LT), ly = r / LT, lx = r % LT;
-        float s = 0.f;
+  float gch[3] = {0.f, 0.f, 0.f};
+  if (cfg.w_ssim != 0.f) {
+    for (int i = threadIdx.x; i < 9 * LW * LW; i += 256) {
+      const int q = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+      const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+      sD[q][ly][lx] = in ? dmaps[q * HW + (size_t)gy * cfg.W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * LW * LT; i += 256) {
+      const int q = i / (LW * LT), r = i % (LW * LT), ly = r / LT, lx = r % LT;
+      float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) s += cfg.window[k] * sD[q][ly][lx + k];
-        hD[q][ly][lx] = s;
-      }
-      __syncthreads();
+      for (int k = 0; k < 11; k++) s += cfg.window[k] * sD[q][ly][lx + k];
+      hD[q][ly][lx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
       float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 11; k++) {
         const float w = cfg.window[k];
-        c0 += w * hD[0][ty + k][tx]; c1 += w * hD[1][ty + k][tx]; c2 += w * hD[2][ty + k][tx];
+        c0 += w * hD[ch * 3 + 0][ty + k][tx]; c1 += w * hD[ch * 3 + 1][ty + k][tx]; c2 += w * hD[ch * 3 + 2][ty + k][tx];
       }
-      if (inside) g = ssim_scale * (c0 + 2.f * out[ch * HW + pix] * c1 + gt[ch * HW + pix] * c2);
+      if (inside) gch[ch] = ssim_scale * (c0 + 2.f * out[ch * HW + pix] * c1 + gt[ch * HW + pix] * c2);
     }
-    if (inside) {
+  }
+  if (inside) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      float g = gch[ch];
       if (cfg.l1_mask == 0 || smask) {
         const float d = out[ch * HW + pix] - gt[ch * HW + pix];
         g += l1_scale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
@@ -214,10 +248,10 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   }
 }
 
-void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, float* dL,
-                 float* loss, hipStream_t s) {
+void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
+                 float* dL, float* loss, hipStream_t s) {
   dim3 grid((cfg.W + LT - 1) / LT, (cfg.H + LT - 1) / LT), block(256);
-  (void)hipMemsetAsync(sums, 0, NSUM * sizeof(double), s);
-  hipLaunchKernelGGL(loss_reduce_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, sums);
+  hipLaunchKernelGGL(loss_reduce_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, partial);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), block, 0, s, partial, (int)(grid.x * grid.y), sums);
   hipLaunchKernelGGL(loss_grad_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, sums, dL, loss);
 }

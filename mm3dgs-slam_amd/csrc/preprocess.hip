@@ -402,22 +402,32 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   }
 }
 
-// one wave: lane k (< 27) walks all workgroup partial rows in order, accumulating in double.
-__global__ void camgrad_finish_kernel(const float* __restrict__ campartial, int nrows, float* __restrict__ dview,
-                                      float* __restrict__ dproj, float* __restrict__ dcampos) {
-  int k = threadIdx.x;
-  if (k >= NCAM) return;
+// 256 lanes: lane = 32 * rowgroup + column (27 used); strided row sums, then the 8 row groups are added in a fixed order
+// in double precision (deterministic).
+__global__ void __launch_bounds__(256)
+camgrad_finish_kernel(const float* __restrict__ campartial, int nrows, float* __restrict__ dview, float* __restrict__ dproj,
+                      float* __restrict__ dcampos) {
+  __shared__ double part[8][32];
+  const int t = threadIdx.x, col = t & 31, grp = t >> 5;
   double acc = 0.0;
-  for (int r = 0; r < nrows; r++) acc += (double)campartial[(size_t)r * 32 + k];
-  float v = (float)acc;
-  if (k < 12) {
-    int i = k / 3, j = k % 3;
-    if (dview) dview[i * 4 + j] = v;
-  } else if (k < 24) {
-    int i = (k - 12) / 3, j = (k - 12) % 3;
-    if (dproj) dproj[i * 4 + (j == 2 ? 3 : j)] = v;
-  } else if (dcampos) {
-    dcampos[k - 24] = v;
+  if (col < NCAM)
+    for (int r = grp; r < nrows; r += 8) acc += (double)campartial[(size_t)r * 32 + col];
+  part[grp][col] = acc;
+  __syncthreads();
+  const int k = t;
+  if (k < NCAM) {
+    double tot = 0.0;
+    for (int q = 0; q < 8; q++) tot += part[q][k];
+    const float v = (float)tot;
+    if (k < 12) {
+      int i = k / 3, j = k % 3;
+      if (dview) dview[i * 4 + j] = v;
+    } else if (k < 24) {
+      int i = (k - 12) / 3, j = (k - 12) % 3;
+      if (dproj) dproj[i * 4 + (j == 2 ? 3 : j)] = v;
+    } else if (dcampos) {
+      dcampos[k - 24] = v;
+    }
   }
   if (k < 4) {  // matrix entries that never receive gradient
     if (dview) dview[k * 4 + 3] = 0.f;
@@ -438,7 +448,7 @@ void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* 
 }
 
 void launch_camgrad_finish(BwdView bw, float* dview, float* dproj, float* dcampos, hipStream_t s) {
-  hipLaunchKernelGGL(camgrad_finish_kernel, dim3(1), dim3(64), 0, s, bw.campartial, bw.nrows, dview,
+  hipLaunchKernelGGL(camgrad_finish_kernel, dim3(1), dim3(256), 0, s, bw.campartial, bw.nrows, dview,
                      dproj, dcampos);
 }
 

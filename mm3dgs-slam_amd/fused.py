@@ -43,7 +43,9 @@ class FusedEngine:
         self.dev = torch.device(renderer.cfg["device"])
         self.lib = _lib.load()
         self.H, self.W = renderer.image_height, renderer.image_width
-        self.img_state = torch.empty(self.lib.mm3dgs_image_bytes(self.H, self.W), dtype=torch.uint8, device=self.dev)
+        # persistent and zero-initialised: the library leaves the header / tile counters zero after every forward
+        self.img_state = torch.zeros(self.lib.mm3dgs_image_bytes(self.H, self.W), dtype=torch.uint8, device=self.dev)
+        self.max_tile_len = 1 << 30
         self.out = torch.empty((6, self.H, self.W), device=self.dev)
         self.dL = torch.empty((6, self.H, self.W), device=self.dev)
         self.loss = torch.zeros(4, device=self.dev)
@@ -98,14 +100,16 @@ class FusedEngine:
         P = int(g._xyz.shape[0])
         self._ensure(P, need_grads)
         si = self.inputs(pose, g)
+        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)      # STATE_CLEAN | SHORT_LISTS (hint from the last check)
         _lib.check(self.lib.mm3dgs_slam_forward(C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
-                                                _p(self.img_state), _p(self.binning), self.n_cap, _stream()))
+                                                _p(self.img_state), _p(self.binning), self.n_cap, flags, _stream()))
         return si
 
     def check_capacity(self):
         """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
         h = self.img_state[:16].view(torch.int32).cpu()
         n, overflow = int(h[0]), int(h[1])
+        self.max_tile_len = int(h[2])
         self.ratio = max(self.ratio or 0.0, n / max(self.P, 1))
         if overflow:
             raise RuntimeError(f"mm3dgs fused render overflowed its binning capacity ({n} > {self.n_cap}); results of the "
