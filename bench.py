@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--policy", default="async", choices=["async", "exact"])
     ap.add_argument("--render-mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
+                    "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=50000)
     return ap.parse_args()
 
@@ -135,7 +137,7 @@ def main():
         torch.cuda.synchronize()
 
     _lib.profile_read()
-    _lib.profile_enable(True)
+    _lib.profile_enable(args.profile)
     barrier()
     log("timed region")
     t0 = time.perf_counter()
@@ -188,7 +190,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                            "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": dur * 1e6, "launches": n_bwd}
-        out["kernel_us"] = {k: (v[1] / v[0] * 1e3 if v[0] else None) for k, v in prof.items()}
+        out["kernel_us"] = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")
         out["cpu_baseline"] = cpu_baseline(args)

@@ -155,6 +155,14 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
                          const float* dL_dout /*[6,H,W]*/, void* backward_scratch, const Mm3dgsSlamGrads* grads,
                          float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, void* stream);
 
+/* n_iter tracking iterations enqueued back to back from C (slam/tracker.py:94-177 with the "vigs" loss): each is
+ * forward -> loss -> backward with the pose Adam step on the device; the pose buffer is updated in place. */
+int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color,
+                      int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity,
+                      int fwd_flags, const struct Mm3dgsLossConfig* loss_cfg, const float* gt_color,
+                      const float* ref_depth_or_null, void* loss_work, float* dL_dout, float* loss4,
+                      void* backward_scratch, const Mm3dgsPoseAdam* pose_adam, void* stream);
+
 /* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:856-873,
  * utils/loss_utils.py): w_l1 * mean|rgb-gt| (optionally over silhouette > sil_thr) + w_ssim * (1 - SSIM 11x11)
  * + w_pearson * (1 - rho(depth, ref)).  loss[4] = {total, l1, 1-ssim, 1-rho}.  work: mm3dgs_loss_work_bytes(). */
@@ -188,7 +196,7 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float bet
 #define MM3DGS_PROF_LOSS 6
 #define MM3DGS_PROF_ADAM 7
 #define MM3DGS_PROF_KERNELS 8
-void mm3dgs_profile_enable(int on);
+void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 only the backward compositor */
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 
 const char* mm3dgs_last_error(void);

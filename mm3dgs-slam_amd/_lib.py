@@ -66,6 +66,8 @@ _SIGS = {
                                       C.c_int, _P]),
     "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
                                        C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), _P]),
+    "mm3dgs_slam_track": (C.c_int, [C.c_int, C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
+                                    C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, C.POINTER(Mm3dgsPoseAdam), _P]),
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_loss": (C.c_int, [C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, _P]),
     "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
@@ -103,8 +105,9 @@ def load():
 PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam")
 
 
-def profile_enable(on: bool):
-    load().mm3dgs_profile_enable(1 if on else 0)
+def profile_enable(mode):
+    """0/False off, 1/True every kernel, 2 only the backward compositor."""
+    load().mm3dgs_profile_enable(int(mode))
 
 
 def profile_read():

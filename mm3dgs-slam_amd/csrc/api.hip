@@ -34,7 +34,8 @@ static std::mutex g_prof_mu;
 static int g_prof_on = 0;
 struct ProfScope {
   int k; hipStream_t s; hipEvent_t e1 = nullptr; bool on;
-  ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on != 0) {
+  // g_prof_on: 0 off, 1 every kernel, 2 only the backward compositor (the roofline kernel: 2 events per iteration)
+  ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && k_ == MM3DGS_PROF_COMPOSITE_BWD)) {
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -260,6 +261,26 @@ int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_co
   launch_loss(lc, out6, gt_color, ref, (float*)(w + 256), (double*)w, (double*)(w + 256 + align_up((size_t)9 * c->H * c->W * 4, 256)), dL,
               loss4, s);
   return check_launch("loss");
+}
+
+int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
+                      void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags,
+                      const Mm3dgsLossConfig* loss_cfg, const float* gt_color, const float* ref, void* loss_work, float* dL_dout,
+                      float* loss4, void* backward_scratch, const Mm3dgsPoseAdam* pose_adam, void* stream) {
+  if (n_iter < 0) return fail(-1, "n_iter < 0");
+  if (!pose_adam || !pose_adam->pose) return fail(-2, "tracking needs the pose Adam state");
+  Mm3dgsSlamGrads none;
+  memset(&none, 0, sizeof(none));
+  for (int it = 0; it < n_iter; it++) {
+    int rc = mm3dgs_slam_forward(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
+    if (rc) return rc;
+    rc = mm3dgs_loss(loss_cfg, out_color, gt_color, ref, loss_work, dL_dout, loss4, stream);
+    if (rc) return rc;
+    rc = mm3dgs_slam_backward(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
+                              nullptr, pose_adam, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float beta1, float beta2, float eps, void* stream) {

@@ -84,9 +84,13 @@ class FusedEngine:
             self.binning = torch.empty(self.lib.mm3dgs_binning_bytes(self.n_cap), **u8)
             self.scratch = torch.empty(self.lib.mm3dgs_backward_scratch_bytes(P, self.n_cap), **u8)
         if need_grads and self.grads is None:
-            f = dict(device=self.dev)
-            self.grads = dict(xyz=torch.empty(P, 3, **f), f_dc=torch.empty(P, 1, 3, **f), opacity=torch.empty(P, 1, **f),
-                              scaling=torch.empty(P, 3, **f), rotation=torch.empty(P, 4, **f))
+            # one flat buffer [xyz 3P | f_dc 3P | opacity P | scaling 3P | rotation 4P | accum P | denom P]: the multi-GPU
+            # window all-reduces it in a single collective (window_parallel.py)
+            self.flat = torch.zeros(16 * P, device=self.dev)
+            o = [0, 3 * P, 6 * P, 7 * P, 10 * P, 14 * P, 15 * P, 16 * P]
+            v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
+            self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))
+            self.stat_delta = (torch.zeros(P, device=self.dev), v(5, (P, 1)), v(6, (P, 1)))   # max radii | accum | denom
 
     def inputs(self, pose, g):
         si = _lib.Mm3dgsSlamInputs()
@@ -104,6 +108,17 @@ class FusedEngine:
         _lib.check(self.lib.mm3dgs_slam_forward(C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                                 _p(self.img_state), _p(self.binning), self.n_cap, flags, _stream()))
         return si
+
+    def track_loop(self, n_iter, pose, g, lcfg, gt_color, ref, pose_adam):
+        """All tracking iterations of a frame enqueued by one C call (no Python in the loop)."""
+        P = int(g._xyz.shape[0])
+        self._ensure(P, False)
+        si = self.inputs(pose, g)
+        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)
+        _lib.check(self.lib.mm3dgs_slam_track(n_iter, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
+                                              _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(gt_color),
+                                              _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
+                                              C.byref(pose_adam), _stream()))
 
     def check_capacity(self):
         """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
@@ -171,10 +186,7 @@ class FusedTracker(Tracker):
             gt_color = gt_color.contiguous()
             ref = None if ref is None else ref.contiguous()
             g = self.gaussians
-            for _ in range(num_iter):
-                si = eng.forward(pose, g)
-                eng.loss_call(lcfg, gt_color, ref)
-                eng.backward(si, dpose=None, pose_adam=ad)
+            eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
             eng.check_capacity()
             camera_tensor_q.data.copy_(pose[:4])
             camera_tensor_T.data.copy_(pose[4:])
@@ -186,7 +198,7 @@ class FusedMapper(Mapper):
     def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]
-        if (num_iter == 0 or (m["do_BA"] and idx > 0) or self.window is not None or not FusedEngine.eligible(self.cfg, self.gaussians)):
+        if (num_iter == 0 or (m["do_BA"] and idx > 0) or not FusedEngine.eligible(self.cfg, self.gaussians)):
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
@@ -200,9 +212,12 @@ class FusedMapper(Mapper):
         stack = None
         with torch.no_grad():
             for iteration in range(num_iter):
-                if not stack:
-                    stack = list(keyframe_idx_list)
-                k = stack.pop(randint(0, len(stack) - 1))
+                def pop():
+                    nonlocal stack
+                    if not stack:
+                        stack = list(keyframe_idx_list)
+                    return stack.pop(randint(0, len(stack) - 1))
+                k = self.window.take(pop) if self.window is not None else pop()
                 if k == -1:
                     pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
                 else:
@@ -215,8 +230,18 @@ class FusedMapper(Mapper):
                 si = eng.forward(pose, g, need_grads=True)
                 eng.loss_call(lcfg, gt_color.contiguous(), ref)
                 densify = iteration <= m["densify_until_iter"]
-                stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
-                eng.backward(si, grads=eng.grads, stats=stats)
+                if self.window is not None and self.window.world > 1:
+                    # each rank rendered a different keyframe: sum gradients and statistics over the window
+                    eng.stat_delta[0].zero_(); eng.stat_delta[1].zero_(); eng.stat_delta[2].zero_()
+                    eng.backward(si, grads=eng.grads, stats=eng.stat_delta if densify else None)
+                    self.window.reduce_flat(eng.flat, eng.stat_delta[0])
+                    if densify:
+                        g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
+                        g.xyz_gradient_accum += eng.stat_delta[1]
+                        g.denom += eng.stat_delta[2]
+                else:
+                    stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
+                    eng.backward(si, grads=eng.grads, stats=stats)
                 pruned_now = False
                 if densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0:
                     g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])

@@ -55,3 +55,9 @@ class WindowParallel:
                 p.grad = flat[:, off:off + n].reshape(p.shape).clone()
             off += n
         return flat[:, off:off + 1], flat[:, off + 1:off + 2], rmax
+
+    def reduce_flat(self, flat, rmax):
+        """Native-loop variant: `flat` is the engine's single gradient+statistics buffer (sum), `rmax` the radii (max)."""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)

@@ -195,3 +195,35 @@ def test_fused_path_matches_float64_oracle():
     assert pu.rel_l2(eng.dpose, p64.grad) <= 1e-5          # north_star: pose gradients <= 1e-5
     for name, key in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation")):
         assert pu.rel_l2(eng.grads[name], leaf[key].grad) <= pu.GRAD_TOL, name
+
+
+def _window_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share the one GPU of the test box
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 5}, mapping={"iters": 6, "kf_every": 1})
+    seq = SyntheticSequence(cfg, 3, 6000, seed=6)
+    slam = SLAM(cfg, seq, window=WindowParallel(rank, world))
+    assert type(slam.mapper).__name__ == "FusedMapper"
+    for i in range(3):
+        slam.step(i)
+    torch.save({"xyz": slam.gaussians._xyz.detach().cpu(), "op": slam.gaussians._opacity.detach().cpu(),
+                "acc": slam.gaussians.xyz_gradient_accum.cpu()}, os.path.join(out, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_mapper_window_parallel_two_ranks(tmp_path):
+    """Native mapping loop with the keyframe window sharded over 2 ranks (gloo, both on this GPU): ranks stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_window_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert a["xyz"].shape == b["xyz"].shape and a["xyz"].shape[0] > 0
+    assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["op"], b["op"]) and torch.equal(a["acc"], b["acc"])
