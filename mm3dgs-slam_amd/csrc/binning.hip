@@ -162,6 +162,8 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
   }
 }
 
+#define RANK_SORT_MAX 1024  // lists up to this length are rank-sorted (needs 2 * RANK_SORT_MAX <= CAP keys of LDS)
+
 // Tier kernel: handles tiles with lo < len <= CAP in LDS; when GLOBAL_TAIL it also sorts len > CAP in place in
 // global memory (rare: > 16 K splats on one tile).  After sorting it emits the four sub-tile lists.
 template <int CAP, bool GLOBAL_TAIL>
@@ -183,7 +185,21 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
   if (!GLOBAL_TAIL && len > CAP) return;
   unsigned long long* gk = b.keys + start;
   const bool in_lds = len <= CAP;
-  if (in_lds) {
+  if (in_lds && len <= RANK_SORT_MAX) {
+    // rank sort: keys are unique, so rank(i) = #{ j : key_j < key_i } is a permutation.  Every lane walks the whole
+    // list with broadcast LDS reads (no bank conflicts, ONE barrier) -- far cheaper than the ~45 barrier-separated
+    // steps of a bitonic network at SLAM list lengths (a few hundred).
+    unsigned long long* sk2 = sk + RANK_SORT_MAX;
+    for (int i = tid; i < len; i += 256) sk2[i] = gk[i];
+    __syncthreads();
+    for (int i = tid; i < len; i += 256) {
+      const unsigned long long mine = sk2[i];
+      int rank = 0;
+      for (int j = 0; j < len; j++) rank += (sk2[j] < mine) ? 1 : 0;
+      sk[rank] = mine;
+    }
+    __syncthreads();
+  } else if (in_lds) {
     for (int i = tid; i < len; i += 256) sk[i] = gk[i];
     __syncthreads();
     if (len > 1) bitonic_any_len([&](int i) -> unsigned long long& { return sk[i]; }, len, tid, 256);

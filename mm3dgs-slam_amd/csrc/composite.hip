@@ -208,10 +208,12 @@ __device__ __forceinline__ float xrow_sum(float v) {
   return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 
-// MODE 0: generic, record = dxy(2) dconic(3) dopacity(1) dcolour(C).
-// MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): record = dxy dconic dopacity drgb(3) dz(1) with
+// Record written per (sub-tile, splat); m = (m_x, m_y, m_xx, m_xy, m_yy) are the moments sum_p u_p (dx, dy, dx^2, dx dy, dy^2)
+// of u = dL/dG * G over the sub-tile's pixels (d/dxy and d/dconic follow from them with the splat's conic).
+// MODE 0: generic, record = m(5) dopacity(1) dcolour(C).
+// MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): record = m(5) dopacity drgb(3) dz(1) with
 //         dz = sum w (dL_3 + 2 z dL_5) -- the chain rule of the depth bundle folded into the reduction (10 values, not 12).
-// MODE 2: SLAM tracking: record = dxy dconic dz (6 values): opacity / colour gradients are never consumed.
+// MODE 2: SLAM tracking: record = m(5) dz (6 values): opacity / colour gradients are never consumed.
 template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
@@ -250,9 +252,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   }
   const float Tf_bg = T_final * bg_dot;
   float Tr = T_final;
-  float behind[C];  // colour accumulated behind the current list position
-#pragma unroll
-  for (int ch = 0; ch < C; ch++) behind[ch] = 0.f;
+  float behind_dot = 0.f;  // (colour accumulated behind the current list position) . dL
 
   // nothing behind the deepest contributor of any pixel of the sub-tile matters
   uint32_t todo = last_contributor;
@@ -324,27 +324,32 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         if (C > 4) col[4] = Cc.z;
         if (C > 5) col[5] = Cc.w;
         float vals[NV];
-        float dLa = 0.f;
+        // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
+        // (behind_dot) instead of C running colours: q = c . dL;  dLa = q - behind_dot;  behind_dot += a (q - behind_dot)
+        float q = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) {
-          const float diff = col[ch] - behind[ch];
-          dLa = fmaf(diff, dL[ch], dLa);
-          behind[ch] = fmaf(a_eff, diff, behind[ch]);
-          if (MODE == 0) vals[6 + ch] = w * dL[ch];
+        for (int ch = 0; ch < C; ch++) q = fmaf(col[ch], dL[ch], q);
+        const float diff = q - behind_dot;
+        behind_dot = fmaf(a_eff, diff, behind_dot);
+        if (MODE == 0) {
+#pragma unroll
+          for (int ch = 0; ch < C; ch++) vals[6 + ch] = w * dL[ch];
         }
         if (MODE == 1) {
           vals[6] = w * dL[0]; vals[7] = w * dL[1]; vals[8] = w * dL[2];
           vals[9] = w * fmaf(2.f * col[3], dL[5], dL[3]);
         }
         if (MODE == 2) vals[5] = w * fmaf(2.f * col[3], dL[5], dL[3]);
-        dLa = dLa * Tr - Tf_bg * r;
-        const float dL_dG = B.y * dLa;
-        const float gdx = G_eff * dx, gdy = G_eff * dy;
-        vals[0] = -dL_dG * (gdx * A.z + gdy * A.w);
-        vals[1] = -dL_dG * (gdy * B.x + gdx * A.w);
-        vals[2] = -0.5f * gdx * dx * dL_dG;
-        vals[3] = -gdx * dy * dL_dG;
-        vals[4] = -0.5f * gdy * dy * dL_dG;
+        const float dLa = diff * Tr - Tf_bg * r;
+        // screen-space geometry: only the five moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns
+        // them into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
+        const float u = B.y * dLa * G_eff;
+        const float mx = u * dx, my = u * dy;
+        vals[0] = mx;
+        vals[1] = my;
+        vals[2] = mx * dx;
+        vals[3] = mx * dy;
+        vals[4] = my * dy;
         if (MODE != 2) vals[5] = G_eff * dLa;
         tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
       }

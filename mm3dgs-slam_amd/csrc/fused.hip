@@ -235,7 +235,12 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
     float dlogit = 0.f, gnorm = 0.f;
     if (rad > 0) {
-      const float gpx = acc0.x, gpy = acc0.y, gA = acc0.z, gB = acc0.w, gC = acc1.x;
+      // moments -> d/dxy (pixel units) and d/dconic, with this splat's conic (composite.hip record layout)
+      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
+      const float4 sp0 = spl[0], sp1 = spl[1];
+      const float qa = sp0.z, qb = sp0.w, qc = sp1.x;
+      const float gpx = -(qa * acc0.x + qb * acc0.y), gpy = -(qc * acc0.y + qb * acc0.x);
+      const float gA = -0.5f * acc0.z, gB = -acc0.w, gC = -0.5f * acc1.x;
       const float dop = TRACK ? 0.f : acc1.y, dc0 = acc1.z, dc1 = acc1.w, dc2 = acc2.x;
       const float dz_tot = TRACK ? acc1.y : acc2.y;   // d/dz of the [z, 1, z^2] bundle, already chained by the compositor
       const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
@@ -445,12 +450,29 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(AdamArgs a) {
   for (int gi = 0; gi < a.ngroups; gi++) {
     const AdamGroup G = a.grp[gi];
     const float step = G.lr / a.bc1;
-    for (unsigned long long i = tid; i < G.n; i += stride) {
-      const float gr = G.g[i];
-      const float mi = G.m[i] + (gr - G.m[i]) * (1.f - a.beta1);
-      const float vi = G.v[i] * a.beta2 + gr * gr * (1.f - a.beta2);
-      G.m[i] = mi; G.v[i] = vi;
-      G.p[i] -= step * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+    const bool vec = ((G.n & 3ull) == 0) && ((((uintptr_t)G.p | (uintptr_t)G.g | (uintptr_t)G.m | (uintptr_t)G.v) & 15) == 0);
+    if (vec) {
+      const unsigned long long n4 = G.n >> 2;
+      float4* p4 = (float4*)G.p; const float4* g4 = (const float4*)G.g; float4* m4 = (float4*)G.m; float4* v4 = (float4*)G.v;
+      for (unsigned long long i = tid; i < n4; i += stride) {
+        float4 pr = p4[i], gr = g4[i], mi = m4[i], vi = v4[i];
+        float* pp = (float*)&pr; const float* gg = (const float*)&gr; float* mm = (float*)&mi; float* vv = (float*)&vi;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          mm[c] = mm[c] + (gg[c] - mm[c]) * (1.f - a.beta1);
+          vv[c] = vv[c] * a.beta2 + gg[c] * gg[c] * (1.f - a.beta2);
+          pp[c] -= step * (mm[c] / (sqrtf(vv[c]) / a.bc2s + a.eps));
+        }
+        p4[i] = pr; m4[i] = mi; v4[i] = vi;
+      }
+    } else {
+      for (unsigned long long i = tid; i < G.n; i += stride) {
+        const float gr = G.g[i];
+        const float mi = G.m[i] + (gr - G.m[i]) * (1.f - a.beta1);
+        const float vi = G.v[i] * a.beta2 + gr * gr * (1.f - a.beta2);
+        G.m[i] = mi; G.v[i] = vi;
+        G.p[i] -= step * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+      }
     }
   }
 }
@@ -458,7 +480,7 @@ void launch_fused_adam(const AdamArgs& a, hipStream_t s) {
   unsigned long long tot = 0;
   for (int i = 0; i < a.ngroups; i++) tot = tot > a.grp[i].n ? tot : a.grp[i].n;
   if (!tot) return;
-  int blocks = (int)((tot + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((tot / 4 + 255) / 256) + 1;
+  if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(fused_adam_kernel, dim3(blocks), dim3(256), 0, s, a);
 }

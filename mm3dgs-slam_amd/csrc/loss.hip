@@ -16,18 +16,16 @@
 #define LW (LT + 2 * HALO)  // 26
 #define NSUM 16
 
-// sum of NR per-lane doubles over the 256-lane workgroup: wave shuffle, then one LDS exchange for all values
+// sum of NR per-lane values over the 256-lane workgroup: float DPP reduction inside each wave (<= 64 addends), the four
+// wave totals are combined in double by lane 0
 template <int NR>
 __device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR]) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NR; k++) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    const float t = wave_sum_to_lane63((float)v[k]);
+    if (lane == 63) sh[wv][k] = (double)t;
   }
-  if (lane == 0)
-#pragma unroll
-    for (int k = 0; k < NR; k++) sh[wv][k] = v[k];
   __syncthreads();
   if (threadIdx.x == 0)
 #pragma unroll

@@ -230,7 +230,12 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     const bool vis = radii[idx] > 0;
     if (vis) {
       float4 d0 = acc0, d1 = acc1, d2 = acc2;
-      float gpx = d0.x, gpy = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
+      // moments -> d/dxy (pixel units) and d/dconic, with this splat's conic (composite.hip record layout)
+      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
+      const float4 sp0 = spl[0], sp1 = spl[1];
+      const float qa = sp0.z, qb = sp0.w, qc = sp1.x;
+      float gpx = -(qa * d0.x + qb * d0.y), gpy = -(qc * d0.y + qb * d0.x);
+      float gA = -0.5f * d0.z, gB = -d0.w, gC = -0.5f * d1.x;
       dop = d1.y;
       dcol[0] = d1.z; dcol[1] = d1.w; dcol[2] = d2.x; dcol[3] = d2.y; dcol[4] = d2.z; dcol[5] = d2.w;
       float p[3] = {means3D[(size_t)idx * 3], means3D[(size_t)idx * 3 + 1], means3D[(size_t)idx * 3 + 2]};
