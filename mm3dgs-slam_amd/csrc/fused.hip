@@ -368,24 +368,27 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 // One wave: fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through
 // R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
 // betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
-__global__ void slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
+__global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
                                         float* __restrict__ dpose, PoseAdam ad) {
-  // 256 lanes: lane = 16 * rowgroup + column; every lane sums its strided rows, then the 16 row groups are added in a
-  // fixed order (deterministic, double precision)
-  __shared__ double part[16][16];
+  // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
+  // added in a fixed order (deterministic, double precision)
+  __shared__ double part[64][16];
   __shared__ double tot[NPOSE];
   const int k = threadIdx.x;
   {
     const int col = k & 15, grp = k >> 4;
-    double acc = 0.0;
-    if (col < NPOSE)
-      for (int r = grp; r < nrows; r += 16) acc += (double)posepartial[(size_t)r * 32 + col];
-    part[grp][col] = acc;
+    double a0 = 0.0, a1 = 0.0;
+    if (col < NPOSE) {
+      int r = grp;
+      for (; r + 64 < nrows; r += 128) { a0 += (double)posepartial[(size_t)r * 32 + col]; a1 += (double)posepartial[(size_t)(r + 64) * 32 + col]; }
+      if (r < nrows) a0 += (double)posepartial[(size_t)r * 32 + col];
+    }
+    part[grp][col] = a0 + a1;
   }
   __syncthreads();
   if (k < NPOSE) {
     double acc = 0.0;
-    for (int gq = 0; gq < 16; gq++) acc += part[gq][k];
+    for (int gq = 0; gq < 64; gq++) acc += part[gq][k];
     tot[k] = acc;
   }
   __syncthreads();
@@ -438,7 +441,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
                          bw.dsub, bw.campartial, out);
   }
-  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(256), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
+  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -125,18 +125,22 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
   }
 }
 
-// one workgroup: fixed-order sum of the per-workgroup rows (deterministic)
-__global__ void __launch_bounds__(256) loss_finish_kernel(const double* __restrict__ partial, int nrows, double* __restrict__ sums) {
-  __shared__ double part[16][16];
+// one 1024-lane workgroup: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short (the
+// kernel is pure latency), then the groups are added in a fixed order (deterministic)
+__global__ void __launch_bounds__(1024) loss_finish_kernel(const double* __restrict__ partial, int nrows, double* __restrict__ sums) {
+  __shared__ double part[64][16];
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  double acc = 0.0;
-  if (col < 12)
-    for (int r = grp; r < nrows; r += 16) acc += partial[(size_t)r * 12 + col];
-  part[grp][col] = acc;
+  double a0 = 0.0, a1 = 0.0;
+  if (col < 12) {
+    int r = grp;
+    for (; r + 64 < nrows; r += 128) { a0 += partial[(size_t)r * 12 + col]; a1 += partial[(size_t)(r + 64) * 12 + col]; }
+    if (r < nrows) a0 += partial[(size_t)r * 12 + col];
+  }
+  part[grp][col] = a0 + a1;
   __syncthreads();
   if (threadIdx.x < 16) {
     double t = 0.0;
-    for (int q = 0; q < 16; q++) t += part[q][threadIdx.x];
+    for (int q = 0; q < 64; q++) t += part[q][threadIdx.x];
     sums[threadIdx.x] = t;
   }
 }
@@ -250,6 +254,6 @@ void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const fl
                  float* dL, float* loss, hipStream_t s) {
   dim3 grid((cfg.W + LT - 1) / LT, (cfg.H + LT - 1) / LT), block(256);
   hipLaunchKernelGGL(loss_reduce_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, partial);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), block, 0, s, partial, (int)(grid.x * grid.y), sums);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)(grid.x * grid.y), sums);
   hipLaunchKernelGGL(loss_grad_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, sums, dL, loss);
 }
