@@ -295,12 +295,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     const uint32_t* wI = sI[cur][wv];
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, todo - base));
-    float4 A = wA[0], B = wB[0], Cc = wC[0];
-    uint32_t ti = wI[0];
-    for (int j = 0; j < cnt; j++) {
-      const int jn = j + 1 < cnt ? j + 1 : j;
-      const float4 nA = wA[jn], nB = wB[jn], nC = wC[C > 2 ? jn : 0];
-      const uint32_t nti = wI[jn];
+    // one splat: evaluate, reduce over the wave, store the record
+    auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti, const int j) {
       const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the sub-tile list
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
@@ -355,7 +351,22 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       }
       // this wave is the only writer of the (sub-tile, splat) record: 12 lanes store 48 contiguous bytes
       if (my_slot >= 0) my_rec[(size_t)ti * (4 * SPLAT_F)] = tot;
-      A = nA; B = nB; Cc = nC; ti = nti;
+    };
+    // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
+    // without any register-to-register copies
+    float4 A0 = wA[0], B0 = wB[0], C0 = wC[0];
+    uint32_t t0 = wI[0];
+    for (int j = 0; j < cnt; j += 2) {
+      const int j1 = j + 1 < cnt ? j + 1 : j;
+      const float4 A1 = wA[j1], B1 = wB[j1], C1 = wC[C > 2 ? j1 : 0];
+      const uint32_t t1 = wI[j1];
+      splat_bwd(A0, B0, C0, t0, j);
+      if (j + 1 < cnt) {
+        const int j2 = j + 2 < cnt ? j + 2 : j1;
+        A0 = wA[j2]; B0 = wB[j2]; C0 = wC[C > 2 ? j2 : 0];
+        t0 = wI[j2];
+        splat_bwd(A1, B1, C1, t1, j1);
+      }
     }
     sA[cur ^ 1][wv][lane] = rec_n.A;
     sB[cur ^ 1][wv][lane] = rec_n.B;
