@@ -57,9 +57,10 @@ def log(msg):
 
 
 def cpu_baseline(args):
-    """PyTorch-CPU oracle on the host cores, bounded sample: ONE tracking iteration (fused render fwd + masked-L1 +
-    backward) of config C1's scene at HALF resolution per axis (a quarter of the 16x16 tiles and a quarter of the 50k
-    Gaussians: same splats-per-tile density), scaled by 4 to the full 640x480 / 50k iteration and by 250 to a frame."""
+    """PyTorch-CPU oracle on the host cores, bounded sample of config C1 (BASELINE.json configs[0]: 640x480, 50k
+    Gaussians, tracking): whole tracking iterations (fused 6-channel render fwd + masked-L1 + backward through the
+    torch-graph Renderer with the oracle rasterizer injected) repeated until ~10 s of CPU work or 5 iterations, then
+    scaled to the iterations of a frame."""
     from mm3dgs_slam_amd import synthetic as syn
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.renderer import Renderer
@@ -67,7 +68,7 @@ def cpu_baseline(args):
     from oracle.raster_ref import RefRasterizer
     cores = min(os.cpu_count() or 1, 16)        # the oracle is a Python loop over tiles of small tensor ops: more threads only add overhead
     torch.set_num_threads(cores)
-    H, W, P = args.height // 2, args.width // 2, args.cpu_baseline_gaussians // 4
+    H, W, P = args.height, args.width, args.cpu_baseline_gaussians
     cfg = default_config(device="cpu", height=H, width=W)
     c = cfg["cam"]
     color, depth = syn.rgbd_frame(H, W, seed=0)
@@ -75,19 +76,39 @@ def cpu_baseline(args):
     pc = _FixedMap(G, cfg)
     R = Renderer(cfg, rasterizer_cls=RefRasterizer)
     pose = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], requires_grad=True)
-    t0 = time.perf_counter()
-    r = R.render(pc, pose)
-    sil = r["depth"][1]
-    loss = (r["render"] - color).abs()[:, sil > 0.99].mean()
-    loss.backward()
-    sec = (time.perf_counter() - t0) * 4.0
+    n, t0 = 0, time.perf_counter()
+    while n < 5 and (n == 0 or time.perf_counter() - t0 < 10.0):
+        pose.grad = None
+        r = R.render(pc, pose)
+        sil = r["depth"][1]
+        loss = (r["render"] - color).abs()[:, sil > 0.99].mean()
+        loss.backward()
+        n += 1
+    sec = (time.perf_counter() - t0) / n
     per_frame = sec * (args.track_iters + args.map_iters)
     return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 tracking iteration (fused 6-channel render fwd + masked-L1 + backward) of the PyTorch-CPU oracle at "
-                      f"{W}x{H}, {P} Gaussians (a quarter of config C1's tiles and Gaussians) x4 = {sec:.1f} s per full-size "
-                      f"iteration, x{args.track_iters + args.map_iters} iterations/frame; the reference itself has no CPU path "
-                      f"(CUDA-only rasterizer)",
+            "sample": f"{n} tracking iteration(s) (fused 6-channel render fwd + masked-L1 + backward) of the PyTorch-CPU oracle at "
+                      f"{W}x{H}, {P} Gaussians (BASELINE.json configs[0]) = {sec:.2f} s each, x{args.track_iters + args.map_iters} "
+                      f"iterations/frame; the reference itself has no CPU path (CUDA-only rasterizer)",
             "sec_per_iteration": sec}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the backward compositor from the committed rocprofv3 PMC passes (profiles/*_pmc_*.csv,
+    produced by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KB units, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950).  None when no such summary is committed."""
+    import csv
+    import glob
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_slam_pmc_{c}.csv")))
+        if not files:
+            return None
+        rows = [r for r in csv.DictReader(open(files[-1])) if "composite_bwd_kernel<6, 1>" in r["kernel"]]
+        if not rows:
+            return None
+        vals[c] = float(rows[0]["mean_counter_value"]) * 1024.0
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
 
 
 def main():
@@ -188,7 +209,7 @@ def main():
         dur = ms_bwd / n_bwd * 1e-3
         ach = alg_bytes / dur / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                           "frac": ach / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                           "frac": ach / 8000.0, "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": dur * 1e6, "launches": n_bwd}
         out["kernel_us"] = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:

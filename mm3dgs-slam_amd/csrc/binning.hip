@@ -225,8 +225,8 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
       // alpha >= 1/255  <=>  d^T Q d <= 2 tau, tau = ln(255 o), Q = [[A.z, A.w],[A.w, B.x]]
       const float tau = __logf(255.f * B.y);
       const float det = A.z * B.x - A.w * A.w;
-      bool ovx0, ovx1, ovy0, ovy1;
       if (det > 0.f) {
+        bool ovx0, ovx1, ovy0, ovy1;
         const float k = 2.f * fmaxf(tau, 0.f) / det;
         const float hx = sqrtf(k * B.x) * 1.0002f + 0.002f;
         const float hy = sqrtf(k * A.z) * 1.0002f + 0.002f;
@@ -237,10 +237,21 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
         ovx1 = live && (xl <= 15.f) && (xh >= 8.f);
         ovy0 = live && (yl <= 7.f) && (yh >= 0.f);
         ovy1 = live && (yl <= 15.f) && (yh >= 8.f);
+        // second necessary condition: the sub-tile must come within sqrt(2 tau lambda_max) of the centre (exact for
+        // isotropic splats, where the box test alone keeps the corners a disc cannot reach)
+        const float sxx = B.x / det, syy = A.z / det, mid = 0.5f * (sxx + syy);
+        const float lam = mid + sqrtf(fmaxf(mid * mid - 1.f / det, 0.f));
+        const float r2 = 2.f * fmaxf(tau, 0.f) * lam * 1.0004f + 0.01f;
+        const float cx = A.x - tx0, cy = A.y - ty0;
+        const float dx0 = fmaxf(fmaxf(0.f - cx, cx - 7.f), 0.f), dx1 = fmaxf(fmaxf(8.f - cx, cx - 15.f), 0.f);
+        const float dy0 = fmaxf(fmaxf(0.f - cy, cy - 7.f), 0.f), dy1 = fmaxf(fmaxf(8.f - cy, cy - 15.f), 0.f);
+        ov0 = ovx0 && ovy0 && (dx0 * dx0 + dy0 * dy0 <= r2);
+        ov1 = ovx1 && ovy0 && (dx1 * dx1 + dy0 * dy0 <= r2);
+        ov2 = ovx0 && ovy1 && (dx0 * dx0 + dy1 * dy1 <= r2);
+        ov3 = ovx1 && ovy1 && (dx1 * dx1 + dy1 * dy1 <= r2);
       } else {
-        ovx0 = ovx1 = ovy0 = ovy1 = true;  // degenerate conic: no culling, the exact per-pixel rule decides
+        ov0 = ov1 = ov2 = ov3 = true;  // degenerate conic: no culling, the exact per-pixel rule decides
       }
-      ov0 = ovx0 && ovy0; ov1 = ovx1 && ovy0; ov2 = ovx0 && ovy1; ov3 = ovx1 && ovy1;
       // where the backward pass finds this (Gaussian, tile) pair
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;

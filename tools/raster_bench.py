@@ -12,6 +12,7 @@ ap.add_argument("--C", type=int, default=3)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--policy", default="async")
 ap.add_argument("--aniso", action="store_true")
+ap.add_argument("--fused", action="store_true", help="time the fused SLAM engine (mapping-mode backward) instead of the autograd path")
 a = ap.parse_args()
 dev = "cuda"
 K = dict(syn.TUM_INTRINSICS)
@@ -35,6 +36,28 @@ if a.C == 6:
     z = means.detach()[:, 2:3]
     extra = torch.cat([z, torch.ones_like(z), z * z], 1).requires_grad_(True)
 R.set_binning_policy(a.policy)
+if a.fused:
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import FusedEngine
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    from mm3dgs_slam_amd.renderer import Renderer
+    cfg = default_config(device=dev, height=a.H, width=a.W)
+    gm = GaussianModel(cfg); gm.training_setup()
+    gm.densification_postfix(G["xyz"], G["f_dc"], torch.zeros(a.P, 0, 3, device=dev), G["opacity"], G["scaling"], G["rotation"], G["rgb"])
+    eng = FusedEngine(Renderer(cfg))
+    pose = torch.tensor([1.0, 0, 0, 0, 0, 0, 0], device=dev)
+    si = eng.forward(pose, gm, need_grads=True); eng.check_capacity()
+    eng.dL.normal_()
+    def it():
+        s_ = eng.forward(pose, gm, need_grads=True)
+        eng.backward(s_, grads=eng.grads)
+    for _ in range(5): it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters): it()
+    torch.cuda.synchronize()
+    print(json.dumps(dict(P=a.P, fused=True, fwdbwd_ms=(time.perf_counter() - t0) * 1e3 / a.iters)))
+    sys.exit(0)
 
 def fwd():
     return rast(means3D=means, means2D=m2d, opacities=opac, shs=shs, scales=scales, rotations=rots, extra_channels=extra)
