@@ -8,7 +8,7 @@
 //      workgroup then splits the tile's list into four depth-ordered 8x8 sub-tile lists: a splat is listed for a
 //      sub-tile only if the axis-aligned bound of { alpha >= 1/255 } reaches it (conservative, so compositing the
 //      sub-list equals compositing the full tile list), and records for every pair (Gaussian, tile) the slot the
-//      backward pass will find it under (gslot) plus which sub-tiles hold it (submask).
+//      backward pass will find it under (its Gaussian-major pair index, stored next to the id) and which sub-tiles hold it.
 // HBM traffic is ~45 B/pair, versus 24 B/pair x 6 passes for a global radix sort of 64-bit keys.
 #include "mm3dgs_common.h"
 
@@ -216,7 +216,7 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
   for (int base = 0; base < len; base += 256) {
     const int i = base + tid;
     const bool have = i < len;
-    uint32_t id = 0;
+    uint32_t id = 0, pidx = 0;
     bool ov0 = false, ov1 = false, ov2 = false, ov3 = false;
     if (have) {
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
@@ -252,13 +252,15 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
       } else {
         ov0 = ov1 = ov2 = ov3 = true;  // degenerate conic: no culling, the exact per-pixel rule decides
       }
-      // where the backward pass finds this (Gaussian, tile) pair
+      // pair index of (Gaussian, tile) in Gaussian-major order: the backward records of one Gaussian are contiguous
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
-      const uint32_t local = (uint32_t)((tty - miny) * rw + (ttx - minx));
-      const uint32_t goff = g.block_tiles[id >> 8] + g.tileoff[id];
-      if (goff + local < N_cap) b.gslot[goff + local] = start + (uint32_t)i;
-      b.submask[start + i] = (uint8_t)((ov0 ? 1 : 0) | (ov1 ? 2 : 0) | (ov2 ? 4 : 0) | (ov3 ? 8 : 0));
+      pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
+      if (pidx < N_cap) {
+        b.submask[pidx] = (uint8_t)((ov0 ? 1 : 0) | (ov1 ? 2 : 0) | (ov2 ? 4 : 0) | (ov3 ? 8 : 0));
+      } else {
+        ov0 = ov1 = ov2 = ov3 = false;   // only on capacity overflow (flagged in the header)
+      }
     }
     const unsigned long long m0 = __ballot(ov0), m1 = __ballot(ov1), m2 = __ballot(ov2), m3 = __ballot(ov3);
     if (lane == 0) {
@@ -268,7 +270,7 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t pre[4] = {run[0], run[1], run[2], run[3]};
     for (int w2 = 0; w2 < wv; w2++) { pre[0] += wcnt[w2][0]; pre[1] += wcnt[w2][1]; pre[2] += wcnt[w2][2]; pre[3] += wcnt[w2][3]; }
-    const uint2 ent = make_uint2(id, (uint32_t)i);
+    const uint2 ent = make_uint2(id, pidx);
     if (ov0) sub[0 * len + pre[0] + __popcll(m0 & lt)] = ent;
     if (ov1) sub[(size_t)1 * len + pre[1] + __popcll(m1 & lt)] = ent;
     if (ov2) sub[(size_t)2 * len + pre[2] + __popcll(m2 & lt)] = ent;

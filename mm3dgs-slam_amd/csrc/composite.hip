@@ -262,7 +262,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + lane; e < count; e += 64) {
-    float4* r = (float4*)(dsub + (((size_t)start + list[e].y) * 4 + wv) * SPLAT_F);
+    float4* r = (float4*)(dsub + ((size_t)list[e].y * 4 + wv) * SPLAT_F);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int q = 0; q < NF4; q++) r[q] = z;
@@ -270,8 +270,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   if (todo == 0) return;
 
   const int my_slot = (lane < 16) ? WaveReduce<NV>::slot(lane) : -1;
-  // this lane's component of record 0 of this sub-tile; record of tile-list entry i is 192 B further per i
-  float* const my_rec = dsub + ((size_t)start * 4 + wv) * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
+  // this lane's component of this sub-tile's record of pair 0; the record of pair p is 192 B further per p
+  float* const my_rec = dsub + (size_t)wv * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
 
   // chunk c holds list entries todo-1-(64c+lane): lane order == traversal order (back to front)

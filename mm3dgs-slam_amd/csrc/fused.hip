@@ -190,8 +190,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     }
     auto add_pair = [&](uint32_t gi) {
       if (gi >= N_cap) return;
-      const uint32_t slot = bn.gslot[gi];
-      if (slot >= N_cap) return;
+      const uint32_t slot = gi;   // records are indexed by the Gaussian-major pair index: contiguous per Gaussian
       const uint32_t m = bn.submask[slot];
 #pragma unroll
       for (int w = 0; w < 4; w++) {

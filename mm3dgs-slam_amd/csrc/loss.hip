@@ -52,12 +52,29 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
   const float sil = inside ? out[4 * HW + pix] : 0.f;
   const bool smask = sil > cfg.sil_thr;
   if (cfg.w_ssim != 0.f) {
-    for (int i = threadIdx.x; i < 3 * LW * LW; i += 256) {
-      const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-      sI[ch][ly][lx] = in ? out[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
-      sG[ch][ly][lx] = in ? gt[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+    // halo load: every lane issues its 8 pairs of global loads before the first LDS write (fixed trip count, so the
+    // loads overlap instead of being serialised one latency at a time)
+    {
+      constexpr int NIT = (3 * LW * LW + 255) / 256;
+      float va[NIT], vb[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = threadIdx.x + it * 256;
+        const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+        const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+        const bool in = i < 3 * LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+        va[it] = in ? out[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+        vb[it] = in ? gt[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = threadIdx.x + it * 256;
+        if (i < 3 * LW * LW) {
+          const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+          sI[ch][ly][lx] = va[it];
+          sG[ch][ly][lx] = vb[it];
+        }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * LW * LT; i += 256) {
@@ -170,11 +187,28 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   const bool smask = sil > cfg.sil_thr;
   float gch[3] = {0.f, 0.f, 0.f};
   if (cfg.w_ssim != 0.f) {
-    for (int i = threadIdx.x; i < 9 * LW * LW; i += 256) {
-      const int q = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      const bool in = gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-      sD[q][ly][lx] = in ? dmaps[q * HW + (size_t)gy * cfg.W + gx] : 0.f;
+    {
+      constexpr int NIT = (9 * LW * LW + 255) / 256;   // 24: issued in three groups of 8 independent loads
+#pragma unroll
+      for (int grp = 0; grp < NIT; grp += 8) {
+        float v[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int i = threadIdx.x + (grp + it) * 256;
+          const int q = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+          const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+          const bool in = i < 9 * LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+          v[it] = in ? dmaps[q * HW + (size_t)gy * cfg.W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int i = threadIdx.x + (grp + it) * 256;
+          if (i < 9 * LW * LW) {
+            const int q = i / (LW * LW), r = i % (LW * LW);
+            sD[q][r / LW][r % LW] = v[it];
+          }
+        }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * LW * LT; i += 256) {

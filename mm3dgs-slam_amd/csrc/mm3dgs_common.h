@@ -4,12 +4,13 @@
 //                  | clamped[P] (u8, SH clamp bits) | tileoff[P] (u32, workgroup-local exclusive scan of tiles touched)
 //                  | block_tiles[ceil(P/256)+1] (u32, tiles touched per preprocess workgroup -> exclusive prefix)
 //   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | subcount[4T] | final_T[H*W] | n_contrib[H*W]
-//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | gslot[N_cap] (u32: for
-//                  Gaussian g's k-th tile, the slot of that pair in the tile bins) | sublist[4*N_cap] (uint2 {id, i}:
-//                  depth-ordered list of each 8x8 sub-tile; sub-tile w of a tile with bin [start,end) owns
-//                  [4*start + w*len, +subcount)) | submask[N_cap] (u8: which sub-tiles list the pair)
-//   bwd scratch  : dsub[4*N_cap] (12 floats: dxy(2) dconic(3) dopacity(1) dcolor(6); one record per (sub-tile, splat),
-//                  written once by the owning wave -- no atomics) | campartial[ceil(P/256)][32]
+//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | sublist[4*N_cap] (uint2
+//                  {id, pair}: depth-ordered list of each 8x8 sub-tile; sub-tile w of a tile with bin [start,end) owns
+//                  [4*start + w*len, +subcount); pair = Gaussian-major index of the (Gaussian, tile) pair)
+//                  | submask[N_cap] (u8, indexed by pair: which sub-tiles list it)
+//   bwd scratch  : dsub[4*N_cap] (12 floats, indexed by 4*pair + sub-tile: moments(5) dopacity(1) dcolour(6); one
+//                  record per (sub-tile, splat), written once by the owning wave -- no atomics; a Gaussian's records
+//                  are contiguous) | campartial[ceil(P/256)][32]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -83,20 +84,18 @@ static inline ImageView image_view(void* base, int H, int W) {
 
 struct BinView {
   unsigned long long* keys;  // [N_cap]
-  uint32_t* gslot;           // [N_cap]
   uint2* sublist;            // [4*N_cap]
   uint8_t* submask;          // [N_cap]
 };
 static inline size_t binning_bytes_impl(size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 8, 256) + align_up(N * 4, 256) + align_up(N * 32, 256) + align_up(N, 256);
+  return align_up(N * 8, 256) + align_up(N * 32, 256) + align_up(N, 256);
 }
 static inline BinView bin_view(void* base, size_t N) {
   if (N < 1) N = 1;
   char* c = (char*)base;
   BinView b;
   b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
-  b.gslot = (uint32_t*)c;           c += align_up(N * 4, 256);
   b.sublist = (uint2*)c;            c += align_up(N * 32, 256);
   b.submask = (uint8_t*)c;
   return b;

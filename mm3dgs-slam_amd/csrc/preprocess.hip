@@ -184,8 +184,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     }
     auto add_pair = [&](uint32_t gi) {
       if (gi >= N_cap) return;
-      const uint32_t slot = bn.gslot[gi];
-      if (slot >= N_cap) return;
+      const uint32_t slot = gi;   // records are indexed by the Gaussian-major pair index: contiguous per Gaussian
       const uint32_t m = bn.submask[slot];
 #pragma unroll
       for (int w = 0; w < 4; w++) {
