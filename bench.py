@@ -44,6 +44,7 @@ def parse():
                     help="fraction of frame-0 pixels that seed a Gaussian (0 = choose it so the map has ~--gaussians)")
     ap.add_argument("--policy", default="async", choices=["async", "exact"])
     ap.add_argument("--render-mode", default="fused", choices=["fused", "reference"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
                     "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
@@ -119,12 +120,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
+    if os.environ.get("MM3DGS_BENCH_SINGLE_DEVICE"):      # plumbing test of the N > 1 path on a 1-GPU box (with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.backend)
 
     from mm3dgs_slam_amd import _lib, rasterizer
     from mm3dgs_slam_amd.config import default_config
