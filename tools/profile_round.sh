@@ -23,7 +23,7 @@ with open(f"{out}/slam_pmc_{c}.csv", "w") as fh:
     fh.write("kernel,launches,mean_counter_value\n")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         if "composite" in k or "preprocess" in k or "sort" in k or "scatter" in k or "scan" in k:
-            fh.write(f"{k},{len(v)},{sum(v)/len(v)}\n")
+            fh.write(f'"{k}",{len(v)},{sum(v)/len(v)}\n')
 print(open(f"{out}/slam_pmc_{c}.csv").read())
 PY
 done
