@@ -14,6 +14,7 @@
 #define LT 16
 #define HALO 5
 #define LW (LT + 2 * HALO)  // 26
+#define LWP 27              // LDS row stride (odd: rows start on different banks; 48 would be conflict-free but costs a workgroup of occupancy)
 #define NSUM 16
 
 // sum of NR per-lane values over the 256-lane workgroup: float DPP reduction inside each wave (<= 64 addends), the four
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256)
 loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
                    float* __restrict__ dmaps, double* __restrict__ partial) {
   // all three colour channels are staged at once: 4 barriers per workgroup instead of ~40
-  __shared__ float sI[3][LW][LW + 1], sG[3][LW][LW + 1];
+  __shared__ float sI[3][LW][LWP], sG[3][LW][LWP];
   __shared__ float hM1[3][LW][LT], hM2[3][LW][LT], hE11[3][LW][LT], hE22[3][LW][LT], hE12[3][LW][LT];
   __shared__ double red[4][12];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -52,40 +53,55 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
   const float sil = inside ? out[4 * HW + pix] : 0.f;
   const bool smask = sil > cfg.sil_thr;
   if (cfg.w_ssim != 0.f) {
-    // halo load: every lane issues its 8 pairs of global loads before the first LDS write (fixed trip count, so the
-    // loads overlap instead of being serialised one latency at a time)
+    // halo load: the (row, column) of a lane's three halo elements are computed once and reused for every channel; all 18
+    // global loads are issued before the first LDS write
     {
-      constexpr int NIT = (3 * LW * LW + 255) / 256;
-      float va[NIT], vb[NIT];
+      constexpr int NEL = (LW * LW + 255) / 256;   // 3
+      int off[NEL], lds[NEL];
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int i = threadIdx.x + it * 256;
-        const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
+      for (int e = 0; e < NEL; e++) {
+        const int i = threadIdx.x + e * 256;
+        const int ly = i / LW, lx = i - ly * LW;
         const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-        const bool in = i < 3 * LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-        va[it] = in ? out[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
-        vb[it] = in ? gt[ch * HW + (size_t)gy * cfg.W + gx] : 0.f;
+        const bool in = i < LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+        off[e] = in ? gy * cfg.W + gx : -1;
+        lds[e] = i < LW * LW ? ly * LWP + lx : -1;
       }
+      float va[3][NEL], vb[3][NEL];
 #pragma unroll
-      for (int it = 0; it < NIT; it++) {
-        const int i = threadIdx.x + it * 256;
-        if (i < 3 * LW * LW) {
-          const int ch = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
-          sI[ch][ly][lx] = va[it];
-          sG[ch][ly][lx] = vb[it];
+      for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int e = 0; e < NEL; e++) {
+          va[ch][e] = off[e] >= 0 ? out[ch * HW + off[e]] : 0.f;
+          vb[ch][e] = off[e] >= 0 ? gt[ch * HW + off[e]] : 0.f;
         }
-      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int e = 0; e < NEL; e++)
+          if (lds[e] >= 0) { (&sI[ch][0][0])[lds[e]] = va[ch][e]; (&sG[ch][0][0])[lds[e]] = vb[ch][e]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * LW * LT; i += 256) {
-      const int ch = i / (LW * LT), r = i % (LW * LT), ly = r / LT, lx = r % LT;
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: 26 rows x 16 columns per channel = 416 outputs, lane t takes outputs t and t + 256 (shift/mask only)
 #pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float a = sI[ch][ly][lx + k], b = sG[ch][ly][lx + k], w = cfg.window[k];
-        m1 += w * a; m2 += w * b; e11 += w * a * a; e22 += w * b * b; e12 += w * a * b;
+    for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int o = threadIdx.x + e * 256;
+        if (o < LW * LT) {
+          const int ly = o >> 4, lx = o & 15;
+          const float* ri = &sI[ch][ly][lx];
+          const float* rg = &sG[ch][ly][lx];
+          float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; k++) {
+            const float a = ri[k], b = rg[k], w = cfg.window[k];
+            const float wa = w * a, wb = w * b;
+            m1 += wa; m2 += wb; e11 = fmaf(wa, a, e11); e22 = fmaf(wb, b, e22); e12 = fmaf(wa, b, e12);
+          }
+          hM1[ch][ly][lx] = m1; hM2[ch][ly][lx] = m2; hE11[ch][ly][lx] = e11; hE22[ch][ly][lx] = e22; hE12[ch][ly][lx] = e12;
+        }
       }
-      hM1[ch][ly][lx] = m1; hM2[ch][ly][lx] = m2; hE11[ch][ly][lx] = e11; hE22[ch][ly][lx] = e22; hE12[ch][ly][lx] = e12;
     }
     __syncthreads();
 #pragma unroll
@@ -173,7 +189,7 @@ __device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, d
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
                  const float* __restrict__ dmaps, const double* __restrict__ sums, float* __restrict__ dL, float* __restrict__ loss) {
-  __shared__ float sD[9][LW][LW + 1];
+  __shared__ float sD[9][LW][LWP];
   __shared__ float hD[9][LW][LT];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
@@ -188,35 +204,46 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   float gch[3] = {0.f, 0.f, 0.f};
   if (cfg.w_ssim != 0.f) {
     {
-      constexpr int NIT = (9 * LW * LW + 255) / 256;   // 24: issued in three groups of 8 independent loads
+      constexpr int NEL = (LW * LW + 255) / 256;   // 3 halo elements per lane and map
+      int off[NEL], lds[NEL];
 #pragma unroll
-      for (int grp = 0; grp < NIT; grp += 8) {
-        float v[8];
+      for (int e = 0; e < NEL; e++) {
+        const int i = threadIdx.x + e * 256;
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+        const bool in = i < LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+        off[e] = in ? gy * cfg.W + gx : -1;
+        lds[e] = i < LW * LW ? ly * LWP + lx : -1;
+      }
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-          const int i = threadIdx.x + (grp + it) * 256;
-          const int q = i / (LW * LW), r = i % (LW * LW), ly = r / LW, lx = r % LW;
-          const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-          const bool in = i < 9 * LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-          v[it] = in ? dmaps[q * HW + (size_t)gy * cfg.W + gx] : 0.f;
-        }
+      for (int q0 = 0; q0 < 9; q0 += 3) {   // 9 loads in flight per group
+        float v[3][NEL];
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-          const int i = threadIdx.x + (grp + it) * 256;
-          if (i < 9 * LW * LW) {
-            const int q = i / (LW * LW), r = i % (LW * LW);
-            sD[q][r / LW][r % LW] = v[it];
-          }
-        }
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+          for (int e = 0; e < NEL; e++) v[q][e] = off[e] >= 0 ? dmaps[(size_t)(q0 + q) * HW + off[e]] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+          for (int e = 0; e < NEL; e++)
+            if (lds[e] >= 0) (&sD[q0 + q][0][0])[lds[e]] = v[q][e];
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * LW * LT; i += 256) {
-      const int q = i / (LW * LT), r = i % (LW * LT), ly = r / LT, lx = r % LT;
-      float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 11; k++) s += cfg.window[k] * sD[q][ly][lx + k];
-      hD[q][ly][lx] = s;
+    for (int q = 0; q < 9; q++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int o = threadIdx.x + e * 256;
+        if (o < LW * LT) {
+          const int ly = o >> 4, lx = o & 15;
+          const float* rd = &sD[q][ly][lx];
+          float sacc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; k++) sacc = fmaf(cfg.window[k], rd[k], sacc);
+          hD[q][ly][lx] = sacc;
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
