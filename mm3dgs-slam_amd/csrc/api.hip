@@ -201,8 +201,10 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
   if (!(flags & MM3DGS_FWD_STATE_CLEAN))
     if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
   cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
+  // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
+  cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
-  { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
+  if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s); }
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");

@@ -20,6 +20,7 @@
 #define TILE 16
 #define TILE_PIX 256
 #define SPLAT_F MM3DGS_SPLAT_FLOATS
+#define MAX_FUSED_SCAN_TILES 4096  // scatter_scan_kernel keeps 2 T words of LDS
 #define MAX_LDS_TILES 12288  // per-workgroup LDS tile histogram (48 KB) covers up to ~1920x1600
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -130,6 +131,7 @@ struct CamDev {
   int tilemap;  // 0: tile = workgroup id; 1: contiguous tile span per XCD
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
+  int fused_scan;   // 1: no scan_tiles launch, every scatter workgroup scans the tile counters itself (persistent state)
   const float* bg;
   const float* view;
   const float* proj;
@@ -151,6 +153,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.tilemap = env_flag("MM3DGS_TILEMAP", 0);
   d.stats = env_flag("MM3DGS_STATS", 0);
   d.sort_single = 0;
+  d.fused_scan = 0;
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
   return d;
 }
