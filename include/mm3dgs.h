@@ -138,6 +138,14 @@ typedef struct Mm3dgsSlamGrads {
   float* max_radii2D; float* grad_accum; float* denom; /* [P] updated in place when max_radii2D != NULL          */
 } Mm3dgsSlamGrads;
 
+/* Optional: the map's Adam step applied inside the backward projection kernel (no gradient round trip through HBM, one
+ * launch less).  Same formula as mm3dgs_adam / torch.optim.Adam; groups in the order xyz, f_dc, opacity, scaling, rotation.
+ * When passed to mm3dgs_slam_backward the d_* outputs of Mm3dgsSlamGrads may be NULL. */
+typedef struct Mm3dgsMapAdam {
+  float* param[5]; float* exp_avg[5]; float* exp_avg_sq[5]; float lr[5];
+  float beta1, beta2, eps; int32_t step;
+} Mm3dgsMapAdam;
+
 typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
   float* pose; float* m; float* v; int32_t* step; float lr_q, lr_t, beta1, beta2, eps;
 } Mm3dgsPoseAdam;
@@ -153,7 +161,8 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
 int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                          const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                          const float* dL_dout /*[6,H,W]*/, void* backward_scratch, const Mm3dgsSlamGrads* grads,
-                         float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, void* stream);
+                         float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam,
+                         void* stream);
 
 /* n_iter tracking iterations enqueued back to back from C (slam/tracker.py:94-177 with the "vigs" loss): each is
  * forward -> loss -> backward with the pose Adam step on the device; the pose buffer is updated in place. */

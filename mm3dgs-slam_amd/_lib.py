@@ -34,6 +34,11 @@ class Mm3dgsSlamGrads(C.Structure):
                 ("d_rotation", C.c_void_p), ("max_radii2D", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p)]
 
 
+class Mm3dgsMapAdam(C.Structure):
+    _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32)]
+
+
 class Mm3dgsPoseAdam(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_float),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
@@ -65,7 +70,7 @@ _SIGS = {
     "mm3dgs_slam_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                       C.c_int, _P]),
     "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
-                                       C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), _P]),
+                                       C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), C.POINTER(Mm3dgsMapAdam), _P]),
     "mm3dgs_slam_track": (C.c_int, [C.c_int, C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                     C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, C.POINTER(Mm3dgsPoseAdam), _P]),
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),

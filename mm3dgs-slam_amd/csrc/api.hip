@@ -213,7 +213,7 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
 int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                          const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                          const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
-                         const Mm3dgsPoseAdam* pose_adam, void* stream) {
+                         const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!geom_state || !image_state || !binning_state || !dL_dout || !backward_scratch || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -238,8 +238,22 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
     pa.pose = pose_adam->pose; pa.m = pose_adam->m; pa.v = pose_adam->v; pa.step = pose_adam->step;
     pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = pose_adam->eps;
   }
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, sg.d_xyz == nullptr, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, s); }
+  MapAdam ma;
+  memset(&ma, 0, sizeof(ma));
+  if (map_adam) {
+    if (map_adam->step < 1) return fail(-1, "map Adam step must be >= 1");
+    for (int i = 0; i < 5; i++) {
+      if (!map_adam->param[i] || !map_adam->exp_avg[i] || !map_adam->exp_avg_sq[i]) return fail(-2, "map Adam group %d has a NULL pointer", i);
+      ma.p[i] = map_adam->param[i]; ma.m[i] = map_adam->exp_avg[i]; ma.v[i] = map_adam->exp_avg_sq[i]; ma.lr[i] = map_adam->lr[i];
+    }
+    ma.beta1 = map_adam->beta1; ma.beta2 = map_adam->beta2; ma.eps = map_adam->eps;
+    ma.bc1 = 1.f - powf(ma.beta1, (float)map_adam->step);
+    ma.bc2s = sqrtf(1.f - powf(ma.beta2, (float)map_adam->step));
+    ma.on = 1;
+  }
+  const bool tracking = sg.d_xyz == nullptr && !ma.on;
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s); }
   return check_launch("slam_backward");
 }
 
@@ -279,7 +293,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
     rc = mm3dgs_loss(loss_cfg, out_color, gt_color, ref, loss_work, dL_dout, loss4, stream);
     if (rc) return rc;
     rc = mm3dgs_slam_backward(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                              nullptr, pose_adam, stream);
+                              nullptr, pose_adam, nullptr, stream);
     if (rc) return rc;
   }
   return 0;

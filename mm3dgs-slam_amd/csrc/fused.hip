@@ -169,7 +169,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
 template <bool TRACK>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out) {
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
   const int idx = blockIdx.x * FB + threadIdx.x;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
@@ -293,7 +293,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       cg[3] = dm[1] * x0; cg[4] = dm[1] * x1; cg[5] = dm[1] * x2;
       cg[6] = dm[2] * x0; cg[7] = dm[2] * x1; cg[8] = dm[2] * x2;
       cg[9] = dm[0]; cg[10] = dm[1]; cg[11] = dm[2];
-      if (out.d_xyz) {
+      if (out.d_xyz || ma.on) {
 #pragma unroll
         for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2];
         const uint8_t cl = g.clamped[idx];
@@ -346,6 +346,25 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       out.d_scaling[(size_t)idx * 3] = dls[0]; out.d_scaling[(size_t)idx * 3 + 1] = dls[1]; out.d_scaling[(size_t)idx * 3 + 2] = dls[2];
       out.d_rotation[(size_t)idx * 4] = dqr[0]; out.d_rotation[(size_t)idx * 4 + 1] = dqr[1];
       out.d_rotation[(size_t)idx * 4 + 2] = dqr[2]; out.d_rotation[(size_t)idx * 4 + 3] = dqr[3];
+    }
+    if (ma.on) {
+      // the map's Adam step for this Gaussian (every Gaussian, visible or not: zero gradients still decay the moments)
+      auto adam = [&](int grp, size_t off, float gr) {
+        float* pp = ma.p[grp] + off; float* pm = ma.m[grp] + off; float* pv = ma.v[grp] + off;
+        const float mi = *pm + (gr - *pm) * (1.f - ma.beta1);
+        const float vi = *pv * ma.beta2 + gr * gr * (1.f - ma.beta2);
+        *pm = mi; *pv = vi;
+        *pp -= (ma.lr[grp] / ma.bc1) * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+      };
+#pragma unroll
+      for (int c = 0; c < 3; c++) adam(0, (size_t)idx * 3 + c, dxyz[c]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) adam(1, (size_t)idx * 3 + c, dfd[c]);
+      adam(2, (size_t)idx, dlogit);
+#pragma unroll
+      for (int c = 0; c < 3; c++) adam(3, (size_t)idx * 3 + c, dls[c]);
+#pragma unroll
+      for (int c = 0; c < 4; c++) adam(4, (size_t)idx * 4 + c, dqr[c]);
     }
   }
   {
@@ -430,15 +449,15 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 }
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
-                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, hipStream_t s) {
+                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   if (P > 0) {
-    if (out.d_xyz)
+    if (out.d_xyz || ma.on)
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, bw.campartial, out);
+                         bw.dsub, bw.campartial, out, ma);
     else
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, bw.campartial, out);
+                         bw.dsub, bw.campartial, out, ma);
   }
   hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
 }

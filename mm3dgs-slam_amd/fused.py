@@ -135,7 +135,7 @@ class FusedEngine:
         _lib.check(self.lib.mm3dgs_loss(C.byref(cfg), _p(self.out), _p(gt_color), _p(ref), _p(self.loss_work), _p(self.dL),
                                         _p(self.loss), _stream()))
 
-    def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None):
+    def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None, map_adam=None):
         sg = _lib.Mm3dgsSlamGrads()
         if grads is not None:
             sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
@@ -144,7 +144,8 @@ class FusedEngine:
             sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
         _lib.check(self.lib.mm3dgs_slam_backward(C.byref(self.cam), self.P, C.byref(si), _p(self.radii), _p(self.geom), _p(self.img_state),
                                                  _p(self.binning), self.n_cap, _p(self.dL), _p(self.scratch), C.byref(sg), _p(dpose),
-                                                 C.byref(pose_adam) if pose_adam is not None else None, _stream()))
+                                                 C.byref(pose_adam) if pose_adam is not None else None,
+                                                 C.byref(map_adam) if map_adam is not None else None, _stream()))
 
 
 def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr):
@@ -239,17 +240,40 @@ class FusedMapper(Mapper):
                         g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
                         g.xyz_gradient_accum += eng.stat_delta[1]
                         g.denom += eng.stat_delta[2]
+                    prune_now = densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0
+                    if not prune_now:
+                        self._adam_step(eng)
                 else:
+                    # single GPU: the Adam step rides inside the backward projection kernel (no gradient round trip)
+                    prune_now = densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
-                    eng.backward(si, grads=eng.grads, stats=stats)
-                pruned_now = False
-                if densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0:
+                    eng.backward(si, grads=eng.grads if prune_now else None, stats=stats, map_adam=None if prune_now else self._inline_adam())
+                if prune_now:
+                    # the reference prunes BEFORE optimizer.step(): parameters are replaced, so that step is a no-op
                     g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
-                    pruned_now = True      # the reference's Adam step is a no-op here (parameters were replaced)
-                if not pruned_now:
-                    self._adam_step(eng)
             eng.check_capacity()
         self.mapping_iter_count += num_iter
+
+    def _inline_adam(self):
+        """Mm3dgsMapAdam over the optimiser's own state tensors (created like torch.optim.Adam would on its first step)."""
+        opt = self.gaussians.optimizer
+        ma = _lib.Mm3dgsMapAdam()
+        step_val = None
+        for i, name in enumerate(("xyz", "f_dc", "opacity", "scaling", "rotation")):
+            group = next(gr for gr in opt.param_groups if gr["name"] == name)
+            p = group["params"][0]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            step_val = int(st["step"].item()) if step_val is None else step_val
+            ma.param[i], ma.exp_avg[i], ma.exp_avg_sq[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            ma.lr[i] = float(group["lr"])
+        b1, b2 = opt.param_groups[0]["betas"]
+        ma.beta1, ma.beta2, ma.eps, ma.step = float(b1), float(b2), float(opt.param_groups[0]["eps"]), step_val
+        return ma
 
     def _adam_step(self, eng):
         g = self.gaussians
