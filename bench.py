@@ -46,10 +46,34 @@ def parse():
     ap.add_argument("--render-mode", default="fused", choices=["fused", "reference"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for plumbing tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: per-phase wall time of a frame (adds device syncs)")
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
                     "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=50000)
     return ap.parse_args()
+
+
+def instrument_phases(slam):
+    """--phases: wall time of each host-level phase of a frame with a device sync around it (diagnostic; perturbs `value`)."""
+    import collections
+    acc = collections.OrderedDict()
+    def wrap(obj, name, label):
+        fn = getattr(obj, name)
+        def timed(*a, **k):
+            torch.cuda.synchronize(); t = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize(); acc[label] = acc.get(label, 0.0) + time.perf_counter() - t
+            return r
+        setattr(obj, name, timed)
+    wrap(slam.tracker, "optimize_cam", "track.optimize_cam")
+    wrap(slam.tracker, "run_frame", "track.run_frame(total)")
+    wrap(slam.mapper, "get_covisible_set", "map.get_covisible_set")
+    wrap(slam.mapper, "need_new_keyframe", "map.need_new_keyframe")
+    wrap(slam.mapper, "initialize_new_gaussians", "map.initialize_new_gaussians")
+    wrap(slam.mapper, "add_keyframe", "map.add_keyframe")
+    wrap(slam.mapper, "optimize_map", "map.optimize_map")
+    wrap(slam.mapper, "run_frame", "map.run_frame(total)")
+    return acc
 
 
 def log(msg):
@@ -163,6 +187,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    phases = instrument_phases(slam) if args.phases else None
     _lib.profile_read()
     _lib.profile_enable(args.profile)
     barrier()
@@ -175,6 +200,9 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_read()
     log(f"timed region done: {elapsed:.2f} s")
+    if phases:
+        for k, v in phases.items():
+            log(f"  phase {k:34s} {v / args.steps * 1e3:8.2f} ms/frame")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

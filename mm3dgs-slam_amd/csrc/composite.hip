@@ -164,6 +164,9 @@ struct WaveReduce {
     return ok ? idx : -1;
   }
   __device__ static __forceinline__ float run(const float (&v)[NV], int lane) {
+    // no fma contraction here: v[i] is usually a product, and  fma(a, b, dpp(a*b))  costs mul + mov_dpp + fma where
+    // (a*b) + dpp(a*b)  is mul + ONE add with a DPP operand
+#pragma clang fp contract(off)
     const bool b0 = lane & 1, b1 = lane & 2;
     float l1[M1];
 #pragma unroll

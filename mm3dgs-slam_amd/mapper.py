@@ -94,6 +94,10 @@ class Mapper:
             return idx == 0 or (idx + 1) % m["kf_every"] == 0 or idx == self.n_img - 2
         if len(self.keyframes) == 0 or idx == 0:
             return True
+        # The reference renders the last keyframe and tests covisibility first (slam/mapper.py:141-173), but a frame closer
+        # than kf_every to the last keyframe is rejected on either branch: decide that without the render (same result).
+        if idx - self.keyframes[-1].idx < m["kf_every"]:
+            return False
         pts, (h, w) = self._rendered_depth_cloud(self.keyframes[-1].pose)
         if self.is_covisible(pts, self.estimate_pose_list[idx], h, w, threshold=m["min_covisibility"]):
             return False
