@@ -66,9 +66,9 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
 
   // wave-private, double-buffered staging: [buffer][wave][entry]
-  __shared__ float4 sA[2][4][64];
-  __shared__ float4 sB[2][4][64];
-  __shared__ float4 sC[2][4][64];
+  // [buffer][wave][field A|B|C][entry]: lane-contiguous (conflict-free) writes, and ONE address register per splat for the
+  // broadcast reads (fields are a constant 1 KB apart -> immediate offsets)
+  __shared__ float4 stg[2][4][3][64];
 
   float Tr = 1.f;
   float acc[C];
@@ -82,9 +82,9 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   {
     const uint32_t id0 = lane < count ? list[lane].x : 0u;
     const SplatRec r0 = load_rec<C>(g.splat, id0, lane < count);
-    sA[0][wv][lane] = r0.A;
-    sB[0][wv][lane] = r0.B;
-    if (C > 2) sC[0][wv][lane] = r0.C;
+    stg[0][wv][0][lane] = r0.A;
+    stg[0][wv][1][lane] = r0.B;
+    if (C > 2) stg[0][wv][2][lane] = r0.C;
   }
   uint32_t id_nxt = 64u + lane < count ? list[64u + lane].x : 0u;
   int cur = 0;
@@ -93,15 +93,10 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     // issue the gathers for the following chunks before touching this one; they land while it is composited
     const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + 64u + lane < count);
     const uint32_t id_nn = base + 128u + lane < count ? list[base + 128u + lane].x : 0u;
-    const float4* wA = sA[cur][wv];
-    const float4* wB = sB[cur][wv];
-    const float4* wC = sC[cur][wv];
+    const float4 (*wS)[64] = stg[cur][wv];
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, count - base));
-    float4 A = wA[0], B = wB[0], Cc = wC[0];
-    for (int j = 0; j < cnt; j++) {
-      const int jn = j + 1 < cnt ? j + 1 : j;
-      const float4 nA = wA[jn], nB = wB[jn], nC = wC[C > 2 ? jn : 0];
+    auto splat_fwd = [&](const float4& A, const float4& B, const float4& Cc, const int j) {
       n_iter++;
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
@@ -120,12 +115,23 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       if (C > 5) acc[5] = fmaf(Cc.w, w, acc[5]);
       Tr = contrib ? test_T : Tr;
       last_contributor = contrib ? base + (uint32_t)j + 1u : last_contributor;
-      A = nA; B = nB; Cc = nC;
+    };
+    // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated
+    float4 A0 = wS[0][0], B0 = wS[1][0], C0 = wS[2][0];
+    for (int j = 0; j < cnt; j += 2) {
+      const int j1 = j + 1 < cnt ? j + 1 : j;
+      const float4 A1 = wS[0][j1], B1 = wS[1][j1], C1 = wS[2][j1];
+      splat_fwd(A0, B0, C0, j);
+      if (j + 1 < cnt) {
+        const int j2 = j + 2 < cnt ? j + 2 : j1;
+        A0 = wS[0][j2]; B0 = wS[1][j2]; C0 = wS[2][j2];
+        splat_fwd(A1, B1, C1, j1);
+      }
     }
     if (__ballot(!done) == 0ull) break;
-    sA[cur ^ 1][wv][lane] = rec_n.A;
-    sB[cur ^ 1][wv][lane] = rec_n.B;
-    if (C > 2) sC[cur ^ 1][wv][lane] = rec_n.C;
+    stg[cur ^ 1][wv][0][lane] = rec_n.A;
+    stg[cur ^ 1][wv][1][lane] = rec_n.B;
+    if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
     id_nxt = id_nn;
   }
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
@@ -238,10 +244,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 6);
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
-  __shared__ float4 sA[2][4][64];
-  __shared__ float4 sB[2][4][64];
-  __shared__ float4 sC[2][4][64];
-  __shared__ uint32_t sI[2][4][64];
+  // [buffer][wave][field A|B|C|pair index][entry]: lane-contiguous (conflict-free) writes, and ONE address register per
+  // splat for the broadcast reads (fields are a constant 1 KB apart -> immediate offsets)
+  __shared__ float4 stg[2][4][4][64];
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   const float T_final = inside ? iv.final_T[pix] : 0.f;
@@ -281,10 +286,10 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   {
     const uint2 e0 = lane < todo ? list[todo - 1u - lane] : make_uint2(0u, 0u);
     const SplatRec r0 = load_rec<C>(g.splat, e0.x, lane < todo);
-    sA[0][wv][lane] = r0.A;
-    sB[0][wv][lane] = r0.B;
-    if (C > 2) sC[0][wv][lane] = r0.C;
-    sI[0][wv][lane] = e0.y;
+    stg[0][wv][0][lane] = r0.A;
+    stg[0][wv][1][lane] = r0.B;
+    if (C > 2) stg[0][wv][2][lane] = r0.C;
+    ((uint32_t*)&stg[0][wv][3][lane])[0] = e0.y;
   }
   uint2 ent_nxt = 64u + lane < todo ? list[todo - 1u - (64u + lane)] : make_uint2(0u, 0u);
   int cur = 0;
@@ -292,10 +297,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   for (uint32_t base = 0; base < todo; base += 64, cur ^= 1) {
     const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + 64u + lane < todo);
     const uint2 ent_nn = base + 128u + lane < todo ? list[todo - 1u - (base + 128u + lane)] : make_uint2(0u, 0u);
-    const float4* wA = sA[cur][wv];
-    const float4* wB = sB[cur][wv];
-    const float4* wC = sC[cur][wv];
-    const uint32_t* wI = sI[cur][wv];
+    const float4 (*wS)[64] = stg[cur][wv];
+    auto pair_of = [&](int j) { return ((const uint32_t*)&wS[3][j])[0]; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, todo - base));
     // one splat: evaluate, reduce over the wave, store the record
@@ -357,24 +360,24 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
-    float4 A0 = wA[0], B0 = wB[0], C0 = wC[0];
-    uint32_t t0 = wI[0];
+    float4 A0 = wS[0][0], B0 = wS[1][0], C0 = wS[2][0];
+    uint32_t t0 = pair_of(0);
     for (int j = 0; j < cnt; j += 2) {
       const int j1 = j + 1 < cnt ? j + 1 : j;
-      const float4 A1 = wA[j1], B1 = wB[j1], C1 = wC[C > 2 ? j1 : 0];
-      const uint32_t t1 = wI[j1];
+      const float4 A1 = wS[0][j1], B1 = wS[1][j1], C1 = wS[2][j1];
+      const uint32_t t1 = pair_of(j1);
       splat_bwd(A0, B0, C0, t0, j);
       if (j + 1 < cnt) {
         const int j2 = j + 2 < cnt ? j + 2 : j1;
-        A0 = wA[j2]; B0 = wB[j2]; C0 = wC[C > 2 ? j2 : 0];
-        t0 = wI[j2];
+        A0 = wS[0][j2]; B0 = wS[1][j2]; C0 = wS[2][j2];
+        t0 = pair_of(j2);
         splat_bwd(A1, B1, C1, t1, j1);
       }
     }
-    sA[cur ^ 1][wv][lane] = rec_n.A;
-    sB[cur ^ 1][wv][lane] = rec_n.B;
-    if (C > 2) sC[cur ^ 1][wv][lane] = rec_n.C;
-    sI[cur ^ 1][wv][lane] = ent_nxt.y;
+    stg[cur ^ 1][wv][0][lane] = rec_n.A;
+    stg[cur ^ 1][wv][1][lane] = rec_n.B;
+    if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
+    ((uint32_t*)&stg[cur ^ 1][wv][3][lane])[0] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   if (cam.stats && lane == 0) {
