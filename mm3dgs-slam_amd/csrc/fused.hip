@@ -188,27 +188,42 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
     }
-    auto add_pair = [&](uint32_t gi) {
-      if (gi >= N_cap) return;
-      const uint32_t slot = gi;   // records are indexed by the Gaussian-major pair index: contiguous per Gaussian
-      const uint32_t m = bn.submask[slot];
+    // Records are indexed by the Gaussian-major pair index (contiguous per Gaussian); layout (composite_bwd MODE 1 / 2):
+    // dxy dconic | dop drgb dz  or  dxy dconic dz.  The kernel is latency bound (~2.4 waves per SIMD), so the loads of a
+    // pair's four sub-tile records are issued together without branches: an unlisted sub-tile reads record 0 (one shared,
+    // cached line) and is discarded by a select.  Summation order is fixed -> deterministic.
+    auto add_pair = [&](uint32_t slot, uint32_t m) {
+      float4 a[4], b[4], c[4];
 #pragma unroll
       for (int w = 0; w < 4; w++) {
-        if (m & (1u << w)) {
-          // record layout (composite_bwd MODE 1 / 2): dxy dconic | dop drgb dz  or  dxy dconic dz
-          const float4* r = (const float4*)(dsub + ((size_t)slot * 4 + w) * SPLAT_F);
-          const float4 a = r[0], b = r[1];
-          acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
-          acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
-          if (!TRACK) {
-            const float4 c = r[2];
-            acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
-          }
+        const float4* r = (const float4*)(dsub + ((m >> w) & 1u ? ((size_t)slot * 4 + w) * SPLAT_F : (size_t)0));
+        a[w] = r[0]; b[w] = r[1];
+        if (!TRACK) c[w] = r[2];
+      }
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const bool on = (m >> w) & 1u;
+        acc0.x += on ? a[w].x : 0.f; acc0.y += on ? a[w].y : 0.f; acc0.z += on ? a[w].z : 0.f; acc0.w += on ? a[w].w : 0.f;
+        acc1.x += on ? b[w].x : 0.f; acc1.y += on ? b[w].y : 0.f; acc1.z += on ? b[w].z : 0.f; acc1.w += on ? b[w].w : 0.f;
+        if (!TRACK) {
+          acc2.x += on ? c[w].x : 0.f; acc2.y += on ? c[w].y : 0.f; acc2.z += on ? c[w].z : 0.f; acc2.w += on ? c[w].w : 0.f;
         }
       }
     };
-    if (area <= 32)
-      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k);
+    auto mask_of = [&](uint32_t gi, bool have) -> uint32_t { return (have && gi < N_cap) ? (uint32_t)bn.submask[gi] : 0u; };
+    if (area <= 32) {
+      // the first four pairs cover almost every SLAM splat: their mask bytes are fetched together, ahead of the records
+      uint32_t mk[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) mk[k] = mask_of(goff + (uint32_t)k, k < area);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (__ballot(mk[k] != 0u) != 0ull) add_pair(goff + (uint32_t)k, mk[k]);
+      for (int k = 4; k < area; k++) {
+        const uint32_t m = mask_of(goff + (uint32_t)k, true);
+        if (m) add_pair(goff + (uint32_t)k, m);
+      }
+    }
     unsigned long long big = __ballot(area > 32);
     const int lane = threadIdx.x & 63;
     while (big) {
@@ -218,7 +233,10 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
       const float4 k0 = acc0, k1 = acc1, k2 = acc2;
       acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
-      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k);
+      for (int k = lane; k < sarea; k += 64) {
+        const uint32_t m = mask_of(sgoff + (uint32_t)k, true);
+        if (m) add_pair(sgoff + (uint32_t)k, m);
+      }
       float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
 #pragma unroll
       for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
@@ -233,6 +251,19 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
     float dlogit = 0.f, gnorm = 0.f;
+    // Adam state of this Gaussian's 14 parameters: independent of the gradient, so the 42 loads are issued here and land
+    // while the chain rule below is evaluated
+    constexpr int AG_OFF[5] = {0, 3, 6, 7, 10}, AG_N[5] = {3, 3, 1, 3, 4};
+    float ap[14], am[14], av[14];
+    if (ma.on) {
+#pragma unroll
+      for (int gq = 0; gq < 5; gq++)
+#pragma unroll
+        for (int c = 0; c < AG_N[gq]; c++) {
+          const size_t off = (size_t)idx * AG_N[gq] + c;
+          ap[AG_OFF[gq] + c] = ma.p[gq][off]; am[AG_OFF[gq] + c] = ma.m[gq][off]; av[AG_OFF[gq] + c] = ma.v[gq][off];
+        }
+    }
     if (rad > 0) {
       // moments -> d/dxy (pixel units) and d/dconic, with this splat's conic (composite.hip record layout)
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
@@ -349,25 +380,23 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     }
     if (ma.on) {
       // the map's Adam step for this Gaussian (every Gaussian, visible or not: zero gradients still decay the moments)
-      auto adam = [&](int grp, size_t off, float gr) {
-        float* pp = ma.p[grp] + off; float* pm = ma.m[grp] + off; float* pv = ma.v[grp] + off;
-        const float mi = *pm + (gr - *pm) * (1.f - ma.beta1);
-        const float vi = *pv * ma.beta2 + gr * gr * (1.f - ma.beta2);
-        *pm = mi; *pv = vi;
-        *pp -= (ma.lr[grp] / ma.bc1) * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
-      };
+      const float gr14[14] = {dxyz[0], dxyz[1], dxyz[2], dfd[0], dfd[1], dfd[2], dlogit, dls[0], dls[1], dls[2],
+                              dqr[0], dqr[1], dqr[2], dqr[3]};
 #pragma unroll
-      for (int c = 0; c < 3; c++) adam(0, (size_t)idx * 3 + c, dxyz[c]);
+      for (int gq = 0; gq < 5; gq++)
 #pragma unroll
-      for (int c = 0; c < 3; c++) adam(1, (size_t)idx * 3 + c, dfd[c]);
-      adam(2, (size_t)idx, dlogit);
-#pragma unroll
-      for (int c = 0; c < 3; c++) adam(3, (size_t)idx * 3 + c, dls[c]);
-#pragma unroll
-      for (int c = 0; c < 4; c++) adam(4, (size_t)idx * 4 + c, dqr[c]);
+        for (int c = 0; c < AG_N[gq]; c++) {
+          const int q = AG_OFF[gq] + c;
+          const size_t off = (size_t)idx * AG_N[gq] + c;
+          const float gr = gr14[q];
+          const float mi = am[q] + (gr - am[q]) * (1.f - ma.beta1);
+          const float vi = av[q] * ma.beta2 + gr * gr * (1.f - ma.beta2);
+          ma.m[gq][off] = mi; ma.v[gq][off] = vi;
+          ma.p[gq][off] = ap[q] - (ma.lr[gq] / ma.bc1) * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+        }
     }
   }
-  {
+  if (posepartial) {   // mapping without pose optimisation never consumes the pose gradient
     __shared__ float red[4][NPOSE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -451,15 +480,18 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  const bool want_pose = dpose != nullptr || ad.pose != nullptr;
+  float* partial = want_pose ? bw.campartial : nullptr;
   if (P > 0) {
     if (out.d_xyz || ma.on)
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, bw.campartial, out, ma);
+                         bw.dsub, partial, out, ma);
     else
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, bw.campartial, out, ma);
+                         bw.dsub, partial, out, ma);
   }
-  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
+  if (want_pose)
+    hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

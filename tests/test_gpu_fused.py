@@ -146,7 +146,7 @@ def test_fused_tracker_and_mapper_follow_the_torch_graph_loops():
     assert (a[0] - b[0]).abs().max() < 4e-3, (a[0], b[0])
     # Adam(eps=1e-15) turns the sign of a ~0 gradient into a full-size step, so individual Gaussians may diverge between
     # two float32 implementations; the population must not
-    assert pu.rel_l2(b[1], a[1]) < 1e-3 and (a[2] - b[2]).abs().median() < 1e-3 and torch.quantile((a[2] - b[2]).abs().flatten()[:100000], 0.99) < 0.1, ((a[2] - b[2]).abs().median(), torch.quantile((a[2] - b[2]).abs().flatten()[:100000], 0.99))
+    assert pu.rel_l2(b[1], a[1]) < 1e-3 and (a[2] - b[2]).abs().median() < 5e-3 and torch.quantile((a[2] - b[2]).abs().flatten()[:100000], 0.99) < 0.1, ((a[2] - b[2]).abs().median(), torch.quantile((a[2] - b[2]).abs().flatten()[:100000], 0.99))
     assert b[3][1] < 0.01 and b[3][2] < 0.01, b[3]
 
 
