@@ -169,6 +169,14 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
   __shared__ uint32_t maxlen_s;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) maxlen_s = 0;
+  // this lane's Gaussian: loads issued first, they land while the tile counters are scanned
+  const int idx = blockIdx.x * 256 + tid;
+  uint32_t r0 = 0, r1 = 0, dbits = 0;
+  if (idx < P) {
+    r0 = g.rect[(size_t)idx * 2];
+    r1 = g.rect[(size_t)idx * 2 + 1];
+    dbits = __float_as_uint(g.depth[idx]);
+  }
   for (int t = tid; t < T; t += 256) { hist[t] = 0; rng[t] = iv.tile_count[t]; }
   __syncthreads();
   const uint32_t total = block256_excl_scan_inplace(rng, T, wave_tot, &maxlen_s);
@@ -186,13 +194,7 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
     const uint32_t tot2 = block256_excl_scan_inplace(g.block_tiles, nblocks_pre, wave_tot, nullptr);
     if (tid == 0) g.block_tiles[nblocks_pre] = tot2;
   }
-  int idx = blockIdx.x * 256 + tid;
-  uint32_t r0 = 0, r1 = 0, dbits = 0;
-  if (idx < P) {
-    r0 = g.rect[(size_t)idx * 2];
-    r1 = g.rect[(size_t)idx * 2 + 1];
-    if (r1 != r0) dbits = __float_as_uint(g.depth[idx]);
-  }
+  if (r1 == r0) dbits = 0;   // culled: depth[] was not written this frame
   const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
   const int w = maxx - minx, h = maxy - miny;
   const int area = (w > 0 && h > 0) ? w * h : 0;

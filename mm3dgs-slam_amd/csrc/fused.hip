@@ -28,18 +28,17 @@ __device__ __forceinline__ PoseDev load_pose(const float* __restrict__ pose) {
   return p;
 }
 
-__device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod, float S3[3][3], float R[3][3], float sm[3],
-                                           float qn[4], float& qinv) {
-  const float* q = in.rotation + (size_t)idx * 4;
+// raw rotation quaternion q[4] and log-scales ls[3] -> normalised quaternion, R, scales, Sigma = (R S)(R S)^T
+__device__ __forceinline__ void slam_cov3d_vals(const float q[4], const float ls[3], bool isotropic, float mod, float S3[3][3],
+                                                float R[3][3], float sm[3], float qn[4], float& qinv) {
   float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   n = fmaxf(n, 1e-12f);  // torch.nn.functional.normalize eps
   qinv = 1.f / n;
   qn[0] = q[0] * qinv; qn[1] = q[1] * qinv; qn[2] = q[2] * qinv; qn[3] = q[3] * qinv;
   quat_to_R(qn, R);
-  const float* ls = in.scaling + (size_t)idx * 3;
   sm[0] = mod * __expf(ls[0]);
-  sm[1] = in.isotropic ? sm[0] : mod * __expf(ls[1]);
-  sm[2] = in.isotropic ? sm[0] : mod * __expf(ls[2]);
+  sm[1] = isotropic ? sm[0] : mod * __expf(ls[1]);
+  sm[2] = isotropic ? sm[0] : mod * __expf(ls[2]);
   float Mx[3][3];
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -49,6 +48,14 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) S3[i][j] = Mx[i][0] * Mx[j][0] + Mx[i][1] * Mx[j][1] + Mx[i][2] * Mx[j][2];
+}
+
+__device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod, float S3[3][3], float R[3][3], float sm[3],
+                                           float qn[4], float& qinv) {
+  const float* qp = in.rotation + (size_t)idx * 4;
+  const float* lp = in.scaling + (size_t)idx * 3;
+  const float q[4] = {qp[0], qp[1], qp[2], qp[3]}, ls[3] = {lp[0], lp[1], lp[2]};
+  slam_cov3d_vals(q, ls, in.isotropic != 0, mod, S3, R, sm, qn, qinv);
 }
 
 __global__ void __launch_bounds__(FB)
@@ -63,8 +70,16 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(in.pose);
   float p[3] = {0.f, 0.f, 0.f};
+  // every parameter of this Gaussian is requested up front (one memory latency for the kernel, not two: the map is
+  // almost entirely in view in a SLAM iteration, so nothing is wasted on culled splats)
+  float q_raw[4] = {1.f, 0.f, 0.f, 0.f}, ls_raw[3] = {0.f, 0.f, 0.f}, fd_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
   if (live) {
     const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q_raw[k] = in.rotation[(size_t)idx * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ls_raw[k] = in.scaling[(size_t)idx * 3 + k]; fd_raw[k] = in.f_dc[(size_t)idx * 3 + k]; }
+    op_raw = in.opacity[idx];
 #pragma unroll
     for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
   }
@@ -76,7 +91,7 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
     float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
     float pw = 1.f / (hw + 1e-7f);
     float S3[3][3], R[3][3], sm[3], qn[4], qinv;
-    slam_cov3d(in, idx, cam.scale_modifier, S3, R, sm, qn, qinv);
+    slam_cov3d_vals(q_raw, ls_raw, in.isotropic != 0, cam.scale_modifier, S3, R, sm, qn, qinv);
     Ewa e;
     ewa_project(cam, Vi, p, S3, e);
     float det = e.a * e.c - e.b * e.b;
@@ -96,11 +111,11 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
         rad = (int32_t)fminf(rf, 2.0e9f);
         r0 = (uint32_t)minx | ((uint32_t)miny << 16);
         r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
-        const float* fd = in.f_dc + (size_t)idx * 3;
+        const float* fd = fd_raw;
         float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
         g.clamped[idx] = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
         const float z = p[2];
-        const float op = 1.f / (1.f + __expf(-in.opacity[idx]));
+        const float op = 1.f / (1.f + __expf(-op_raw));
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
         sp[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
         sp[1] = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
