@@ -244,7 +244,13 @@ def main():
         ach = alg_bytes / dur / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                            "frac": ach / 8000.0, "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg_bytes,
-                           "avg_launch_us": dur * 1e6, "launches": n_bwd}
+                           "avg_launch_us": dur * 1e6, "launches": n_bwd,
+                           # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any
+                           # early-out, ~25 flop + 1 exp each (SURVEY's figure), against the dense f32 VALU peak.  This
+                           # is the ceiling the kernel actually runs into (profiles/r01_sq_counters.md)
+                           "valu": {"evaluations_per_launch": 256 * N, "achieved_gevals_per_s": 256 * N / dur / 1e9,
+                                    "flop_per_evaluation": 25, "achieved_tflops": 256 * N * 25 / dur / 1e12,
+                                    "peak_tflops": 157.3, "frac": 256 * N * 25 / dur / 1e12 / 157.3}}
         out["kernel_us"] = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")

@@ -210,6 +210,81 @@ struct WaveReduce {
   }
 };
 
+#define ROW_ROR12 0x12C
+
+// Separable reduction of the SLAM modes.  The wave is an 8x8 pixel block (lane = 8 y + x) and the geometric moments factor:
+// sum u dx^a dy^b = sum_y dy^b (sum_x u dx^a).  The x direction (lane bits 0..2) is reduced first on 8 values
+//   a[] = { u, u dx, u dx^2, c0, c1, c2, c3, u }      (c* = colour / depth terms, plain sums; u twice on purpose)
+// with a halving butterfly (8 -> 4 -> 2 -> 1 registers); lane x then holds row-sum number  idx(x) = b2 + 2 b1 + 4 b0.
+// The y direction needs only TWO registers: X itself (-> M0, Mx, Mxx, c*) and Y = X * {dy, dy, dy^2} on the lanes
+// holding {R0, R1, R0'} (-> My, Mxy, Myy); they are merged on lane bit 3 and summed over bits 4, 5.  40 VALU per splat
+// instead of 49 for the generic 10-value butterfly.  Result: lanes 0..7 hold the X totals, lanes 8..15 the Y totals.
+template <bool RGB>
+struct SepReduce {
+  // record position of the value a lane < 16 ends up with (-1: nothing to store)
+  //   mapping (RGB): [M0 Mx Mxx c0 | c1 c2 c3 My | Mxy Myy];   tracking (!RGB): [M0 Mx Mxx c3 | My Mxy Myy]
+  __device__ static __forceinline__ int slot(int lane) {
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+    const int idx = b2 + 2 * b1 + 4 * b0;
+    if (!b3) {
+      if (idx <= 2) return idx;
+      if (RGB) return idx <= 6 ? idx : -1;
+      return idx == 6 ? 3 : -1;
+    }
+    const int base = RGB ? 7 : 4;
+    if (idx == 0) return base;       // My  = sum dy R0
+    if (idx == 1) return base + 1;   // Mxy = sum dy R1
+    if (idx == 7) return base + 2;   // Myy = sum dy^2 R0'
+    return -1;
+  }
+  // per-lane multiplier selectors of the Y register: (ma, mb) with Y = X * dy * (ma + mb * dy)
+  __device__ static __forceinline__ void ymult(int lane, float& ma, float& mb) {
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1;
+    const int idx = b2 + 2 * b1 + 4 * b0;
+    ma = (idx == 0 || idx == 1) ? 1.f : 0.f;
+    mb = idx == 7 ? 1.f : 0.f;
+  }
+  __device__ static __forceinline__ float run(float u, float dx, float dy, float c0, float c1, float c2, float c3, int lane, float ma,
+                                              float mb) {
+#pragma clang fp contract(off)
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    const float udx = u * dx, udxx = udx * dx;
+    // bit 0: pairs (i, i + 4)
+    float l1[4];
+    {
+      const float s0 = u + dpp_all<QP_XOR1>(u), s1 = udx + dpp_all<QP_XOR1>(udx), s2 = udxx + dpp_all<QP_XOR1>(udxx);
+      const float s3 = c0 + dpp_all<QP_XOR1>(c0);
+      const float s6 = c3 + dpp_all<QP_XOR1>(c3);
+      if (RGB) {
+        const float s4 = c1 + dpp_all<QP_XOR1>(c1), s5 = c2 + dpp_all<QP_XOR1>(c2);
+        l1[0] = b0 ? s4 : s0; l1[1] = b0 ? s5 : s1;
+      } else {
+        l1[0] = s0; l1[1] = s1;   // odd lanes carry junk there: never stored (slot() = -1)
+      }
+      l1[2] = b0 ? s6 : s2;
+      l1[3] = b0 ? s0 : s3;       // value 7 is u again (s0), value 3 is c0
+      if (!RGB) l1[3] = s0;       // tracking has no c0: keep u on both parities (even lanes: junk slot 3, never stored)
+    }
+    // bit 1: pairs (i, i + 2)
+    float l2[2];
+    {
+      const float t0 = l1[0] + dpp_all<QP_XOR2>(l1[0]), t1 = l1[1] + dpp_all<QP_XOR2>(l1[1]);
+      const float t2 = l1[2] + dpp_all<QP_XOR2>(l1[2]), t3 = l1[3] + dpp_all<QP_XOR2>(l1[3]);
+      l2[0] = b1 ? t2 : t0;
+      l2[1] = b1 ? t3 : t1;
+    }
+    // bit 2: lanes with b2 = 0 take value i = 0 from their partner 4 lanes up, b2 = 1 take i = 1 from 4 lanes down
+    // (row_ror:n hands lane i the value of lane i - n: measured with tools/ubench/dpp_dir.hip)
+    const float x0 = l2[0] + dpp_all<ROW_ROR12>(l2[0]);
+    const float x1 = l2[1] + dpp_all<ROW_ROR4>(l2[1]);
+    const float X = b2 ? x1 : x0;
+    // y direction
+    const float Y = X * (dy * (ma + mb * dy));
+    const float tX = X + dpp_all<ROW_ROR8>(X), tY = Y + dpp_all<ROW_ROR8>(Y);
+    return b3 ? tY : tX;
+  }
+};
+
 __device__ __forceinline__ float xrow_sum(float v) {
   // add the four 16-lane rows lane-wise: xor 16 through the LDS crossbar (ds_swizzle), xor 32 with permlane32_swap
   v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
@@ -241,7 +316,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   if (count == 0) return;  // wave-uniform
   const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
 
-  constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 6);
+  constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
   // [buffer][wave][field A|B|C|pair index][entry]: lane-contiguous (conflict-free) writes, and ONE address register per
@@ -277,7 +352,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   }
   if (todo == 0) return;
 
-  const int my_slot = (lane < 16) ? WaveReduce<NV>::slot(lane) : -1;
+  const int my_slot = lane >= 16 ? -1 : (MODE == 0 ? WaveReduce<NV>::slot(lane) : SepReduce<MODE == 1>::slot(lane));
+  float ym_a = 0.f, ym_b = 0.f;
+  if (MODE != 0) SepReduce<MODE == 1>::ymult(lane, ym_a, ym_b);
   // this lane's component of this sub-tile's record of pair 0; the record of pair p is 192 B further per p
   float* const my_rec = dsub + (size_t)wv * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
@@ -325,7 +402,6 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         if (C > 3) col[3] = Cc.y;
         if (C > 4) col[4] = Cc.z;
         if (C > 5) col[5] = Cc.w;
-        float vals[NV];
         // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
         // (behind_dot) instead of C running colours: q = c . dL;  dLa = q - behind_dot;  behind_dot += a (q - behind_dot)
         float q = 0.f;
@@ -333,27 +409,27 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         for (int ch = 0; ch < C; ch++) q = fmaf(col[ch], dL[ch], q);
         const float diff = q - behind_dot;
         behind_dot = fmaf(a_eff, diff, behind_dot);
+        const float dLa = diff * Tr - Tf_bg * r;
+        // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
+        // into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
+        const float u = B.y * dLa * G_eff;
         if (MODE == 0) {
+          float vals[NV];
 #pragma unroll
           for (int ch = 0; ch < C; ch++) vals[6 + ch] = w * dL[ch];
+          const float mx = u * dx, my = u * dy;
+          vals[0] = mx;
+          vals[1] = my;
+          vals[2] = mx * dx;
+          vals[3] = mx * dy;
+          vals[4] = my * dy;
+          vals[5] = G_eff * dLa;
+          tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
+        } else {
+          // SLAM records: the zeroth moment M0 = sum u also carries the opacity gradient (sum G dL/dalpha = M0 / opacity)
+          const float cz = w * fmaf(2.f * col[3], dL[5], dL[3]);   // d/dz of the [z, 1, z^2] bundle, chained here
+          tot = xrow_sum(SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_a, ym_b));
         }
-        if (MODE == 1) {
-          vals[6] = w * dL[0]; vals[7] = w * dL[1]; vals[8] = w * dL[2];
-          vals[9] = w * fmaf(2.f * col[3], dL[5], dL[3]);
-        }
-        if (MODE == 2) vals[5] = w * fmaf(2.f * col[3], dL[5], dL[3]);
-        const float dLa = diff * Tr - Tf_bg * r;
-        // screen-space geometry: only the five moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns
-        // them into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
-        const float u = B.y * dLa * G_eff;
-        const float mx = u * dx, my = u * dy;
-        vals[0] = mx;
-        vals[1] = my;
-        vals[2] = mx * dx;
-        vals[3] = mx * dy;
-        vals[4] = my * dy;
-        if (MODE != 2) vals[5] = G_eff * dLa;
-        tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
       }
       // this wave is the only writer of the (sub-tile, splat) record: 12 lanes store 48 contiguous bytes
       if (my_slot >= 0) my_rec[(size_t)ti * (4 * SPLAT_F)] = tot;

@@ -203,8 +203,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
     }
-    // Records are indexed by the Gaussian-major pair index (contiguous per Gaussian); layout (composite_bwd MODE 1 / 2):
-    // dxy dconic | dop drgb dz  or  dxy dconic dz.  The kernel is latency bound (~2.4 waves per SIMD), so the loads of a
+    // Records are indexed by the Gaussian-major pair index (contiguous per Gaussian); 10 (mapping) / 7 (tracking) floats.  The kernel is latency bound (~2.4 waves per SIMD), so the loads of a
     // pair's four sub-tile records are issued together without branches: an unlisted sub-tile reads record 0 (one shared,
     // cached line) and is discarded by a select.  Summation order is fixed -> deterministic.
     auto add_pair = [&](uint32_t slot, uint32_t m) {
@@ -284,10 +283,13 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
       const float4 sp0 = spl[0], sp1 = spl[1];
       const float qa = sp0.z, qb = sp0.w, qc = sp1.x;
-      const float gpx = -(qa * acc0.x + qb * acc0.y), gpy = -(qc * acc0.y + qb * acc0.x);
-      const float gA = -0.5f * acc0.z, gB = -acc0.w, gC = -0.5f * acc1.x;
-      const float dop = TRACK ? 0.f : acc1.y, dc0 = acc1.z, dc1 = acc1.w, dc2 = acc2.x;
-      const float dz_tot = TRACK ? acc1.y : acc2.y;   // d/dz of the [z, 1, z^2] bundle, already chained by the compositor
+      // record layouts of composite.hip's SepReduce:  mapping [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy],  tracking [M0 Mx Mxx cz | My Mxy Myy]
+      const float M0 = acc0.x, m_x = acc0.y, m_xx = acc0.z;
+      const float m_y = TRACK ? acc1.x : acc1.w, m_xy = TRACK ? acc1.y : acc2.x, m_yy = TRACK ? acc1.z : acc2.y;
+      const float dc0 = acc0.w, dc1 = acc1.x, dc2 = acc1.y;        // mapping only
+      const float dz_tot = TRACK ? acc0.w : acc1.z;               // d/dz of the [z, 1, z^2] bundle, already chained by the compositor
+      const float gpx = -(qa * m_x + qb * m_y), gpy = -(qc * m_y + qb * m_x);
+      const float gA = -0.5f * m_xx, gB = -m_xy, gC = -0.5f * m_yy;
       const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
       float p[3];
 #pragma unroll
@@ -347,7 +349,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
         dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
         dfd[2] = (cl & 4) ? 0.f : SH_C0F * dc2;
         const float o = 1.f / (1.f + __expf(-in.opacity[idx]));
-        dlogit = dop * o * (1.f - o);
+        dlogit = M0 * (1.f - o);   // sum G dL/dalpha = M0 / o, times d sigmoid = o (1 - o)
         float dM[3][3], dR[3][3], ds[3];
 #pragma unroll
         for (int i = 0; i < 3; i++)
