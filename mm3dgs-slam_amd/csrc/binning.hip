@@ -248,8 +248,9 @@ template <int CAP, bool GLOBAL_TAIL>
 __global__ void __launch_bounds__(256)
 sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean) {
   __shared__ unsigned long long sk[CAP];
-  __shared__ uint32_t wcnt[4][4];
-  __shared__ uint32_t run[4];
+  __shared__ uint32_t wcnt[4][NLIST];   // per-wave entry counts of a 256-entry chunk, per block list
+  __shared__ uint32_t pre[4][NLIST];    // write cursor of (wave, list) for the chunk
+  __shared__ uint32_t run[NLIST];
   const int tile = blockIdx.x;
   if (tile >= T) return;
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
@@ -257,7 +258,7 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (clean && tid == 0) { iv.tile_count[tile] = 0; iv.cursor[tile] = 0; }   // scatter_scan_kernel's counters stay zero
   if (lo == 0 && len == 0) {
-    if (tid < 4) iv.subcount[4 * tile + tid] = 0;
+    if (tid < NLIST) iv.subcount[NLIST * tile + tid] = 0;
     return;
   }
   if (len <= lo) return;
@@ -286,17 +287,16 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
     __syncthreads();
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
   }
-  // ---- emit sub-tile lists (order preserving) ----
+  // ---- emit the 16 block lists (order preserving) ----
   const int ttx = tile % gx, tty = tile / gx;
   const float tx0 = (float)(ttx * TILE), ty0 = (float)(tty * TILE);
-  if (tid < 4) run[tid] = 0;
+  if (tid < NLIST) run[tid] = 0;
   __syncthreads();
-  uint2* sub = b.sublist + (size_t)4 * start;
+  uint2* sub = b.sublist + (size_t)NLIST * start;
   for (int base = 0; base < len; base += 256) {
     const int i = base + tid;
     const bool have = i < len;
-    uint32_t id = 0, pidx = 0;
-    bool ov0 = false, ov1 = false, ov2 = false, ov3 = false;
+    uint32_t id = 0, pidx = 0, mask = 0;
     if (have) {
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
       const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
@@ -305,60 +305,74 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
       const float tau = __logf(255.f * B.y);
       const float det = A.z * B.x - A.w * A.w;
       if (det > 0.f) {
-        bool ovx0, ovx1, ovy0, ovy1;
-        const float k = 2.f * fmaxf(tau, 0.f) / det;
+        // a 4x4 block (pixel centres [x0, x0+3] x [y0, y0+3]) is listed only where the {alpha >= 1/255} region can reach:
+        // its axis-aligned bound must overlap the block AND the block must come within sqrt(2 tau lambda_max) of the centre
+        // (exact for isotropic splats, where the box test alone keeps the corners a disc cannot reach).  Both necessary.
+        const float t2 = 2.f * fmaxf(tau, 0.f);
+        const float k = t2 / det;
         const float hx = sqrtf(k * B.x) * 1.0002f + 0.002f;
         const float hy = sqrtf(k * A.z) * 1.0002f + 0.002f;
-        const float xl = A.x - hx - tx0, xh = A.x + hx - tx0;
-        const float yl = A.y - hy - ty0, yh = A.y + hy - ty0;
-        const bool live = tau > 0.f;
-        ovx0 = live && (xl <= 7.f) && (xh >= 0.f);
-        ovx1 = live && (xl <= 15.f) && (xh >= 8.f);
-        ovy0 = live && (yl <= 7.f) && (yh >= 0.f);
-        ovy1 = live && (yl <= 15.f) && (yh >= 8.f);
-        // second necessary condition: the sub-tile must come within sqrt(2 tau lambda_max) of the centre (exact for
-        // isotropic splats, where the box test alone keeps the corners a disc cannot reach)
         const float sxx = B.x / det, syy = A.z / det, mid = 0.5f * (sxx + syy);
         const float lam = mid + sqrtf(fmaxf(mid * mid - 1.f / det, 0.f));
-        const float r2 = 2.f * fmaxf(tau, 0.f) * lam * 1.0004f + 0.01f;
+        const float r2 = t2 * lam * 1.0004f + 0.01f;
         const float cx = A.x - tx0, cy = A.y - ty0;
-        const float dx0 = fmaxf(fmaxf(0.f - cx, cx - 7.f), 0.f), dx1 = fmaxf(fmaxf(8.f - cx, cx - 15.f), 0.f);
-        const float dy0 = fmaxf(fmaxf(0.f - cy, cy - 7.f), 0.f), dy1 = fmaxf(fmaxf(8.f - cy, cy - 15.f), 0.f);
-        ov0 = ovx0 && ovy0 && (dx0 * dx0 + dy0 * dy0 <= r2);
-        ov1 = ovx1 && ovy0 && (dx1 * dx1 + dy0 * dy0 <= r2);
-        ov2 = ovx0 && ovy1 && (dx0 * dx0 + dy1 * dy1 <= r2);
-        ov3 = ovx1 && ovy1 && (dx1 * dx1 + dy1 * dy1 <= r2);
+        const bool live = tau > 0.f;
+        bool bx[4], by[4];
+        float ex[4], ey[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float lo = 4.f * q, hi = 4.f * q + 3.f;
+          bx[q] = live && (cx - hx <= hi) && (cx + hx >= lo);
+          by[q] = live && (cy - hy <= hi) && (cy + hy >= lo);
+          const float dxq = fmaxf(fmaxf(lo - cx, cx - hi), 0.f), dyq = fmaxf(fmaxf(lo - cy, cy - hi), 0.f);
+          ex[q] = dxq * dxq; ey[q] = dyq * dyq;
+        }
+#pragma unroll
+        for (int my = 0; my < 4; my++)
+#pragma unroll
+          for (int kx = 0; kx < 4; kx++) {
+            const int L = 4 * ((my >> 1) * 2 + (kx >> 1)) + (my & 1) * 2 + (kx & 1);   // 4 * sub-tile + block in sub-tile
+            if (bx[kx] && by[my] && (ex[kx] + ey[my] <= r2)) mask |= 1u << L;
+          }
       } else {
-        ov0 = ov1 = ov2 = ov3 = true;  // degenerate conic: no culling, the exact per-pixel rule decides
+        mask = 0xffffu;  // degenerate conic: no culling, the exact per-pixel rule decides
       }
       // pair index of (Gaussian, tile) in Gaussian-major order: the backward records of one Gaussian are contiguous
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
       pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
-      if (pidx < N_cap) {
-        b.submask[pidx] = (uint8_t)((ov0 ? 1 : 0) | (ov1 ? 2 : 0) | (ov2 ? 4 : 0) | (ov3 ? 8 : 0));
-      } else {
-        ov0 = ov1 = ov2 = ov3 = false;   // only on capacity overflow (flagged in the header)
-      }
+      if (pidx < N_cap) b.submask[pidx] = (uint16_t)mask;
+      else mask = 0;   // only on capacity overflow (flagged in the header)
     }
-    const unsigned long long m0 = __ballot(ov0), m1 = __ballot(ov1), m2 = __ballot(ov2), m3 = __ballot(ov3);
-    if (lane == 0) {
-      wcnt[wv][0] = __popcll(m0); wcnt[wv][1] = __popcll(m1); wcnt[wv][2] = __popcll(m2); wcnt[wv][3] = __popcll(m3);
+    unsigned long long bal[NLIST];
+#pragma unroll
+    for (int L = 0; L < NLIST; L++) bal[L] = __ballot((mask >> L) & 1u);
+    if (lane < NLIST) {
+      unsigned long long mine = bal[0];
+#pragma unroll
+      for (int L = 1; L < NLIST; L++) mine = lane == L ? bal[L] : mine;
+      wcnt[wv][lane] = __popcll(mine);
     }
     __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t pre[4] = {run[0], run[1], run[2], run[3]};
-    for (int w2 = 0; w2 < wv; w2++) { pre[0] += wcnt[w2][0]; pre[1] += wcnt[w2][1]; pre[2] += wcnt[w2][2]; pre[3] += wcnt[w2][3]; }
-    const uint2 ent = make_uint2(id, pidx);
-    if (ov0) sub[0 * len + pre[0] + __popcll(m0 & lt)] = ent;
-    if (ov1) sub[(size_t)1 * len + pre[1] + __popcll(m1 & lt)] = ent;
-    if (ov2) sub[(size_t)2 * len + pre[2] + __popcll(m2 & lt)] = ent;
-    if (ov3) sub[(size_t)3 * len + pre[3] + __popcll(m3 & lt)] = ent;
+    if (tid < 4 * NLIST) {
+      const int w = tid >> 4, L = tid & 15;
+      uint32_t p0 = run[L];
+      for (int w2 = 0; w2 < w; w2++) p0 += wcnt[w2][L];
+      pre[w][L] = p0;
+    }
     __syncthreads();
-    if (tid < 4) run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    if (mask) {
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const uint2 ent = make_uint2(id, pidx);
+#pragma unroll
+      for (int L = 0; L < NLIST; L++)
+        if ((mask >> L) & 1u) sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = ent;
+    }
+    __syncthreads();
+    if (tid < NLIST) run[tid] = pre[3][tid] + wcnt[3][tid];
     __syncthreads();
   }
-  if (tid < 4) iv.subcount[4 * tile + tid] = run[tid];
+  if (tid < NLIST) iv.subcount[NLIST * tile + tid] = run[tid];
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)

@@ -56,19 +56,28 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (lane & 7);
-  const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (lane >> 3);
+  // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
+  const int row = lane >> 4, q = lane & 15;
+  const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (row & 1) * 4 + (q & 3);
+  const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
   const uint32_t len = end - start;
-  const uint32_t count = __builtin_amdgcn_readfirstlane(len ? min(iv.subcount[4 * tile + wv], len) : 0u);
-  const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
+  const int L = 4 * wv + row;
+  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
+  uint32_t maxcount = count;
+  maxcount = max(maxcount, (uint32_t)__builtin_amdgcn_readlane((int)count, 16));
+  maxcount = max(maxcount, (uint32_t)__builtin_amdgcn_readlane((int)count, 32));
+  maxcount = max(maxcount, (uint32_t)__builtin_amdgcn_readlane((int)count, 48));
+  maxcount = max((uint32_t)__builtin_amdgcn_readlane((int)count, 0), maxcount);
+  maxcount = __builtin_amdgcn_readfirstlane(maxcount);
+  const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
-  // wave-private, double-buffered staging: [buffer][wave][entry]
-  // [buffer][wave][field A|B|C][entry]: lane-contiguous (conflict-free) writes, and ONE address register per splat for the
-  // broadcast reads (fields are a constant 1 KB apart -> immediate offsets)
+  // [buffer][wave][field A|B|C][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address register per
+  // splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
   __shared__ float4 stg[2][4][3][64];
+  constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   float Tr = 1.f;
   float acc[C];
@@ -80,28 +89,29 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 
   // pipeline prologue: chunk 0 parked in LDS buffer 0, ids of chunk 1 in registers
   {
-    const uint32_t id0 = lane < count ? list[lane].x : 0u;
-    const SplatRec r0 = load_rec<C>(g.splat, id0, lane < count);
+    const uint32_t id0 = (uint32_t)q < count ? list[q].x : 0u;
+    const SplatRec r0 = load_rec<C>(g.splat, id0, (uint32_t)q < count);
     stg[0][wv][0][lane] = r0.A;
     stg[0][wv][1][lane] = r0.B;
     if (C > 2) stg[0][wv][2][lane] = r0.C;
   }
-  uint32_t id_nxt = 64u + lane < count ? list[64u + lane].x : 0u;
+  uint32_t id_nxt = CH + q < count ? list[CH + q].x : 0u;
   int cur = 0;
 
-  for (uint32_t base = 0; base < count; base += 64, cur ^= 1) {
+  for (uint32_t base = 0; base < maxcount; base += CH, cur ^= 1) {
     // issue the gathers for the following chunks before touching this one; they land while it is composited
-    const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + 64u + lane < count);
-    const uint32_t id_nn = base + 128u + lane < count ? list[base + 128u + lane].x : 0u;
+    const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + CH + q < count);
+    const uint32_t id_nn = base + 2 * CH + q < count ? list[base + 2 * CH + q].x : 0u;
     const float4 (*wS)[64] = stg[cur][wv];
+    const int r16 = row * 16;
     __builtin_amdgcn_wave_barrier();
-    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, count - base));
+    const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxcount - base));
     auto splat_fwd = [&](const float4& A, const float4& B, const float4& Cc, const int j) {
       n_iter++;
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
       const float alpha = fminf(0.99f, B.y * __expf(power));
-      const bool ok = !done && !(power > 0.f) && !(alpha < ALPHA_MIN);
+      const bool ok = !done && (base + (uint32_t)j < count) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       const float test_T = Tr * (1.f - alpha);
       const bool stop = ok && (test_T < T_EPS);
       const bool contrib = ok && !stop;
@@ -117,18 +127,18 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       last_contributor = contrib ? base + (uint32_t)j + 1u : last_contributor;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated
-    float4 A0 = wS[0][0], B0 = wS[1][0], C0 = wS[2][0];
+    float4 A0 = wS[0][r16], B0 = wS[1][r16], C0 = wS[2][r16];
     for (int j = 0; j < cnt; j += 2) {
       const int j1 = j + 1 < cnt ? j + 1 : j;
-      const float4 A1 = wS[0][j1], B1 = wS[1][j1], C1 = wS[2][j1];
+      const float4 A1 = wS[0][r16 + j1], B1 = wS[1][r16 + j1], C1 = wS[2][r16 + j1];
       splat_fwd(A0, B0, C0, j);
       if (j + 1 < cnt) {
         const int j2 = j + 2 < cnt ? j + 2 : j1;
-        A0 = wS[0][j2]; B0 = wS[1][j2]; C0 = wS[2][j2];
+        A0 = wS[0][r16 + j2]; B0 = wS[1][r16 + j2]; C0 = wS[2][r16 + j2];
         splat_fwd(A1, B1, C1, j1);
       }
     }
-    if (__ballot(!done) == 0ull) break;
+    if (__ballot(!done && base + CH < count) == 0ull) break;
     stg[cur ^ 1][wv][0][lane] = rec_n.A;
     stg[cur ^ 1][wv][1][lane] = rec_n.B;
     if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
@@ -212,19 +222,19 @@ struct WaveReduce {
 
 #define ROW_ROR12 0x12C
 
-// Separable reduction of the SLAM modes.  The wave is an 8x8 pixel block (lane = 8 y + x) and the geometric moments factor:
-// sum u dx^a dy^b = sum_y dy^b (sum_x u dx^a).  The x direction (lane bits 0..2) is reduced first on 8 values
+// Separable reduction of the SLAM modes over ONE 16-lane row = one 4x4 pixel block (lane bits 0,1 = x, bits 2,3 = y).
+// The geometric moments factor: sum u dx^a dy^b = sum_y dy^b (sum_x u dx^a).  The x direction is reduced first on 8 values
 //   a[] = { u, u dx, u dx^2, c0, c1, c2, c3, u }      (c* = colour / depth terms, plain sums; u twice on purpose)
-// with a halving butterfly (8 -> 4 -> 2 -> 1 registers); lane x then holds row-sum number  idx(x) = b2 + 2 b1 + 4 b0.
-// The y direction needs only TWO registers: X itself (-> M0, Mx, Mxx, c*) and Y = X * {dy, dy, dy^2} on the lanes
-// holding {R0, R1, R0'} (-> My, Mxy, Myy); they are merged on lane bit 3 and summed over bits 4, 5.  40 VALU per splat
-// instead of 49 for the generic 10-value butterfly.  Result: lanes 0..7 hold the X totals, lanes 8..15 the Y totals.
+// with a halving butterfly (8 -> 4 -> 2 registers); register i of lane (b0, b1) then holds row-sum idx = i + 2 b1 + 4 b0.
+// The y direction works on those two registers and their dy-weighted copies Y_i = X_i * {dy, dy, dy^2} on the lanes
+// holding {R0, R1, R0'} (-> My, Mxy, Myy), halved on lane bits 2 and 3.  Result: lanes with b3 = 0 hold the X totals
+// (M0 Mx Mxx c0 c1 c2 c3), lanes with b3 = 1 the Y totals, value index idx = b2 + 2 b1 + 4 b0.
 template <bool RGB>
 struct SepReduce {
-  // record position of the value a lane < 16 ends up with (-1: nothing to store)
+  // record position of the value lane q (0..15 within its row) ends up with (-1: nothing to store)
   //   mapping (RGB): [M0 Mx Mxx c0 | c1 c2 c3 My | Mxy Myy];   tracking (!RGB): [M0 Mx Mxx c3 | My Mxy Myy]
-  __device__ static __forceinline__ int slot(int lane) {
-    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+  __device__ static __forceinline__ int slot(int q) {
+    const int b0 = q & 1, b1 = (q >> 1) & 1, b2 = (q >> 2) & 1, b3 = (q >> 3) & 1;
     const int idx = b2 + 2 * b1 + 4 * b0;
     if (!b3) {
       if (idx <= 2) return idx;
@@ -237,15 +247,15 @@ struct SepReduce {
     if (idx == 7) return base + 2;   // Myy = sum dy^2 R0'
     return -1;
   }
-  // per-lane multiplier selectors of the Y register: (ma, mb) with Y = X * dy * (ma + mb * dy)
-  __device__ static __forceinline__ void ymult(int lane, float& ma, float& mb) {
-    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1;
-    const int idx = b2 + 2 * b1 + 4 * b0;
-    ma = (idx == 0 || idx == 1) ? 1.f : 0.f;
-    mb = idx == 7 ? 1.f : 0.f;
+  // per-lane selectors of the dy weights: Y0 = X0 * dy * m0,  Y1 = X1 * dy * (m1a + m1b * dy)
+  __device__ static __forceinline__ void ymult(int q, float& m0, float& m1a, float& m1b) {
+    const int b0 = q & 1, b1 = (q >> 1) & 1;
+    m0 = (!b0 && !b1) ? 1.f : 0.f;    // register 0 holds idx 0 (R0) there
+    m1a = (!b0 && !b1) ? 1.f : 0.f;   // register 1 holds idx 1 (R1) there
+    m1b = (b0 && b1) ? 1.f : 0.f;     // register 1 holds idx 7 (R0') there
   }
-  __device__ static __forceinline__ float run(float u, float dx, float dy, float c0, float c1, float c2, float c3, int lane, float ma,
-                                              float mb) {
+  __device__ static __forceinline__ float run(float u, float dx, float dy, float c0, float c1, float c2, float c3, int lane, float m0,
+                                              float m1a, float m1b) {
 #pragma clang fp contract(off)
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
     const float udx = u * dx, udxx = udx * dx;
@@ -253,33 +263,31 @@ struct SepReduce {
     float l1[4];
     {
       const float s0 = u + dpp_all<QP_XOR1>(u), s1 = udx + dpp_all<QP_XOR1>(udx), s2 = udxx + dpp_all<QP_XOR1>(udxx);
-      const float s3 = c0 + dpp_all<QP_XOR1>(c0);
       const float s6 = c3 + dpp_all<QP_XOR1>(c3);
       if (RGB) {
-        const float s4 = c1 + dpp_all<QP_XOR1>(c1), s5 = c2 + dpp_all<QP_XOR1>(c2);
+        const float s3 = c0 + dpp_all<QP_XOR1>(c0), s4 = c1 + dpp_all<QP_XOR1>(c1), s5 = c2 + dpp_all<QP_XOR1>(c2);
         l1[0] = b0 ? s4 : s0; l1[1] = b0 ? s5 : s1;
+        l1[3] = b0 ? s0 : s3;     // value 7 is u again (s0), value 3 is c0
       } else {
         l1[0] = s0; l1[1] = s1;   // odd lanes carry junk there: never stored (slot() = -1)
+        l1[3] = s0;               // no c0: keep u on both parities (even lanes: junk value 3, never stored)
       }
       l1[2] = b0 ? s6 : s2;
-      l1[3] = b0 ? s0 : s3;       // value 7 is u again (s0), value 3 is c0
-      if (!RGB) l1[3] = s0;       // tracking has no c0: keep u on both parities (even lanes: junk slot 3, never stored)
     }
     // bit 1: pairs (i, i + 2)
-    float l2[2];
+    float X0, X1;
     {
       const float t0 = l1[0] + dpp_all<QP_XOR2>(l1[0]), t1 = l1[1] + dpp_all<QP_XOR2>(l1[1]);
       const float t2 = l1[2] + dpp_all<QP_XOR2>(l1[2]), t3 = l1[3] + dpp_all<QP_XOR2>(l1[3]);
-      l2[0] = b1 ? t2 : t0;
-      l2[1] = b1 ? t3 : t1;
+      X0 = b1 ? t2 : t0;
+      X1 = b1 ? t3 : t1;
     }
-    // bit 2: lanes with b2 = 0 take value i = 0 from their partner 4 lanes up, b2 = 1 take i = 1 from 4 lanes down
-    // (row_ror:n hands lane i the value of lane i - n: measured with tools/ubench/dpp_dir.hip)
-    const float x0 = l2[0] + dpp_all<ROW_ROR12>(l2[0]);
-    const float x1 = l2[1] + dpp_all<ROW_ROR4>(l2[1]);
-    const float X = b2 ? x1 : x0;
-    // y direction
-    const float Y = X * (dy * (ma + mb * dy));
+    // y direction: dy-weighted copies, then bit 2 (partner 4 lanes away: row_ror:n hands lane i the value of lane i - n,
+    // measured with tools/ubench/dpp_dir.hip) and bit 3 (partner 8 lanes away)
+    const float Y0 = X0 * (dy * m0), Y1 = X1 * (dy * (m1a + m1b * dy));
+    const float xa = X0 + dpp_all<ROW_ROR12>(X0), xb = X1 + dpp_all<ROW_ROR4>(X1);
+    const float ya = Y0 + dpp_all<ROW_ROR12>(Y0), yb = Y1 + dpp_all<ROW_ROR4>(Y1);
+    const float X = b2 ? xb : xa, Y = b2 ? yb : ya;
     const float tX = X + dpp_all<ROW_ROR8>(X), tY = Y + dpp_all<ROW_ROR8>(Y);
     return b3 ? tY : tX;
   }
@@ -306,22 +314,25 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (lane & 7);
-  const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (lane >> 3);
+  // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
+  const int row = lane >> 4, q = lane & 15;
+  const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (row & 1) * 4 + (q & 3);
+  const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
   const uint32_t len = end - start;
-  const uint32_t count = __builtin_amdgcn_readfirstlane(len ? min(iv.subcount[4 * tile + wv], len) : 0u);
-  if (count == 0) return;  // wave-uniform
-  const uint2* __restrict__ list = b.sublist + (size_t)4 * start + (size_t)wv * len;
+  const int L = 4 * wv + row;
+  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
+  const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
-  // [buffer][wave][field A|B|C|pair index][entry]: lane-contiguous (conflict-free) writes, and ONE address register per
-  // splat for the broadcast reads (fields are a constant 1 KB apart -> immediate offsets)
+  // [buffer][wave][field A|B|C|pair index][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address
+  // register per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
   __shared__ float4 stg[2][4][4][64];
+  constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   const float T_final = inside ? iv.final_T[pix] : 0.f;
@@ -337,55 +348,60 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   float Tr = T_final;
   float behind_dot = 0.f;  // (colour accumulated behind the current list position) . dL
 
-  // nothing behind the deepest contributor of any pixel of the sub-tile matters
+  // nothing behind the deepest contributor of any pixel of the block matters: todo = max over the row
   uint32_t todo = last_contributor;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
-  todo = min((uint32_t)__builtin_amdgcn_readfirstlane(todo), count);
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR1, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR2, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR4, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR8, 0xf, 0xf, true));
+  todo = min(todo, count);
+  uint32_t maxtodo = max(max((uint32_t)__builtin_amdgcn_readlane((int)todo, 0), (uint32_t)__builtin_amdgcn_readlane((int)todo, 16)),
+                         max((uint32_t)__builtin_amdgcn_readlane((int)todo, 32), (uint32_t)__builtin_amdgcn_readlane((int)todo, 48)));
 
   // entries behind `todo` receive no gradient: their records are zero
-  for (uint32_t e = todo + lane; e < count; e += 64) {
-    float4* r = (float4*)(dsub + ((size_t)list[e].y * 4 + wv) * SPLAT_F);
+  for (uint32_t e = todo + q; e < count; e += 16) {
+    float4* r = (float4*)(dsub + ((size_t)list[e].y * NLIST + L) * SPLAT_F);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < NF4; q++) r[q] = z;
+    for (int f = 0; f < NF4; f++) r[f] = z;
   }
-  if (todo == 0) return;
+  if (maxtodo == 0) return;   // wave-uniform
 
-  const int my_slot = lane >= 16 ? -1 : (MODE == 0 ? WaveReduce<NV>::slot(lane) : SepReduce<MODE == 1>::slot(lane));
-  float ym_a = 0.f, ym_b = 0.f;
-  if (MODE != 0) SepReduce<MODE == 1>::ymult(lane, ym_a, ym_b);
-  // this lane's component of this sub-tile's record of pair 0; the record of pair p is 192 B further per p
-  float* const my_rec = dsub + (size_t)wv * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
+  const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : SepReduce<MODE == 1>::slot(q);
+  float ym_0 = 0.f, ym_1a = 0.f, ym_1b = 0.f;
+  if (MODE != 0) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
+  // this lane's component of this block's record of pair 0; the record of pair p is NLIST * 48 B further per p
+  float* const my_rec = dsub + (size_t)L * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
 
-  // chunk c holds list entries todo-1-(64c+lane): lane order == traversal order (back to front)
+  // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
   {
-    const uint2 e0 = lane < todo ? list[todo - 1u - lane] : make_uint2(0u, 0u);
-    const SplatRec r0 = load_rec<C>(g.splat, e0.x, lane < todo);
+    const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
+    const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
     stg[0][wv][0][lane] = r0.A;
     stg[0][wv][1][lane] = r0.B;
     if (C > 2) stg[0][wv][2][lane] = r0.C;
     ((uint32_t*)&stg[0][wv][3][lane])[0] = e0.y;
   }
-  uint2 ent_nxt = 64u + lane < todo ? list[todo - 1u - (64u + lane)] : make_uint2(0u, 0u);
+  uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
 
-  for (uint32_t base = 0; base < todo; base += 64, cur ^= 1) {
-    const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + 64u + lane < todo);
-    const uint2 ent_nn = base + 128u + lane < todo ? list[todo - 1u - (base + 128u + lane)] : make_uint2(0u, 0u);
+  for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
+    const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
+    const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
     const float4 (*wS)[64] = stg[cur][wv];
-    auto pair_of = [&](int j) { return ((const uint32_t*)&wS[3][j])[0]; };
+    const int r16 = row * 16;
+    auto pair_of = [&](int j) { return ((const uint32_t*)&wS[3][r16 + j])[0]; };
     __builtin_amdgcn_wave_barrier();
-    const int cnt = __builtin_amdgcn_readfirstlane((int)min(64u, todo - base));
-    // one splat: evaluate, reduce over the wave, store the record
+    const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti, const int j) {
-      const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the sub-tile list
+      const bool row_on = base + (uint32_t)j < todo;          // this row still has an entry at this step
+      const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the row's list (garbage when !row_on)
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
       const float G = __expf(power);
       const float alpha = fminf(0.99f, B.y * G);
-      const bool valid = (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
+      const bool valid = row_on && (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       float tot = 0.f;
       n_visit++;
       if (__ballot(valid) != 0ull) {
@@ -403,11 +419,11 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         if (C > 4) col[4] = Cc.z;
         if (C > 5) col[5] = Cc.w;
         // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
-        // (behind_dot) instead of C running colours: q = c . dL;  dLa = q - behind_dot;  behind_dot += a (q - behind_dot)
-        float q = 0.f;
+        // (behind_dot) instead of C running colours: qd = c . dL;  dLa = qd - behind_dot;  behind_dot += a (qd - behind_dot)
+        float qd = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) q = fmaf(col[ch], dL[ch], q);
-        const float diff = q - behind_dot;
+        for (int ch = 0; ch < C; ch++) qd = fmaf(col[ch], dL[ch], qd);
+        const float diff = qd - behind_dot;
         behind_dot = fmaf(a_eff, diff, behind_dot);
         const float dLa = diff * Tr - Tf_bg * r;
         // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
@@ -424,28 +440,28 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
           vals[3] = mx * dy;
           vals[4] = my * dy;
           vals[5] = G_eff * dLa;
-          tot = xrow_sum(WaveReduce<NV>::run(vals, lane));
+          tot = WaveReduce<NV>::run(vals, lane);
         } else {
           // SLAM records: the zeroth moment M0 = sum u also carries the opacity gradient (sum G dL/dalpha = M0 / opacity)
           const float cz = w * fmaf(2.f * col[3], dL[5], dL[3]);   // d/dz of the [z, 1, z^2] bundle, chained here
-          tot = xrow_sum(SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_a, ym_b));
+          tot = SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_0, ym_1a, ym_1b);
         }
       }
-      // this wave is the only writer of the (sub-tile, splat) record: 12 lanes store 48 contiguous bytes
-      if (my_slot >= 0) my_rec[(size_t)ti * (4 * SPLAT_F)] = tot;
+      // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
+      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * (NLIST * SPLAT_F)] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
-    float4 A0 = wS[0][0], B0 = wS[1][0], C0 = wS[2][0];
+    float4 A0 = wS[0][r16], B0 = wS[1][r16], C0 = wS[2][r16];
     uint32_t t0 = pair_of(0);
     for (int j = 0; j < cnt; j += 2) {
       const int j1 = j + 1 < cnt ? j + 1 : j;
-      const float4 A1 = wS[0][j1], B1 = wS[1][j1], C1 = wS[2][j1];
+      const float4 A1 = wS[0][r16 + j1], B1 = wS[1][r16 + j1], C1 = wS[2][r16 + j1];
       const uint32_t t1 = pair_of(j1);
       splat_bwd(A0, B0, C0, t0, j);
       if (j + 1 < cnt) {
         const int j2 = j + 2 < cnt ? j + 2 : j1;
-        A0 = wS[0][j2]; B0 = wS[1][j2]; C0 = wS[2][j2];
+        A0 = wS[0][r16 + j2]; B0 = wS[1][r16 + j2]; C0 = wS[2][r16 + j2];
         t0 = pair_of(j2);
         splat_bwd(A1, B1, C1, t1, j1);
       }

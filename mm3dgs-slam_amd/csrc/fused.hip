@@ -203,39 +203,42 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
     }
-    // Records are indexed by the Gaussian-major pair index (contiguous per Gaussian); 10 (mapping) / 7 (tracking) floats.  The kernel is latency bound (~2.4 waves per SIMD), so the loads of a
-    // pair's four sub-tile records are issued together without branches: an unlisted sub-tile reads record 0 (one shared,
-    // cached line) and is discarded by a select.  Summation order is fixed -> deterministic.
-    auto add_pair = [&](uint32_t slot, uint32_t m) {
-      float4 a[4], b[4], c[4];
+    // Records are indexed by 16 * (Gaussian-major pair index) + block: a Gaussian's records are contiguous, and bit i of the
+    // concatenated 16-bit block masks of consecutive pairs addresses record  16 * first_pair + i.  Each lane walks ITS OWN
+    // set bits, four at a time (12 independent 16-byte loads in flight: the kernel is latency bound at ~2.4 waves per SIMD);
+    // a lane that has run out reads record 0 (one shared, cached line) and discards it.  Ascending bit order = fixed
+    // summation order -> deterministic.  10 (mapping) / 7 (tracking) floats per record.
+    auto drain = [&](unsigned long long M, size_t rec0) {
+      while (__ballot(M != 0ull) != 0ull) {
+        float4 a[4], b[4], c[4];
+        bool on[4];
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const float4* r = (const float4*)(dsub + ((m >> w) & 1u ? ((size_t)slot * 4 + w) * SPLAT_F : (size_t)0));
-        a[w] = r[0]; b[w] = r[1];
-        if (!TRACK) c[w] = r[2];
-      }
+        for (int u = 0; u < 4; u++) {
+          on[u] = M != 0ull;
+          const int bit = on[u] ? __ffsll((long long)M) - 1 : 0;
+          M &= M - 1ull;
+          const float4* r = (const float4*)(dsub + (on[u] ? (rec0 + (size_t)bit) * SPLAT_F : (size_t)0));
+          a[u] = r[0]; b[u] = r[1];
+          if (!TRACK) c[u] = r[2];
+        }
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const bool on = (m >> w) & 1u;
-        acc0.x += on ? a[w].x : 0.f; acc0.y += on ? a[w].y : 0.f; acc0.z += on ? a[w].z : 0.f; acc0.w += on ? a[w].w : 0.f;
-        acc1.x += on ? b[w].x : 0.f; acc1.y += on ? b[w].y : 0.f; acc1.z += on ? b[w].z : 0.f; acc1.w += on ? b[w].w : 0.f;
-        if (!TRACK) {
-          acc2.x += on ? c[w].x : 0.f; acc2.y += on ? c[w].y : 0.f; acc2.z += on ? c[w].z : 0.f; acc2.w += on ? c[w].w : 0.f;
+        for (int u = 0; u < 4; u++) {
+          acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
+          acc1.x += on[u] ? b[u].x : 0.f; acc1.y += on[u] ? b[u].y : 0.f; acc1.z += on[u] ? b[u].z : 0.f; acc1.w += on[u] ? b[u].w : 0.f;
+          if (!TRACK) {
+            acc2.x += on[u] ? c[u].x : 0.f; acc2.y += on[u] ? c[u].y : 0.f; acc2.z += on[u] ? c[u].z : 0.f; acc2.w += on[u] ? c[u].w : 0.f;
+          }
         }
       }
     };
-    auto mask_of = [&](uint32_t gi, bool have) -> uint32_t { return (have && gi < N_cap) ? (uint32_t)bn.submask[gi] : 0u; };
+    auto mask_of = [&](uint32_t gi, bool have) -> unsigned long long { return (have && gi < N_cap) ? (unsigned long long)bn.submask[gi] : 0ull; };
     if (area <= 32) {
-      // the first four pairs cover almost every SLAM splat: their mask bytes are fetched together, ahead of the records
-      uint32_t mk[4];
+      // four pairs (64 mask bits) per round; the first round covers almost every SLAM splat
+      for (int k0 = 0; __ballot(k0 < area) != 0ull; k0 += 4) {
+        unsigned long long M = 0ull;
 #pragma unroll
-      for (int k = 0; k < 4; k++) mk[k] = mask_of(goff + (uint32_t)k, k < area);
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (__ballot(mk[k] != 0u) != 0ull) add_pair(goff + (uint32_t)k, mk[k]);
-      for (int k = 4; k < area; k++) {
-        const uint32_t m = mask_of(goff + (uint32_t)k, true);
-        if (m) add_pair(goff + (uint32_t)k, m);
+        for (int k = 0; k < 4; k++) M |= mask_of(goff + (uint32_t)(k0 + k), k0 + k < area) << (16 * k);
+        drain(M, (size_t)(goff + (uint32_t)k0) * NLIST);
       }
     }
     unsigned long long big = __ballot(area > 32);
@@ -247,9 +250,9 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
       const float4 k0 = acc0, k1 = acc1, k2 = acc2;
       acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
-      for (int k = lane; k < sarea; k += 64) {
-        const uint32_t m = mask_of(sgoff + (uint32_t)k, true);
-        if (m) add_pair(sgoff + (uint32_t)k, m);
+      for (int kb = 0; kb < sarea; kb += 64) {     // wave-uniform trip count (drain votes across the wave)
+        const int k = kb + lane;
+        drain(mask_of(sgoff + (uint32_t)k, k < sarea), (size_t)(sgoff + (uint32_t)k) * NLIST);
       }
       float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
 #pragma unroll

@@ -3,14 +3,18 @@
 //   geom_state   : Splat[P] (48 B packed AoS record, gathered by id in the compositor) | depth[P] | rect[P] (2x u32)
 //                  | clamped[P] (u8, SH clamp bits) | tileoff[P] (u32, workgroup-local exclusive scan of tiles touched)
 //                  | block_tiles[ceil(P/256)+1] (u32, tiles touched per preprocess workgroup -> exclusive prefix)
-//   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | subcount[4T] | final_T[H*W] | n_contrib[H*W]
-//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | sublist[4*N_cap] (uint2
-//                  {id, pair}: depth-ordered list of each 8x8 sub-tile; sub-tile w of a tile with bin [start,end) owns
-//                  [4*start + w*len, +subcount); pair = Gaussian-major index of the (Gaussian, tile) pair)
-//                  | submask[N_cap] (u8, indexed by pair: which sub-tiles list it)
-//   bwd scratch  : dsub[4*N_cap] (12 floats, indexed by 4*pair + sub-tile: moments(5) dopacity(1) dcolour(6); one
-//                  record per (sub-tile, splat), written once by the owning wave -- no atomics; a Gaussian's records
-//                  are contiguous) | campartial[ceil(P/256)][32]
+//   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | subcount[16T] | final_T[H*W] | n_contrib[H*W]
+//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | sublist[16*N_cap] (uint2
+//                  {id, pair}: depth-ordered list of each 4x4-pixel block; block L = 4 * (8x8 sub-tile) + (block in the
+//                  sub-tile) of a tile with bin [start,end) owns [16*start + L*len, +subcount[16*tile + L]); pair =
+//                  Gaussian-major index of the (Gaussian, tile) pair) | submask[N_cap] (u16, by pair: which blocks list it)
+//   bwd scratch  : dsub[16*N_cap] (12 floats, indexed by 16*pair + L; one record per (block, splat), written once by the
+//                  owning 16-lane row of a wave -- no atomics; a Gaussian's records are contiguous)
+//                  | campartial[ceil(P/256)][32]
+// A wave composites one 8x8 sub-tile; each of its four 16-lane rows owns a 4x4 block and walks that block's own list, so a
+// wave iteration evaluates up to four different splats (SLAM splats cover ~40 pixels: with one list per sub-tile 85 % of the
+// lanes of an iteration were outside the splat; per-block lists need 0.61x the wave iterations).
+#define NLIST 16
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,7 +60,7 @@ struct ImageView {
   uint32_t* tile_count;  // [T]
   uint32_t* ranges;      // [T+1]
   uint32_t* cursor;      // [T]
-  uint32_t* subcount;    // [4T]
+  uint32_t* subcount;    // [16T]
   float* final_T;        // [H*W]
   uint32_t* n_contrib;   // [H*W]
   size_t zero_bytes;     // hdr + tile_count: cleared at the start of every forward
@@ -65,7 +69,7 @@ static inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
-  return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * 16, 256) +
+  return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +
          align_up(px * 4, 256) + align_up(px * 4, 256);
 }
 static inline ImageView image_view(void* base, int H, int W) {
@@ -77,7 +81,7 @@ static inline ImageView image_view(void* base, int H, int W) {
   v.zero_bytes = (size_t)(c - (char*)base);
   v.ranges = (uint32_t*)c;      c += align_up((T + 1) * 4, 256);
   v.cursor = (uint32_t*)c;      c += align_up(T * 4, 256);
-  v.subcount = (uint32_t*)c;    c += align_up(T * 16, 256);
+  v.subcount = (uint32_t*)c;    c += align_up(T * NLIST * 4, 256);
   v.final_T = (float*)c;        c += align_up(px * 4, 256);
   v.n_contrib = (uint32_t*)c;
   return v;
@@ -85,38 +89,38 @@ static inline ImageView image_view(void* base, int H, int W) {
 
 struct BinView {
   unsigned long long* keys;  // [N_cap]
-  uint2* sublist;            // [4*N_cap]
-  uint8_t* submask;          // [N_cap]
+  uint2* sublist;            // [16*N_cap]
+  uint16_t* submask;         // [N_cap]
 };
 static inline size_t binning_bytes_impl(size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 8, 256) + align_up(N * 32, 256) + align_up(N, 256);
+  return align_up(N * 8, 256) + align_up(N * NLIST * 8, 256) + align_up(N * 2, 256);
 }
 static inline BinView bin_view(void* base, size_t N) {
   if (N < 1) N = 1;
   char* c = (char*)base;
   BinView b;
   b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
-  b.sublist = (uint2*)c;            c += align_up(N * 32, 256);
-  b.submask = (uint8_t*)c;
+  b.sublist = (uint2*)c;            c += align_up(N * NLIST * 8, 256);
+  b.submask = (uint16_t*)c;
   return b;
 }
 
 struct BwdView {
-  float* dsub;        // [4*N_cap][12] per-(sub-tile, splat) screen-space gradient records
+  float* dsub;        // [16*N_cap][12] per-(4x4 block, splat) screen-space gradient records
   float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums
   int nrows;
 };
 static inline int bwd_rows(int P) { return (P + 255) / 256; }
 static inline size_t bwd_bytes_impl(int P, size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 4 * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
+  return align_up(N * NLIST * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
 }
 static inline BwdView bwd_view(void* base, int P, size_t N) {
   if (N < 1) N = 1;
   char* c = (char*)base;
   BwdView b;
-  b.dsub = (float*)c;  c += align_up(N * 4 * SPLAT_F * 4, 256);
+  b.dsub = (float*)c;  c += align_up(N * NLIST * SPLAT_F * 4, 256);
   b.campartial = (float*)c;
   b.nrows = bwd_rows(P);
   return b;

@@ -186,10 +186,9 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       if (gi >= N_cap) return;
       const uint32_t slot = gi;   // records are indexed by the Gaussian-major pair index: contiguous per Gaussian
       const uint32_t m = bn.submask[slot];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
+      for (int w = 0; w < NLIST; w++) {   // one record per 4x4 block that lists the splat
         if (m & (1u << w)) {
-          const float4* r = (const float4*)(dsub + ((size_t)slot * 4 + w) * SPLAT_F);
+          const float4* r = (const float4*)(dsub + ((size_t)slot * NLIST + w) * SPLAT_F);
           const float4 a = r[0], b = r[1], c = r[2];
           acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
           acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;

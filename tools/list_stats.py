@@ -24,17 +24,9 @@ torch.cuda.synchronize()
 T = ((W + 15) // 16) * ((H + 15) // 16)
 al = lambda n: (n + 255) // 256 * 256
 off = 256 + al(T * 4) + al((T + 1) * 4) + al(T * 4)
-raw = eng.img_state.view(torch.uint8)[off:off + 16 * T].cpu().numpy().view(np.uint32)
-sc = raw.astype(np.int64)
-print("sub-tiles", sc.size, "sum", sc.sum(), "mean", sc.mean(), "p50/p90/p99/max", np.percentile(sc, [50, 90, 99]), sc.max())
-for nsimd in (1024,):
-    print("ideal per SIMD", sc.sum() / nsimd, "longest single wave", sc.max(), "-> tail ratio", sc.max() / (sc.sum() / nsimd))
-    # greedy in-order dispatch: next wave goes to the SIMD that frees first (5 slots/SIMD ignored)
-    import heapq
-    for order, name in ((np.arange(sc.size), "in-order"), (np.argsort(-sc), "longest-first")):
-        h = [0] * nsimd; heapq.heapify(h)
-        for i in order: heapq.heappush(h, heapq.heappop(h) + int(sc[i]))
-        print(name, "makespan", max(h))
-    for seg in (32, 64, 128):
-        nseg = np.ceil(sc / seg).sum()
-        print("segments of", seg, ":", int(nseg), "waves")
+raw = eng.img_state.view(torch.uint8)[off:off + 64 * T].cpu().numpy().view(np.uint32)
+sc = raw.astype(np.int64).reshape(T * 4, 4)          # [sub-tile (= wave)][4x4 block (= 16-lane row)]
+it = sc.max(1)                                        # wave iterations = longest of its four block lists
+print("block lists", sc.size, "entries", sc.sum(), "mean", sc.mean(), "p50/p90/p99/max", np.percentile(sc, [50, 90, 99]), sc.max())
+print("waves", it.size, "iterations", it.sum(), "mean", it.mean(), "max", it.max(), " row occupancy", sc.sum() / (4 * it.sum()))
+print("ideal iterations per SIMD", it.sum() / 1024)
