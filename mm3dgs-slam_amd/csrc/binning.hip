@@ -63,6 +63,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
   // tiles touched per preprocess workgroup -> exclusive prefix (start of each workgroup's span in gslot)
   uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
   if (threadIdx.x == 0) g.block_tiles[nblocks] = tot2;
+  __syncthreads();
+  // 4x4 blocks per preprocess workgroup -> exclusive prefix (first gradient record of each workgroup's splats)
+  uint32_t tot3 = block_excl_scan(g.block_blk, g.block_blk, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
+  if (threadIdx.x == 0) g.block_blk[nblocks] = tot3;
 }
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s) {
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, (P + 255) / 256, g, iv);
@@ -194,6 +198,11 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
     const uint32_t tot2 = block256_excl_scan_inplace(g.block_tiles, nblocks_pre, wave_tot, nullptr);
     if (tid == 0) g.block_tiles[nblocks_pre] = tot2;
   }
+  if (blockIdx.x == (gridDim.x > 2 ? 2 : 0)) {
+    __syncthreads();
+    const uint32_t tot3 = block256_excl_scan_inplace(g.block_blk, nblocks_pre, wave_tot, nullptr);
+    if (tid == 0) g.block_blk[nblocks_pre] = tot3;
+  }
   if (r1 == r0) dbits = 0;   // culled: depth[] was not written this frame
   const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
   const int w = maxx - minx, h = maxy - miny;
@@ -296,7 +305,8 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
   for (int base = 0; base < len; base += 256) {
     const int i = base + tid;
     const bool have = i < len;
-    uint32_t id = 0, pidx = 0, mask = 0;
+    uint32_t id = 0, pidx = 0, mask = 0, rec0 = 0;
+    BlkRect br = {0, 0, 0, 0};
     if (have) {
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
       const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
@@ -337,11 +347,19 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
       } else {
         mask = 0xffffu;  // degenerate conic: no culling, the exact per-pixel rule decides
       }
-      // pair index of (Gaussian, tile) in Gaussian-major order: the backward records of one Gaussian are contiguous
+      // pair index of (Gaussian, tile) in Gaussian-major order (-> submask), and the splat's first gradient record
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
       pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
-      if (pidx < N_cap) b.submask[pidx] = (uint16_t)mask;
+      br = block_rect(A, B, r0, r1);
+      rec0 = g.block_blk[id >> 8] + g.blkoff[id];
+      // blocks outside the block rectangle cannot be listed (it bounds the same region with slack); belt and braces
+#pragma unroll
+      for (int L = 0; L < NLIST; L++) {
+        const int bx = ttx * 4 + ((L >> 2) & 1) * 2 + (L & 1) - br.bx0, by = tty * 4 + (L >> 3) * 2 + ((L >> 1) & 1) - br.by0;
+        if (bx < 0 || by < 0 || bx >= br.bw || by >= br.bh) mask &= ~(1u << L);
+      }
+      if (pidx < N_cap && (size_t)rec0 + (size_t)br.bw * br.bh <= (size_t)NLIST * N_cap) b.submask[pidx] = (uint16_t)mask;
       else mask = 0;   // only on capacity overflow (flagged in the header)
     }
     unsigned long long bal[NLIST];
@@ -363,10 +381,14 @@ sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, ui
     __syncthreads();
     if (mask) {
       const unsigned long long lt = (1ull << lane) - 1ull;
-      const uint2 ent = make_uint2(id, pidx);
+      // entry = {splat id, gradient record of (splat, block)}: row-major position of the block in the splat's rectangle
+      const uint32_t recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
 #pragma unroll
       for (int L = 0; L < NLIST; L++)
-        if ((mask >> L) & 1u) sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = ent;
+        if ((mask >> L) & 1u) {
+          const uint32_t rec = recT + (uint32_t)(((L >> 3) * 2 + ((L >> 1) & 1)) * br.bw + ((L >> 2) & 1) * 2 + (L & 1));
+          sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = make_uint2(id, rec);
+        }
     }
     __syncthreads();
     if (tid < NLIST) run[tid] = pre[3][tid] + wcnt[3][tid];

@@ -360,7 +360,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + q; e < count; e += 16) {
-    float4* r = (float4*)(dsub + ((size_t)list[e].y * NLIST + L) * SPLAT_F);
+    float4* r = (float4*)(dsub + (size_t)list[e].y * SPLAT_F);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int f = 0; f < NF4; f++) r[f] = z;
@@ -370,8 +370,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : SepReduce<MODE == 1>::slot(q);
   float ym_0 = 0.f, ym_1a = 0.f, ym_1b = 0.f;
   if (MODE != 0) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
-  // this lane's component of this block's record of pair 0; the record of pair p is NLIST * 48 B further per p
-  float* const my_rec = dsub + (size_t)L * SPLAT_F + (my_slot >= 0 ? my_slot : 0);
+  // this lane's component of record 0; the list entries carry the record index of their (splat, block)
+  float* const my_rec = dsub + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
 
   // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
@@ -448,7 +448,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
-      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * (NLIST * SPLAT_F)] = tot;
+      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * SPLAT_F] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies

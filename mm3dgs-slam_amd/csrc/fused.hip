@@ -84,7 +84,7 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
     for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
   }
   int32_t rad = 0;
-  uint32_t r0 = 0, r1 = 0;
+  uint32_t r0 = 0, r1 = 0, nblk = 0;
   if (live && p[2] > 0.2f) {
     float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
     float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
@@ -117,8 +117,11 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
         const float z = p[2];
         const float op = 1.f / (1.f + __expf(-op_raw));
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
-        sp[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
-        sp[1] = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
+        const float4 sA = make_float4(px, py, e.c * dinv, -e.b * dinv), sB = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
+        sp[0] = sA;
+        sp[1] = sB;
+        const BlkRect br = block_rect(sA, sB, r0, r1);
+        nblk = (uint32_t)(br.bw * br.bh);
         sp[2] = make_float4(fmaxf(c2, 0.f), z, 1.f, z * z);
         g.depth[idx] = z;
       }
@@ -135,18 +138,19 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
     {
       __shared__ uint32_t wtot[FB / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-      uint32_t x = (uint32_t)area;
+      __shared__ uint32_t wtot2[FB / 64];
+      uint32_t x = (uint32_t)area, x2 = nblk;   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off, 64);
-        if (ln >= off) x += y;
+        uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
+        if (ln >= off) { x += y; x2 += y2; }
       }
-      if (ln == 63) wtot[wvi] = x;
+      if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
       __syncthreads();
-      uint32_t pre = 0;
-      for (int q = 0; q < wvi; q++) pre += wtot[q];
-      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
-      if (threadIdx.x == FB - 1) g.block_tiles[blockIdx.x] = pre + x;
+      uint32_t pre = 0, pre2 = 0;
+      for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
+      if (live) { g.tileoff[idx] = pre + x - (uint32_t)area; g.blkoff[idx] = pre2 + x2 - nblk; }
+      if (threadIdx.x == FB - 1) { g.block_tiles[blockIdx.x] = pre + x; g.block_blk[blockIdx.x] = pre2 + x2; }
     }
     uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
     const int lane = threadIdx.x & 63;
@@ -203,26 +207,42 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
     }
-    // Records are indexed by 16 * (Gaussian-major pair index) + block: a Gaussian's records are contiguous, and bit i of the
-    // concatenated 16-bit block masks of consecutive pairs addresses record  16 * first_pair + i.  Each lane walks ITS OWN
-    // set bits, four at a time (12 independent 16-byte loads in flight: the kernel is latency bound at ~2.4 waves per SIMD);
-    // a lane that has run out reads record 0 (one shared, cached line) and discards it.  Ascending bit order = fixed
-    // summation order -> deterministic.  10 (mapping) / 7 (tracking) floats per record.
-    auto drain = [&](unsigned long long M, size_t rec0) {
+    // Gradient records: one per (splat, 4x4 block), dense and contiguous per Gaussian (row-major over its block rectangle,
+    // mm3dgs_common.h).  Validity comes from the 16-bit block masks of its (Gaussian, tile) pairs: each lane walks ITS OWN
+    // set bits, eight at a time (up to 24 independent 16-byte loads in flight: the kernel is latency bound at ~2.4 waves
+    // per SIMD); a lane that has run out reads record 0 (one shared, cached line) and discards it.  Ascending bit order =
+    // fixed summation order -> deterministic.  10 (mapping) / 7 (tracking) floats per record.
+    BlkRect br = {0, 0, 0, 0};
+    uint32_t rec0 = 0;
+    int tminx = 0, tminy = 0, tw = 1;
+    if (rad > 0) {
+      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
+      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+      br = block_rect(spl[0], spl[1], r0, r1);
+      rec0 = g.block_blk[idx >> 8] + g.blkoff[idx];
+      tminx = r0 & 0xffff; tminy = r0 >> 16; tw = max((int)(r1 & 0xffff) - tminx, 1);
+    }
+    // M: block masks of up to four pairs; (ox[p], oy[p]) = block coordinates of pair p's tile relative to the block rectangle
+    auto drain = [&](unsigned long long M, const int (&ox)[4], const int (&oy)[4], int bw, uint32_t base) {
+      constexpr int UB = 8;   // records in flight per lane
       while (__ballot(M != 0ull) != 0ull) {
-        float4 a[4], b[4], c[4];
-        bool on[4];
+        float4 a[UB], b[UB], c[UB];
+        bool on[UB];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UB; u++) {
           on[u] = M != 0ull;
           const int bit = on[u] ? __ffsll((long long)M) - 1 : 0;
           M &= M - 1ull;
-          const float4* r = (const float4*)(dsub + (on[u] ? (rec0 + (size_t)bit) * SPLAT_F : (size_t)0));
+          const int pq = bit >> 4, Lb = bit & 15;
+          const int oxp = pq == 0 ? ox[0] : (pq == 1 ? ox[1] : (pq == 2 ? ox[2] : ox[3]));
+          const int oyp = pq == 0 ? oy[0] : (pq == 1 ? oy[1] : (pq == 2 ? oy[2] : oy[3]));
+          const int bx = oxp + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oyp + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
+          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * SPLAT_F : (size_t)0));
           a[u] = r[0]; b[u] = r[1];
           if (!TRACK) c[u] = r[2];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UB; u++) {
           acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
           acc1.x += on[u] ? b[u].x : 0.f; acc1.y += on[u] ? b[u].y : 0.f; acc1.z += on[u] ? b[u].z : 0.f; acc1.w += on[u] ? b[u].w : 0.f;
           if (!TRACK) {
@@ -234,11 +254,17 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     auto mask_of = [&](uint32_t gi, bool have) -> unsigned long long { return (have && gi < N_cap) ? (unsigned long long)bn.submask[gi] : 0ull; };
     if (area <= 32) {
       // four pairs (64 mask bits) per round; the first round covers almost every SLAM splat
+      int tx = 0, ty = 0;   // tile of pair k0 inside the splat's tile rectangle (row-major, width tw)
       for (int k0 = 0; __ballot(k0 < area) != 0ull; k0 += 4) {
         unsigned long long M = 0ull;
+        int ox[4], oy[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) M |= mask_of(goff + (uint32_t)(k0 + k), k0 + k < area) << (16 * k);
-        drain(M, (size_t)(goff + (uint32_t)k0) * NLIST);
+        for (int k = 0; k < 4; k++) {
+          M |= mask_of(goff + (uint32_t)(k0 + k), k0 + k < area) << (16 * k);
+          ox[k] = (tminx + tx) * 4 - br.bx0; oy[k] = (tminy + ty) * 4 - br.by0;
+          if (++tx == tw) { tx = 0; ty++; }
+        }
+        drain(M, ox, oy, br.bw, rec0);
       }
     }
     unsigned long long big = __ballot(area > 32);
@@ -250,9 +276,16 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
       const float4 k0 = acc0, k1 = acc1, k2 = acc2;
       acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
+      // the whole wave sums the big splat `src`: its rectangle / record base are broadcast, lane l takes pairs l, l + 64, ...
+      BlkRect sq;
+      sq.bx0 = __builtin_amdgcn_readlane(br.bx0, src); sq.by0 = __builtin_amdgcn_readlane(br.by0, src);
+      sq.bw = __builtin_amdgcn_readlane(br.bw, src); sq.bh = __builtin_amdgcn_readlane(br.bh, src);
+      const uint32_t srec0 = __builtin_amdgcn_readlane(rec0, src);
+      const int smnx = __builtin_amdgcn_readlane(tminx, src), smny = __builtin_amdgcn_readlane(tminy, src), stw = __builtin_amdgcn_readlane(tw, src);
       for (int kb = 0; kb < sarea; kb += 64) {     // wave-uniform trip count (drain votes across the wave)
-        const int k = kb + lane;
-        drain(mask_of(sgoff + (uint32_t)k, k < sarea), (size_t)(sgoff + (uint32_t)k) * NLIST);
+        const int k = kb + lane, kty = k / stw, ktx = k - kty * stw;
+        const int ox[4] = {(smnx + ktx) * 4 - sq.bx0, 0, 0, 0}, oy[4] = {(smny + kty) * 4 - sq.by0, 0, 0, 0};
+        drain(mask_of(sgoff + (uint32_t)k, k < sarea), ox, oy, sq.bw, srec0);
       }
       float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
 #pragma unroll

@@ -8,8 +8,11 @@
 //                  {id, pair}: depth-ordered list of each 4x4-pixel block; block L = 4 * (8x8 sub-tile) + (block in the
 //                  sub-tile) of a tile with bin [start,end) owns [16*start + L*len, +subcount[16*tile + L]); pair =
 //                  Gaussian-major index of the (Gaussian, tile) pair) | submask[N_cap] (u16, by pair: which blocks list it)
-//   bwd scratch  : dsub[16*N_cap] (12 floats, indexed by 16*pair + L; one record per (block, splat), written once by the
-//                  owning 16-lane row of a wave -- no atomics; a Gaussian's records are contiguous)
+//   bwd scratch  : dsub[16*N_cap] (12 floats; one record per (block, splat), written once by the owning 16-lane row of a
+//                  wave -- no atomics).  A Gaussian's records are contiguous AND dense: record index = first record of the
+//                  Gaussian (block_blk[id>>8] + blkoff[id]) + row-major position of the block inside the splat's block
+//                  rectangle (block_rect()), so the consumer's gather touches ~1.1x the useful bytes (2.3x with 16 slots
+//                  per pair).  The list entries carry the record index.
 //                  | campartial[ceil(P/256)][32]
 // A wave composites one 8x8 sub-tile; each of its four 16-lane rows owns a 4x4 block and walks that block's own list, so a
 // wave iteration evaluates up to four different splats (SLAM splats cover ~40 pixels: with one list per sub-tile 85 % of the
@@ -36,11 +39,13 @@ struct GeomView {
   uint8_t* clamped;   // [P]
   uint32_t* tileoff;  // [P]
   uint32_t* block_tiles;  // [ceil(P/256)+1]
+  uint32_t* blkoff;   // [P]  workgroup-local exclusive scan of the 4x4 blocks in each splat's block rectangle
+  uint32_t* block_blk;    // [ceil(P/256)+1]  blocks per preprocess workgroup -> exclusive prefix
 };
 static inline size_t geom_bytes_impl(int P) {
   size_t p = (size_t)P;
   return align_up(p * SPLAT_F * 4, 256) + align_up(p * 4, 256) + align_up(p * 8, 256) + align_up(p, 256) +
-         align_up(p * 4, 256) + align_up(((p + 255) / 256 + 1) * 4, 256);
+         2 * (align_up(p * 4, 256) + align_up(((p + 255) / 256 + 1) * 4, 256));
 }
 static inline GeomView geom_view(void* base, int P) {
   size_t p = (size_t)P;
@@ -51,7 +56,9 @@ static inline GeomView geom_view(void* base, int P) {
   g.rect = (uint32_t*)c;    c += align_up(p * 8, 256);
   g.clamped = (uint8_t*)c;  c += align_up(p, 256);
   g.tileoff = (uint32_t*)c; c += align_up(p * 4, 256);
-  g.block_tiles = (uint32_t*)c;
+  g.block_tiles = (uint32_t*)c; c += align_up(((p + 255) / 256 + 1) * 4, 256);
+  g.blkoff = (uint32_t*)c;  c += align_up(p * 4, 256);
+  g.block_blk = (uint32_t*)c;
   return g;
 }
 
@@ -124,6 +131,30 @@ static inline BwdView bwd_view(void* base, int P, size_t N) {
   b.campartial = (float*)c;
   b.nrows = bwd_rows(P);
   return b;
+}
+
+// Block rectangle of a splat: the 4x4-pixel blocks (global block coordinates) that its { alpha >= 1/255 } bound can reach,
+// clipped to its tile rectangle.  A superset of the blocks sort_tiles_kernel lists (same bound, 0.01 px of slack against
+// the different rounding of tile-relative arithmetic).  Used by the projection kernels (size), the sort (record index
+// of every list entry) and the backward projection (gather).  A, B = first 32 bytes of the splat record.
+struct BlkRect { int bx0, by0, bw, bh; };
+__device__ __forceinline__ BlkRect block_rect(const float4 A, const float4 B, uint32_t r0, uint32_t r1) {
+  const int X0 = (int)(r0 & 0xffff) * 4, Y0 = (int)(r0 >> 16) * 4, X1 = (int)(r1 & 0xffff) * 4, Y1 = (int)(r1 >> 16) * 4;
+  BlkRect q;
+  q.bx0 = X0; q.by0 = Y0; q.bw = X1 - X0; q.bh = Y1 - Y0;
+  if (q.bw <= 0 || q.bh <= 0) { q.bw = 0; q.bh = 0; return q; }
+  const float tau = __logf(255.f * B.y);
+  const float det = A.z * B.x - A.w * A.w;
+  if (!(det > 0.f)) return q;                      // degenerate conic: no culling
+  if (!(tau > 0.f)) { q.bw = 0; q.bh = 0; return q; }
+  const float k = 2.f * tau / det;
+  const float hx = sqrtf(k * B.x) * 1.0002f + 0.012f, hy = sqrtf(k * A.z) * 1.0002f + 0.012f;
+  // block b covers pixel centres [4b, 4b+3]:  overlap  <=>  c - h <= 4b + 3  and  c + h >= 4b
+  const int bx0 = max(X0, (int)ceilf((A.x - hx - 3.f) * 0.25f)), bx1 = min(X1 - 1, (int)floorf((A.x + hx) * 0.25f));
+  const int by0 = max(Y0, (int)ceilf((A.y - hy - 3.f) * 0.25f)), by1 = min(Y1 - 1, (int)floorf((A.y + hy) * 0.25f));
+  q.bx0 = bx0; q.by0 = by0; q.bw = max(bx1 - bx0 + 1, 0); q.bh = max(by1 - by0 + 1, 0);
+  if (q.bw == 0 || q.bh == 0) { q.bw = 0; q.bh = 0; }
+  return q;
 }
 
 // Camera constants copied by value into kernel arguments (matrices stay device pointers: they are torch

@@ -32,7 +32,7 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   if (live) { p[0] = means3D[(size_t)idx * 3]; p[1] = means3D[(size_t)idx * 3 + 1]; p[2] = means3D[(size_t)idx * 3 + 2]; }
   float tz = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
   int32_t rad = 0;
-  uint32_t r0 = 0, r1 = 0;
+  uint32_t r0 = 0, r1 = 0, nblk = 0;
   if (live && tz > 0.2f) {
     float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
     float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
@@ -81,9 +81,12 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           for (int k = 0; k < ne; k++) col[nsh + k] = colors[(size_t)idx * ne + k];
         }
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
-        sp[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
-        sp[1] = make_float4(e.a * dinv, opac[idx], col[0], col[1]);
+        const float4 sA = make_float4(px, py, e.c * dinv, -e.b * dinv), sB = make_float4(e.a * dinv, opac[idx], col[0], col[1]);
+        sp[0] = sA;
+        sp[1] = sB;
         sp[2] = make_float4(col[2], col[3], col[4], col[5]);
+        const BlkRect br = block_rect(sA, sB, r0, r1);
+        nblk = (uint32_t)(br.bw * br.bh);
         g.depth[idx] = e.t[2];
       }
     }
@@ -100,18 +103,19 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     {  // workgroup-local exclusive scan of tiles touched (start of this Gaussian's span in gslot)
       __shared__ uint32_t wtot[PP_BLOCK / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-      uint32_t x = (uint32_t)area;
+      __shared__ uint32_t wtot2[PP_BLOCK / 64];
+      uint32_t x = (uint32_t)area, x2 = nblk;   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off, 64);
-        if (ln >= off) x += y;
+        uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
+        if (ln >= off) { x += y; x2 += y2; }
       }
-      if (ln == 63) wtot[wvi] = x;
+      if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
       __syncthreads();
-      uint32_t pre = 0;
-      for (int q = 0; q < wvi; q++) pre += wtot[q];
-      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
-      if (threadIdx.x == PP_BLOCK - 1) g.block_tiles[blockIdx.x] = pre + x;
+      uint32_t pre = 0, pre2 = 0;
+      for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
+      if (live) { g.tileoff[idx] = pre + x - (uint32_t)area; g.blkoff[idx] = pre2 + x2 - nblk; }
+      if (threadIdx.x == PP_BLOCK - 1) { g.block_tiles[blockIdx.x] = pre + x; g.block_blk[blockIdx.x] = pre2 + x2; }
     }
     uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
     const int lane = threadIdx.x & 63;
@@ -182,13 +186,29 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
     }
-    auto add_pair = [&](uint32_t gi) {
+    // gradient records: dense and contiguous per Gaussian (row-major over its block rectangle, mm3dgs_common.h); the 16-bit
+    // block mask of each (Gaussian, tile) pair says which blocks of that tile hold one
+    BlkRect br = {0, 0, 0, 0};
+    uint32_t rec0 = 0;
+    int tminx = 0, tminy = 0, tw = 1;
+    if (area > 0) {
+      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
+      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+      br = block_rect(spl[0], spl[1], r0, r1);
+      rec0 = g.block_blk[idx >> 8] + g.blkoff[idx];
+      tminx = r0 & 0xffff; tminy = r0 >> 16; tw = max((int)(r1 & 0xffff) - tminx, 1);
+    }
+    // pair k of a splat with tile rectangle origin (mnx, mny), width w, block rectangle q, first record base
+    auto add_pair = [&](uint32_t gi, int k, const BlkRect& q, uint32_t base, int mnx, int mny, int w) {
       if (gi >= N_cap) return;
-      const uint32_t slot = gi;   // records are indexed by the Gaussian-major pair index: contiguous per Gaussian
-      const uint32_t m = bn.submask[slot];
-      for (int w = 0; w < NLIST; w++) {   // one record per 4x4 block that lists the splat
-        if (m & (1u << w)) {
-          const float4* r = (const float4*)(dsub + ((size_t)slot * NLIST + w) * SPLAT_F);
+      const uint32_t m = bn.submask[gi];
+      if (!m) return;
+      const int ty = k / w, tx = k - ty * w;
+      const int ox = (mnx + tx) * 4 - q.bx0, oy = (mny + ty) * 4 - q.by0;
+      for (int Lb = 0; Lb < NLIST; Lb++) {   // one record per 4x4 block that lists the splat
+        if (m & (1u << Lb)) {
+          const int bx = ox + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oy + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
+          const float4* r = (const float4*)(dsub + (size_t)(base + (uint32_t)(by * q.bw + bx)) * SPLAT_F);
           const float4 a = r[0], b = r[1], c = r[2];
           acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
           acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
@@ -197,7 +217,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       }
     };
     if (area <= 32)
-      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k);
+      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k, k, br, rec0, tminx, tminy, tw);
     unsigned long long big = __ballot(area > 32);
     const int lane = threadIdx.x & 63;
     while (big) {
@@ -207,7 +227,12 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
       const float4 k0 = acc0, k1 = acc1, k2 = acc2;  // keep this lane's own sum
       acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
-      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k);
+      BlkRect sq;
+      sq.bx0 = __builtin_amdgcn_readlane(br.bx0, src); sq.by0 = __builtin_amdgcn_readlane(br.by0, src);
+      sq.bw = __builtin_amdgcn_readlane(br.bw, src); sq.bh = __builtin_amdgcn_readlane(br.bh, src);
+      const uint32_t srec0 = __builtin_amdgcn_readlane(rec0, src);
+      const int smnx = __builtin_amdgcn_readlane(tminx, src), smny = __builtin_amdgcn_readlane(tminy, src), stw = __builtin_amdgcn_readlane(tw, src);
+      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k, k, sq, srec0, smnx, smny, stw);
       float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
 #pragma unroll
       for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
