@@ -205,8 +205,13 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
-  { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s); }
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
+  // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
+  static const int no_fused_sort = env_flag("MM3DGS_NO_FUSED_SORT", 0);
+  const bool fused_sort = cd.sort_single && !no_fused_sort;
+  { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
+    if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s);
+    else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");
 }
 

@@ -17,6 +17,7 @@
 // (sub-tile, splat) record -- stores the 48-byte record with one plain store.  preprocess_bwd later sums a
 // Gaussian's records in a fixed order, which makes the whole backward deterministic.
 #include "mm3dgs_common.h"
+#include "sort_tile.h"
 
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
@@ -49,12 +50,13 @@ __device__ __forceinline__ SplatRec load_rec(const float* __restrict__ splat, ui
   return r;
 }
 
+// Forward compositing of one tile by a 256-lane workgroup.  stg: [buffer][wave][field A|B|C][row * 16 + entry] staging
+// (24 KB of LDS); counts_lds: the sixteen list lengths in LDS when the caller has just produced them (fused kernel), else
+// nullptr (read from image_state).
 template <int C>
-__global__ void __launch_bounds__(256)
-composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out) {
-  const int T = cam.gx * cam.gy;
-  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
-  if (tile >= T) return;
+__device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
+                                                   uint32_t N_cap, float* __restrict__ out, float4 (*stg)[4][3][64],
+                                                   const uint32_t* counts_lds) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
@@ -65,7 +67,7 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
   const uint32_t len = end - start;
   const int L = 4 * wv + row;
-  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
+  const uint32_t count = len ? min(counts_lds ? counts_lds[L] : iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
   uint32_t maxcount = count;
   maxcount = max(maxcount, (uint32_t)__builtin_amdgcn_readlane((int)count, 16));
   maxcount = max(maxcount, (uint32_t)__builtin_amdgcn_readlane((int)count, 32));
@@ -74,9 +76,8 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   maxcount = __builtin_amdgcn_readfirstlane(maxcount);
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
-  // [buffer][wave][field A|B|C][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address register per
-  // splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
-  __shared__ float4 stg[2][4][3][64];
+  // stg = [buffer][wave][field A|B|C][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address register
+  // per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
   constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   float Tr = 1.f;
@@ -152,6 +153,35 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 #pragma unroll
     for (int ch = 0; ch < C; ch++) out[ch * HW + pix] = acc[ch] + (ch < 3 ? Tr * cam.bg[ch] : 0.f);
   }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out) {
+  __shared__ float4 stg[2][4][3][64];
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, stg, nullptr);
+}
+
+// Sort + forward compositing of a tile in ONE launch: both are one-workgroup-per-tile, so the tile's lists go from the
+// sorting phase to the compositing phase of the same workgroup (through global memory -- the backward pass reads them
+// again -- ordered by the barrier).  One launch gap less per render, and the sort phase (memory latency, half-idle VALU)
+// of one workgroup overlaps the compositing phase (VALU bound) of its neighbours on the CU.  The key array and the
+// staging buffers share LDS.  Lists longer than 2048 splats take sort_tile_body's global-memory path (slow, correct).
+template <int C>
+__global__ void __launch_bounds__(256)
+sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean) {
+  __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * 64];   // 24 KB >= 2048 keys (16 KB)
+  __shared__ SortShared sh;
+  static_assert(sizeof(smem) >= 2048 * sizeof(unsigned long long), "LDS union too small for the key array");
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh);
+  __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
+  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run);
 }
 
 // ---- multi-value wave reduction ---------------------------------------------------------------------------------
@@ -500,6 +530,13 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
     hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
   else
     hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+}
+
+void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s) {
+  uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  int T = cam.gx * cam.gy;
+  int grid = ((T + 7) / 8) * 8;
+  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,
