@@ -244,7 +244,7 @@ def main():
         ach = alg_bytes / dur / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                            "frac": ach / 8000.0, "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg_bytes,
-                           "avg_launch_us": dur * 1e6, "launches": n_bwd,
+                           "avg_launch_us": dur * 1e6, "timed_launches": n_bwd,   # every 16th launch of the timed region carries an event pair
                            # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any
                            # early-out, ~25 flop + 1 exp each (SURVEY's figure), against the dense f32 VALU peak.  This
                            # is the ceiling the kernel actually runs into (profiles/r01_sq_counters.md)

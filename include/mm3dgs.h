@@ -172,6 +172,18 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
                       const float* ref_depth_or_null, void* loss_work, float* dL_dout, float* loss4,
                       void* backward_scratch, const Mm3dgsPoseAdam* pose_adam, void* stream);
 
+/* n_iter mapping iterations enqueued back to back from C (the loop of slam/mapper.py:803-950 between two pruning steps):
+ * iteration i renders view i of the window (its pose, colour target, optional reference depth), takes the mapping loss and
+ * the backward pass with the map's Adam step inside (map_adam->step = step number of iteration 0, +1 per iteration);
+ * `stats` (may be NULL): only max_radii2D / grad_accum / denom are used, the densification statistics of
+ * slam/mapper.py:887-899.  `in->pose` is ignored.  No host synchronisation; `views` is read on the host during the call. */
+typedef struct Mm3dgsMapView { const float* pose; const float* gt_color; const float* ref_depth_or_null; } Mm3dgsMapView;
+int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in,
+                    float* out_color, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
+                    size_t N_capacity, int fwd_flags, const struct Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout,
+                    float* loss4, void* backward_scratch, const Mm3dgsSlamGrads* stats, const Mm3dgsMapAdam* map_adam,
+                    void* stream);
+
 /* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:856-873,
  * utils/loss_utils.py): w_l1 * mean|rgb-gt| (optionally over silhouette > sil_thr) + w_ssim * (1 - SSIM 11x11)
  * + w_pearson * (1 - rho(depth, ref)).  loss[4] = {total, l1, 1-ssim, 1-rho}.  work: mm3dgs_loss_work_bytes(). */
@@ -195,7 +207,7 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float bet
 
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
- * launches and their summed duration since the previous read, and resets the counters. */
+ * (timed) launches and their summed duration since the previous read, and resets the counters. */
 #define MM3DGS_PROF_PREPROCESS_FWD 0
 #define MM3DGS_PROF_SCAN 1
 #define MM3DGS_PROF_BIN_SORT 2
@@ -205,7 +217,7 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float bet
 #define MM3DGS_PROF_LOSS 6
 #define MM3DGS_PROF_ADAM 7
 #define MM3DGS_PROF_KERNELS 8
-void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 only the backward compositor */
+void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 16th launch of the backward compositor only */
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 
 const char* mm3dgs_last_error(void);

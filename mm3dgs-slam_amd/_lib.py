@@ -39,6 +39,10 @@ class Mm3dgsMapAdam(C.Structure):
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32)]
 
 
+class Mm3dgsMapView(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("gt_color", C.c_void_p), ("ref_depth_or_null", C.c_void_p)]
+
+
 class Mm3dgsPoseAdam(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_float),
                 ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
@@ -73,6 +77,9 @@ _SIGS = {
                                        C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), C.POINTER(Mm3dgsMapAdam), _P]),
     "mm3dgs_slam_track": (C.c_int, [C.c_int, C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                     C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, C.POINTER(Mm3dgsPoseAdam), _P]),
+    "mm3dgs_slam_map": (C.c_int, [C.c_int, C.POINTER(Mm3dgsMapView), C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P,
+                                  _P, _P, C.c_size_t, C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, C.POINTER(Mm3dgsSlamGrads),
+                                  C.POINTER(Mm3dgsMapAdam), _P]),
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_loss": (C.c_int, [C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, _P]),
     "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),

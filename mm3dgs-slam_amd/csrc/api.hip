@@ -34,8 +34,13 @@ static std::mutex g_prof_mu;
 static int g_prof_on = 0;
 struct ProfScope {
   int k; hipStream_t s; hipEvent_t e1 = nullptr; bool on;
-  // g_prof_on: 0 off, 1 every kernel, 2 only the backward compositor (the roofline kernel: 2 events per iteration)
+  // g_prof_on: 0 off, 1 every kernel, 2 only the backward compositor (the roofline kernel) and only every 16th launch of
+  // it: an event pair around EVERY launch costs ~4 % of the SLAM frame rate (measured), a 1-in-16 sample nothing
   ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && k_ == MM3DGS_PROF_COMPOSITE_BWD)) {
+    if (on && g_prof_on == 2) {
+      static unsigned long long sample = 0;
+      on = (sample++ & 15ull) == 0ull;
+    }
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -300,6 +305,32 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
     rc = mm3dgs_slam_backward(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
                               nullptr, pose_adam, nullptr, stream);
     if (rc) return rc;
+  }
+  return 0;
+}
+
+int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color,
+                    int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags,
+                    const Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout, float* loss4, void* backward_scratch,
+                    const Mm3dgsSlamGrads* stats, const Mm3dgsMapAdam* map_adam, void* stream) {
+  if (n_iter < 0) return fail(-1, "n_iter < 0");
+  if (n_iter > 0 && (!views || !in || !map_adam)) return fail(-1, "NULL argument");
+  Mm3dgsSlamGrads sg;
+  memset(&sg, 0, sizeof(sg));
+  if (stats) { sg.max_radii2D = stats->max_radii2D; sg.grad_accum = stats->grad_accum; sg.denom = stats->denom; }
+  Mm3dgsMapAdam ad = *map_adam;
+  Mm3dgsSlamInputs si = *in;
+  for (int it = 0; it < n_iter; it++) {
+    if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
+    si.pose = views[it].pose;
+    int rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
+    if (rc) return rc;
+    rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
+    if (rc) return rc;
+    rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
+                              nullptr, nullptr, &ad, stream);
+    if (rc) return rc;
+    ad.step++;
   }
   return 0;
 }

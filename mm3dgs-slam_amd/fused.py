@@ -120,6 +120,25 @@ class FusedEngine:
                                               _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
                                               C.byref(pose_adam), _stream()))
 
+    def map_loop(self, views, g, lcfg, stats, map_adam):
+        """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...]."""
+        P = int(g._xyz.shape[0])
+        self._ensure(P, True)
+        si = self.inputs(views[0][0], g)
+        arr = (_lib.Mm3dgsMapView * len(views))()
+        for i, (pose, gt_color, ref) in enumerate(views):
+            arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
+        sg = None
+        if stats is not None:
+            sg = _lib.Mm3dgsSlamGrads()
+            sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
+        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)
+        self._views_keepalive = views      # the device work is asynchronous
+        _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
+                                            _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
+                                            _p(self.dL), _p(self.loss), _p(self.scratch), C.byref(sg) if sg is not None else None,
+                                            C.byref(map_adam), _stream()))
+
     def check_capacity(self):
         """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
         h = self.img_state[:16].view(torch.int32).cpu()
@@ -211,27 +230,49 @@ class FusedMapper(Mapper):
             pmask = 0 if not self.cfg["use_gt_depth"] else 2
         lcfg = _loss_cfg(eng.H, eng.W, 1.0 - lam, lam, w_p, 0, pmask, 0, 0.5)
         stack = None
+
+        def pop():
+            nonlocal stack
+            if not stack:
+                stack = list(keyframe_idx_list)
+            return stack.pop(randint(0, len(stack) - 1))
+
+        def view_of(k):
+            if k == -1:
+                pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
+            else:
+                kf = self.keyframes[k]
+                pose, gt_color, gt_depth, est_depth = kf.pose, kf.gt_color, kf.gt_depth, kf.est_depth
+            ref = None
+            if w_p:
+                ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
+            return pose.detach().float().contiguous(), gt_color.contiguous(), ref
+
+        def prune_at(it):
+            return it <= m["densify_until_iter"] and it >= m["densify_from_iter"] and it % m["pruning_interval"] == 0
+
         with torch.no_grad():
-            for iteration in range(num_iter):
-                def pop():
-                    nonlocal stack
-                    if not stack:
-                        stack = list(keyframe_idx_list)
-                    return stack.pop(randint(0, len(stack) - 1))
-                k = self.window.take(pop) if self.window is not None else pop()
-                if k == -1:
-                    pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
-                else:
-                    kf = self.keyframes[k]
-                    pose, gt_color, gt_depth, est_depth = kf.pose, kf.gt_color, kf.gt_depth, kf.est_depth
-                ref = None
-                if w_p:
-                    ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
-                pose = pose.detach().float().contiguous()
-                si = eng.forward(pose, g, need_grads=True)
-                eng.loss_call(lcfg, gt_color.contiguous(), ref)
+            multi = self.window is not None and self.window.world > 1
+            iteration = 0
+            while iteration < num_iter:
                 densify = iteration <= m["densify_until_iter"]
-                if self.window is not None and self.window.world > 1:
+                if not multi and not prune_at(iteration):
+                    # single GPU: the run of iterations up to the next pruning step (or the end of the densification phase)
+                    # is enqueued by ONE C call -- no Python between the ~9 launches of an iteration
+                    n = 1
+                    while (iteration + n < num_iter and not prune_at(iteration + n)
+                           and (iteration + n <= m["densify_until_iter"]) == densify):
+                        n += 1
+                    views = [view_of(pop()) for _ in range(n)]
+                    stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
+                    eng.map_loop(views, g, lcfg, stats, self._inline_adam(n))
+                    iteration += n
+                    continue
+                k = self.window.take(pop) if self.window is not None else pop()
+                pose, gt_color, ref = view_of(k)
+                si = eng.forward(pose, g, need_grads=True)
+                eng.loss_call(lcfg, gt_color, ref)
+                if multi:
                     # each rank rendered a different keyframe: sum gradients and statistics over the window
                     eng.stat_delta[0].zero_(); eng.stat_delta[1].zero_(); eng.stat_delta[2].zero_()
                     eng.backward(si, grads=eng.grads, stats=eng.stat_delta if densify else None)
@@ -240,22 +281,24 @@ class FusedMapper(Mapper):
                         g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
                         g.xyz_gradient_accum += eng.stat_delta[1]
                         g.denom += eng.stat_delta[2]
-                    prune_now = densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0
+                    prune_now = prune_at(iteration)
                     if not prune_now:
                         self._adam_step(eng)
                 else:
-                    # single GPU: the Adam step rides inside the backward projection kernel (no gradient round trip)
-                    prune_now = densify and iteration >= m["densify_from_iter"] and iteration % m["pruning_interval"] == 0
+                    # a pruning iteration: gradients + statistics only (the reference prunes BEFORE optimizer.step(): the
+                    # parameters are replaced, so that step is a no-op)
+                    prune_now = True
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
-                    eng.backward(si, grads=eng.grads if prune_now else None, stats=stats, map_adam=None if prune_now else self._inline_adam())
+                    eng.backward(si, grads=eng.grads, stats=stats)
                 if prune_now:
-                    # the reference prunes BEFORE optimizer.step(): parameters are replaced, so that step is a no-op
                     g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                iteration += 1
             eng.check_capacity()
         self.mapping_iter_count += num_iter
 
-    def _inline_adam(self):
-        """Mm3dgsMapAdam over the optimiser's own state tensors (created like torch.optim.Adam would on its first step)."""
+    def _inline_adam(self, n=1):
+        """Mm3dgsMapAdam over the optimiser's own state tensors (created like torch.optim.Adam would on its first step);
+        `step` = step number of the first of the n iterations it will serve (the optimiser's counters advance by n)."""
         opt = self.gaussians.optimizer
         ma = _lib.Mm3dgsMapAdam()
         step_val = None
@@ -267,8 +310,9 @@ class FusedMapper(Mapper):
                 st["step"] = torch.tensor(0.0)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
-            step_val = int(st["step"].item()) if step_val is None else step_val
+            first = int(st["step"].item()) + 1
+            st["step"] += n
+            step_val = first if step_val is None else step_val
             ma.param[i], ma.exp_avg[i], ma.exp_avg_sq[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             ma.lr[i] = float(group["lr"])
         b1, b2 = opt.param_groups[0]["betas"]
