@@ -473,8 +473,23 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
   // added in a fixed order (deterministic, double precision)
   __shared__ double part[64][16];
+  __shared__ double part8[8][16];
   __shared__ double tot[NPOSE];
   const int k = threadIdx.x;
+  // lane 0's pose / Adam state: requested first, lands while the rows are summed (this kernel is pure latency)
+  float pin[4] = {1.f, 0.f, 0.f, 0.f}, pcur[7], am[7], av[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) { pcur[i] = 0.f; am[i] = 0.f; av[i] = 0.f; }
+  int step0 = 0;
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) pin[i] = pose_in[i];    // the quaternion the render used (chain rule)
+    if (ad.pose) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) { pcur[i] = ad.pose[i]; am[i] = ad.m[i]; av[i] = ad.v[i]; }
+      step0 = *ad.step;
+    }
+  }
   {
     const int col = k & 15, grp = k >> 4;
     double a0 = 0.0, a1 = 0.0;
@@ -486,14 +501,23 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     part[grp][col] = a0 + a1;
   }
   __syncthreads();
+  // 64 row groups -> 8 -> 1 in a fixed order (a 64-step serial sum of dependent LDS reads cost ~2 us of pure latency)
+  if ((k >> 4) < 8) {
+    double acc = 0.0;
+#pragma unroll
+    for (int gq = 0; gq < 8; gq++) acc += part[(k >> 4) * 8 + gq][k & 15];
+    part8[k >> 4][k & 15] = acc;
+  }
+  __syncthreads();
   if (k < NPOSE) {
     double acc = 0.0;
-    for (int gq = 0; gq < 64; gq++) acc += part[gq][k];
+#pragma unroll
+    for (int gq = 0; gq < 8; gq++) acc += part8[gq][k];
     tot[k] = acc;
   }
   __syncthreads();
   if (k == 0) {
-    const float w0 = pose_in[0], x0 = pose_in[1], y0 = pose_in[2], z0 = pose_in[3];
+    const float w0 = pin[0], x0 = pin[1], y0 = pin[2], z0 = pin[3];
     const float n = sqrtf(w0 * w0 + x0 * x0 + y0 * y0 + z0 * z0), inv = 1.f / n;
     const float r = w0 * inv, x = x0 * inv, y = y0 * inv, z = z0 * inv;
     float dR[3][3];
@@ -514,17 +538,18 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     for (int i = 0; i < 3; i++) grad[4 + i] = (float)tot[9 + i];
     if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
     if (ad.pose) {
-      const int t = ++(*ad.step);
+      const int t = step0 + 1;
+      *ad.step = t;
       const float bc1 = 1.f - powf(ad.beta1, (float)t), bc2 = 1.f - powf(ad.beta2, (float)t);
       const float bc2s = sqrtf(bc2);
       for (int i = 0; i < 7; i++) {
         const float lr = i < 4 ? ad.lr_q : ad.lr_t;
         const float gi = grad[i];
-        const float mi = ad.m[i] + (gi - ad.m[i]) * (1.f - ad.beta1);      // lerp, as torch does
-        const float vi = ad.v[i] * ad.beta2 + gi * gi * (1.f - ad.beta2);
+        const float mi = am[i] + (gi - am[i]) * (1.f - ad.beta1);      // lerp, as torch does
+        const float vi = av[i] * ad.beta2 + gi * gi * (1.f - ad.beta2);
         ad.m[i] = mi; ad.v[i] = vi;
         const float denom = sqrtf(vi) / bc2s + ad.eps;
-        ad.pose[i] -= (lr / bc1) * (mi / denom);
+        ad.pose[i] = pcur[i] - (lr / bc1) * (mi / denom);
       }
     }
   }

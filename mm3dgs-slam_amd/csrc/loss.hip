@@ -171,6 +171,7 @@ __device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, d
 __global__ void __launch_bounds__(1024) loss_finish_kernel(const double* __restrict__ partial, int nrows, double* __restrict__ sums,
                                                            int pearson_on, int pearson_invert) {
   __shared__ double part[64][16];
+  __shared__ double part8[8][16];
   __shared__ double tot[16];
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
   double a0 = 0.0, a1 = 0.0;
@@ -181,9 +182,18 @@ __global__ void __launch_bounds__(1024) loss_finish_kernel(const double* __restr
   }
   part[grp][col] = a0 + a1;
   __syncthreads();
+  // 64 row groups -> 8 -> 1 in a fixed order (a 64-step serial sum of dependent LDS reads cost ~2 us of pure latency)
+  if (grp < 8) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) t += part[grp * 8 + q][col];
+    part8[grp][col] = t;
+  }
+  __syncthreads();
   if (threadIdx.x < 16) {
     double t = 0.0;
-    for (int q = 0; q < 64; q++) t += part[q][threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < 8; q++) t += part8[q][threadIdx.x];
     sums[threadIdx.x] = t;
     tot[threadIdx.x] = t;
   }
