@@ -16,6 +16,7 @@
 // over the wave with a multi-value DPP butterfly (~3 VALU ops per value) and the wave -- the only writer of that
 // (sub-tile, splat) record -- stores the 48-byte record with one plain store.  preprocess_bwd later sums a
 // Gaussian's records in a fixed order, which makes the whole backward deterministic.
+#include <type_traits>
 #include "mm3dgs_common.h"
 #include "sort_tile.h"
 
@@ -359,6 +360,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
+  constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;   // record stride in floats: tracking records (7 floats) are packed at 32 B
   // [buffer][wave][field A|B|C|pair index][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address
   // register per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
   __shared__ float4 stg[2][4][4][64];
@@ -390,7 +392,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + q; e < count; e += 16) {
-    float4* r = (float4*)(dsub + (size_t)list[e].y * SPLAT_F);
+    float4* r = (float4*)(dsub + (size_t)list[e].y * RECF);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int f = 0; f < NF4; f++) r[f] = z;
@@ -416,6 +418,11 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
 
+  // The SLAM losses leave the silhouette and depth^2 channels without gradient (dL[4] = dL[5] = 0): a wave that sees only
+  // zeros there runs a loop instance with those terms removed (exact: they would multiply by zero).
+  const bool z45_wave = MODE != 0 && __ballot(dL[C > 4 ? 4 : 0] != 0.f || dL[C > 5 ? 5 : 0] != 0.f) == 0ull;
+  auto run_chunks = [&](auto z45_tag) {
+  constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
     const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
@@ -442,24 +449,24 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         Tr *= r;  // transmittance in front of this splat
         const float w = a_eff * Tr;
         float col[C];
-        if (C > 0) col[0] = B.z;
-        if (C > 1) col[1] = B.w;
-        if (C > 2) col[2] = Cc.x;
-        if (C > 3) col[3] = Cc.y;
-        if (C > 4) col[4] = Cc.z;
-        if (C > 5) col[5] = Cc.w;
+        if constexpr (C > 0) col[0] = B.z;
+        if constexpr (C > 1) col[1] = B.w;
+        if constexpr (C > 2) col[2] = Cc.x;
+        if constexpr (C > 3) col[3] = Cc.y;
+        if constexpr (C > 4) col[4] = Cc.z;
+        if constexpr (C > 5) col[5] = Cc.w;
         // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
         // (behind_dot) instead of C running colours: qd = c . dL;  dLa = qd - behind_dot;  behind_dot += a (qd - behind_dot)
         float qd = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < C; ch++) qd = fmaf(col[ch], dL[ch], qd);
+        for (int ch = 0; ch < (Z45 ? 4 : C); ch++) qd = fmaf(col[ch], dL[ch], qd);
         const float diff = qd - behind_dot;
         behind_dot = fmaf(a_eff, diff, behind_dot);
         const float dLa = diff * Tr - Tf_bg * r;
         // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
         // into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
         const float u = B.y * dLa * G_eff;
-        if (MODE == 0) {
+        if constexpr (MODE == 0) {
           float vals[NV];
 #pragma unroll
           for (int ch = 0; ch < C; ch++) vals[6 + ch] = w * dL[ch];
@@ -473,12 +480,12 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
           tot = WaveReduce<NV>::run(vals, lane);
         } else {
           // SLAM records: the zeroth moment M0 = sum u also carries the opacity gradient (sum G dL/dalpha = M0 / opacity)
-          const float cz = w * fmaf(2.f * col[3], dL[5], dL[3]);   // d/dz of the [z, 1, z^2] bundle, chained here
+          const float cz = Z45 ? w * dL[3] : w * fmaf(2.f * col[3], dL[5], dL[3]);   // d/dz of the [z, 1, z^2] bundle, chained here
           tot = SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_0, ym_1a, ym_1b);
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
-      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * SPLAT_F] = tot;
+      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * RECF] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
@@ -502,6 +509,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     ((uint32_t*)&stg[cur ^ 1][wv][3][lane])[0] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
+  };
+  if (z45_wave) run_chunks(std::true_type{});
+  else run_chunks(std::false_type{});
   if (cam.stats && lane == 0) {
     atomicAdd(&iv.hdr->bwd_wave_visits, n_visit);
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);

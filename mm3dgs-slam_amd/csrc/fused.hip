@@ -211,7 +211,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     // mm3dgs_common.h).  Validity comes from the 16-bit block masks of its (Gaussian, tile) pairs: each lane walks ITS OWN
     // set bits, eight at a time (up to 24 independent 16-byte loads in flight: the kernel is latency bound at ~2.4 waves
     // per SIMD); a lane that has run out reads record 0 (one shared, cached line) and discards it.  Ascending bit order =
-    // fixed summation order -> deterministic.  10 (mapping) / 7 (tracking) floats per record.
+    // fixed summation order -> deterministic.  10 floats at a 48-B stride (mapping) / 7 floats at a 32-B stride (tracking).
     BlkRect br = {0, 0, 0, 0};
     uint32_t rec0 = 0;
     int tminx = 0, tminy = 0, tw = 1;
@@ -237,7 +237,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
           const int oxp = pq == 0 ? ox[0] : (pq == 1 ? ox[1] : (pq == 2 ? ox[2] : ox[3]));
           const int oyp = pq == 0 ? oy[0] : (pq == 1 ? oy[1] : (pq == 2 ? oy[2] : oy[3]));
           const int bx = oxp + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oyp + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
-          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * SPLAT_F : (size_t)0));
+          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * (TRACK ? 8 : SPLAT_F) : (size_t)0));
           a[u] = r[0]; b[u] = r[1];
           if (!TRACK) c[u] = r[2];
         }
