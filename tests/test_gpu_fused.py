@@ -229,3 +229,34 @@ def test_fused_mapper_window_parallel_two_ranks(tmp_path):
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert a["xyz"].shape == b["xyz"].shape and a["xyz"].shape[0] > 0
     assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["op"], b["op"]) and torch.equal(a["acc"], b["acc"])
+
+
+@pytest.mark.parametrize("long_lists", [False, True])
+def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists):
+    """MM3DGS_FWD_SHORT_LISTS selects the sort + forward-composite kernel; it must reproduce the separate launches bit for
+    bit (same sort order, same lists, same records) -- also when a tile list exceeds its 2048-key LDS tier and takes the
+    global-memory path inside the fused kernel."""
+    from mm3dgs_slam_amd.fused import FusedEngine
+    if long_lists:
+        cfg, g, R, pose, color, depth = _setup(P=12000, H=48, W=64, seed=3)
+        with torch.no_grad():
+            g._scaling += 2.0          # every splat covers most of the small image: thousands of splats per tile
+    else:
+        cfg, g, R, pose, color, depth = _setup(P=20000, H=120, W=168, seed=3)
+    eng = FusedEngine(R)
+    outs = []
+    for hint in (1 << 30, 100):        # no hint -> separate sort launches; "short lists" -> fused kernel
+        eng.max_tile_len = hint
+        si = eng.forward(pose, g, need_grads=True)
+        torch.cuda.synchronize()
+        hdr = eng.img_state[:16].view(torch.int32).cpu()
+        eng.dL.copy_(torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)))
+        eng.backward(si, grads=eng.grads, dpose=eng.dpose)
+        outs.append((eng.out.clone(), eng.radii.clone(), eng.dpose.clone(), {k: v.clone() for k, v in eng.grads.items()}, int(hdr[2])))
+    a, b = outs
+    if long_lists:
+        assert a[4] > 2048, a[4]       # the case really exercises the long-list path
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
