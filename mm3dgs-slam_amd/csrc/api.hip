@@ -193,8 +193,14 @@ static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in
   return 0;
 }
 
-int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
-                        void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream) {
+static bool slam_fused_sort(int flags) {
+  static const int no_fused_sort = env_flag("MM3DGS_NO_FUSED_SORT", 0);
+  return (flags & MM3DGS_FWD_SHORT_LISTS) && !no_fused_sort;
+}
+
+static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
+                             void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
+                             const TrackLoss* tl) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -211,19 +217,24 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
-  static const int no_fused_sort = env_flag("MM3DGS_NO_FUSED_SORT", 0);
-  const bool fused_sort = cd.sort_single && !no_fused_sort;
+  const bool fused_sort = slam_fused_sort(flags);
+  if (tl && !fused_sort) return fail(-1, "internal: folded tracking loss needs the fused sort path");
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
-    if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s);
+    if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
     else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");
 }
 
-int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
-                         const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
-                         const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
-                         const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream) {
+int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
+                        void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream) {
+  return slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, flags, stream, nullptr);
+}
+
+static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
+                              const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
+                              const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
+                              const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!geom_state || !image_state || !binning_state || !dL_dout || !backward_scratch || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -262,12 +273,28 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
     ma.on = 1;
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s); }
+  if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl); }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s); }
   return check_launch("slam_backward");
 }
 
+int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
+                         const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
+                         const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
+                         const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream) {
+  return slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, grads, dL_dpose,
+                            pose_adam, map_adam, stream, nullptr);
+}
+
 static size_t loss_rows(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
+static LossCfg loss_cfg_dev(const Mm3dgsLossConfig* c) {
+  LossCfg lc;
+  lc.H = c->H; lc.W = c->W; lc.w_l1 = c->w_l1; lc.w_ssim = c->w_ssim; lc.w_pearson = c->w_pearson; lc.l1_mask = c->l1_mask;
+  lc.pearson_mask = c->pearson_mask; lc.pearson_invert = c->pearson_invert; lc.sil_thr = c->sil_thr;
+  for (int i = 0; i < 11; i++) lc.window[i] = c->window[i];
+  return lc;
+}
 size_t mm3dgs_loss_work_bytes(int H, int W) {
   return 256 + align_up((size_t)9 * H * W * 4, 256) + align_up(loss_rows(H, W) * 12 * 8, 256);
 }
@@ -277,10 +304,7 @@ int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_co
   if (!c || !out6 || !gt_color || !work || !dL) return fail(-1, "NULL argument");
   if (c->H <= 0 || c->W <= 0) return fail(-1, "bad image size");
   if (c->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
-  LossCfg lc;
-  lc.H = c->H; lc.W = c->W; lc.w_l1 = c->w_l1; lc.w_ssim = c->w_ssim; lc.w_pearson = c->w_pearson; lc.l1_mask = c->l1_mask;
-  lc.pearson_mask = c->pearson_mask; lc.pearson_invert = c->pearson_invert; lc.sil_thr = c->sil_thr;
-  for (int i = 0; i < 11; i++) lc.window[i] = c->window[i];
+  LossCfg lc = loss_cfg_dev(c);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MM3DGS_PROF_LOSS, s);
   char* w = (char*)work;
@@ -297,13 +321,33 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   if (!pose_adam || !pose_adam->pose) return fail(-2, "tracking needs the pose Adam state");
   Mm3dgsSlamGrads none;
   memset(&none, 0, sizeof(none));
+  if (!loss_cfg || !gt_color || !loss_work || !dL_dout) return fail(-1, "NULL argument");
+  if (loss_cfg->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
+  // without SSIM every loss term is per pixel: fold the loss into the compositors (two launches and the gradient image
+  // round trip less per iteration); needs the sort + forward-composite kernel (its workgroup = one 16x16 loss tile)
+  const int no_fold = env_flag("MM3DGS_NO_FOLDED_LOSS", 0);   // read per call: tests compare both paths in one process
+  const bool fold = !no_fold && loss_cfg->w_ssim == 0.f && slam_fused_sort(fwd_flags) && cam->image_height > 0 && cam->image_width > 0;
+  TrackLoss tl = {};
+  if (fold) {
+    tl.cfg = loss_cfg_dev(loss_cfg);
+    char* w = (char*)loss_work;
+    tl.gt = gt_color; tl.ref = ref; tl.out = out_color; tl.sums = (const double*)w;
+    tl.partial = (double*)(w + 256 + align_up((size_t)9 * loss_cfg->H * loss_cfg->W * 4, 256));
+    tl.loss4 = loss4;
+    if (loss_cfg->H != cam->image_height || loss_cfg->W != cam->image_width) return fail(-1, "loss and camera image sizes differ");
+  }
   for (int it = 0; it < n_iter; it++) {
-    int rc = mm3dgs_slam_forward(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
+    int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr);
     if (rc) return rc;
-    rc = mm3dgs_loss(loss_cfg, out_color, gt_color, ref, loss_work, dL_dout, loss4, stream);
-    if (rc) return rc;
-    rc = mm3dgs_slam_backward(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                              nullptr, pose_adam, nullptr, stream);
+    if (fold) {
+      ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
+      launch_loss_finish(tl.cfg, (double*)loss_work, tl.partial, (hipStream_t)stream);
+    } else {
+      rc = mm3dgs_loss(loss_cfg, out_color, gt_color, ref, loss_work, dL_dout, loss4, stream);
+      if (rc) return rc;
+    }
+    rc = slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
+                            nullptr, pose_adam, nullptr, stream, fold ? &tl : nullptr);
     if (rc) return rc;
   }
   return 0;

@@ -19,6 +19,8 @@
 #include <type_traits>
 #include "mm3dgs_common.h"
 #include "sort_tile.h"
+#include "fused_api.h"
+#include "loss_pixel.h"
 
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
@@ -57,7 +59,8 @@ __device__ __forceinline__ SplatRec load_rec(const float* __restrict__ splat, ui
 template <int C>
 __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
                                                    uint32_t N_cap, float* __restrict__ out, float4 (*stg)[4][3][64],
-                                                   const uint32_t* counts_lds) {
+                                                   const uint32_t* counts_lds, const TrackLoss* tl = nullptr,
+                                                   double (*red)[12] = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
@@ -147,12 +150,34 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
     id_nxt = id_nn;
   }
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
+  float fin[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ch++) fin[ch] = acc[ch] + (ch < 3 ? Tr * cam.bg[ch] : 0.f);
+  const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   if (inside) {
-    size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
     iv.final_T[pix] = Tr;
     iv.n_contrib[pix] = last_contributor;
 #pragma unroll
-    for (int ch = 0; ch < C; ch++) out[ch * HW + pix] = acc[ch] + (ch < 3 ? Tr * cam.bg[ch] : 0.f);
+    for (int ch = 0; ch < C; ch++) out[ch * HW + pix] = fin[ch];
+  }
+  if constexpr (C == 6) {
+    if (tl) {
+      // tracking loss folded in: this tile's row of partial sums (what loss_reduce_kernel writes for the same 16x16 tile)
+      double ls[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) ls[k] = 0.0;
+      if (inside) {
+        const float rgb[3] = {fin[0], fin[1], fin[2]};
+        const float g3[3] = {tl->gt[pix], tl->gt[HW + pix], tl->gt[2 * HW + pix]};
+        loss_px_sums(tl->cfg, rgb, fin[4], fin[3], g3, tl->cfg.w_pearson != 0.f ? tl->ref[pix] : 0.f, ls);
+      }
+      block_sums<12>(ls, red);
+      if (threadIdx.x == 0) {
+        double* rowp = tl->partial + (size_t)tile * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) rowp[k] = ls[k];
+      }
+    }
   }
 }
 
@@ -173,16 +198,18 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 // staging buffers share LDS.  Lists longer than 2048 splats take sort_tile_body's global-memory path (slow, correct).
 template <int C>
 __global__ void __launch_bounds__(256)
-sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean) {
+sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean, int has_tl,
+                          TrackLoss tl) {
   __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * 64];   // 24 KB >= 2048 keys (16 KB)
   __shared__ SortShared sh;
+  __shared__ double red[4][12];
   static_assert(sizeof(smem) >= 2048 * sizeof(unsigned long long), "LDS union too small for the key array");
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
   sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh);
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
-  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run);
+  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, has_tl ? &tl : nullptr, red);
 }
 
 // ---- multi-value wave reduction ---------------------------------------------------------------------------------
@@ -340,7 +367,7 @@ __device__ __forceinline__ float xrow_sum(float v) {
 template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
-                     float* __restrict__ dsub) {
+                     float* __restrict__ dsub, int has_tl, TrackLoss tl) {
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
@@ -371,9 +398,27 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const uint32_t last_contributor = inside ? iv.n_contrib[pix] : 0u;
   float dL[C];
   float bg_dot = 0.f;
+  bool dl_done = false;
+  if constexpr (MODE == 2) {
+    if (has_tl) {
+      // tracking loss folded in: dL/d(image) of this pixel from the finished sums (what loss_grad_kernel would have written)
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) dL[ch] = 0.f;
+      if (inside) {
+        const float sil = tl.out[4 * HW + pix];
+        const bool smask = sil > tl.cfg.sil_thr;
+        const float l1s = loss_l1_scale(tl.cfg, tl.sums);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dL[ch] = loss_px_l1_grad(tl.cfg, tl.out[ch * HW + pix], tl.gt[ch * HW + pix], smask, l1s);
+        if (tl.cfg.w_pearson != 0.f) dL[3] = loss_px_pearson_grad(tl.cfg, sil, tl.out[3 * HW + pix], tl.ref[pix], tl.sums);
+      }
+      if (tile == 0 && threadIdx.x == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
+      dl_done = true;
+    }
+  }
 #pragma unroll
   for (int ch = 0; ch < C; ch++) {
-    dL[ch] = inside ? dL_dout[ch * HW + pix] : 0.f;
+    if (!dl_done) dL[ch] = inside ? dL_dout[ch * HW + pix] : 0.f;
     if (ch < 3) bg_dot += cam.bg[ch] * dL[ch];
   }
   const float Tf_bg = T_final * bg_dot;
@@ -529,24 +574,28 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
                          hipStream_t s) {
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+  TrackLoss none = {};
+  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none);
 }
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s) {
+                               float* dsub, hipStream_t s, const TrackLoss* tl) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
+  TrackLoss none = {};
   if (tracking)
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none);
   else
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none);
 }
 
-void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s) {
+void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
+                                const TrackLoss* tl) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean);
+  TrackLoss none = {};
+  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,

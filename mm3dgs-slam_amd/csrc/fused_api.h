@@ -22,11 +22,28 @@ struct LossCfg {
   float window[11];
 };
 
+// A tracking iteration without SSIM folds the per-pixel loss into the compositors (mm3dgs_slam_track): the forward epilogue
+// writes the per-tile partial sums loss_reduce_kernel would, the backward prologue derives dL/d(image) from the finished
+// sums instead of reading the gradient image loss_grad_kernel would have written.  Two launches and a 7 MB round trip less.
+struct TrackLoss {
+  LossCfg cfg;
+  const float* gt;      // [3,H,W]
+  const float* ref;     // [H,W] or NULL (Pearson off)
+  const float* out;     // [6,H,W] the rendered bundle (backward prologue)
+  double* partial;      // [tiles][12]
+  const double* sums;   // finished sums (loss_finish_kernel)
+  float* loss4;         // {total, l1, 1-ssim, 1-rho} or NULL
+};
+void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s);
+
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s);
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s);
+                               float* dsub, hipStream_t s, const TrackLoss* tl = nullptr);
+// sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
+void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
+                                const TrackLoss* tl = nullptr);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s);

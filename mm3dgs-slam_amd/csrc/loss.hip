@@ -10,28 +10,13 @@
 // Channel layout of `out`: 0..2 RGB, 3 depth (alpha-weighted z), 4 silhouette, 5 depth^2.
 #include "mm3dgs_common.h"
 #include "fused_api.h"
+#include "loss_pixel.h"
 
 #define LT 16
 #define HALO 5
 #define LW (LT + 2 * HALO)  // 26
 #define LWP 27              // LDS row stride (odd: rows start on different banks; 48 would be conflict-free but costs a workgroup of occupancy)
 #define NSUM 16
-
-// sum of NR per-lane values over the 256-lane workgroup: float DPP reduction inside each wave (<= 64 addends), the four
-// wave totals are combined in double by lane 0
-template <int NR>
-__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR]) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NR; k++) {
-    const float t = wave_sum_to_lane63((float)v[k]);
-    if (lane == 63) sh[wv][k] = (double)t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-#pragma unroll
-    for (int k = 0; k < NR; k++) v[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
-}
 
 __global__ void __launch_bounds__(256)
 loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
@@ -53,7 +38,6 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
 
   const float sil = inside ? out[4 * HW + pix] : 0.f;
-  const bool smask = sil > cfg.sil_thr;
   if (cfg.w_ssim != 0.f) {
     // the (row, column) of a lane's three halo elements are computed once and reused for every channel
     constexpr int NEL = (LW * LW + 255) / 256;   // 3
@@ -126,26 +110,9 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
       }
     }
   }
-  if (inside && (cfg.l1_mask == 0 || smask)) {
-    float l1 = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) l1 += fabsf(out[ch * HW + pix] - gt[ch * HW + pix]);
-    acc[0] = (double)l1;
-    acc[1] = 1.0;
-  }
-  if (cfg.w_pearson != 0.f && inside) {
-    const float r = ref[pix];
-    bool m = true;
-    if (cfg.pearson_mask & 1) m = m && smask;
-    if (cfg.pearson_mask & 2) m = m && (r > 0.f);
-    if (m) {
-      const double x = (double)out[3 * HW + pix];
-      const double t1 = cfg.pearson_invert ? -(double)r : (double)r;
-      const double t2 = 1.0 / ((double)r + 200.0);
-      acc[3] = 1.0; acc[4] = x; acc[5] = x * x;
-      acc[6] = t1; acc[7] = t1 * t1; acc[8] = x * t1;
-      acc[9] = t2; acc[10] = t2 * t2; acc[11] = x * t2;
-    }
+  if (inside) {
+    const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
+    loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);   // acc[2] (SSIM) untouched
   }
   block_sums<12>(acc, red);
   // one row of partial sums per workgroup (plain stores): 14k double atomics on two cache lines cost ~90 us
@@ -231,8 +198,7 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   const int px = x0 + tx, py = y0 + ty;
   const bool inside = px < cfg.W && py < cfg.H;
   const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
-  const double n_l1 = sums[1];
-  const float l1_scale = n_l1 > 0.0 ? cfg.w_l1 / (float)(3.0 * n_l1) : 0.f;
+  const float l1_scale = loss_l1_scale(cfg, sums);
   const float ssim_scale = -cfg.w_ssim / (float)(3.0 * (double)HW);
   const float sil = inside ? out[4 * HW + pix] : 0.f;
   const bool smask = sil > cfg.sil_thr;
@@ -296,46 +262,19 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   }
   if (inside) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      float g = gch[ch];
-      if (cfg.l1_mask == 0 || smask) {
-        const float d = out[ch * HW + pix] - gt[ch * HW + pix];
-        g += l1_scale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-      }
-      dL[ch * HW + pix] = g;
-    }
-  }
-  // depth channel: Pearson
-  float gd = 0.f;
-  double loss_p = 0.0;
-  if (cfg.w_pearson != 0.f && sums[16] != 0.0) {
-    // d(1 - rho)/dx = -[(t - mean_t) / sqrt(cxx ctt) - rho (x - mean_x) / cxx], scalars prepared by loss_finish_kernel
-    const bool use2 = sums[17] != 0.0;
-    loss_p = sums[23];
-    if (inside) {
-      const float r = ref[pix];
-      bool m = true;
-      if (cfg.pearson_mask & 1) m = m && smask;
-      if (cfg.pearson_mask & 2) m = m && (r > 0.f);
-      if (m) {
-        const double x = (double)out[3 * HW + pix];
-        const double t = use2 ? 1.0 / ((double)r + 200.0) : (cfg.pearson_invert ? -(double)r : (double)r);
-        const double drho = (t - sums[22]) * sums[19] - sums[20] * (x - sums[21]);
-        gd = (float)(-(double)cfg.w_pearson * drho);
-      }
-    }
-  }
-  if (inside) {
-    dL[3 * HW + pix] = gd;
+    for (int ch = 0; ch < 3; ch++)
+      dL[ch * HW + pix] = gch[ch] + loss_px_l1_grad(cfg, out[ch * HW + pix], gt[ch * HW + pix], smask, l1_scale);
+    // depth channel: Pearson; silhouette and depth^2 carry no loss
+    dL[3 * HW + pix] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + pix], ref[pix], sums) : 0.f;
     dL[4 * HW + pix] = 0.f;
     dL[5 * HW + pix] = 0.f;
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss) {
-    const double l1 = n_l1 > 0.0 ? sums[0] / (3.0 * n_l1) : 0.0;
-    const double ss = cfg.w_ssim != 0.f ? 1.0 - sums[2] / (3.0 * (double)HW) : 0.0;
-    loss[1] = (float)l1; loss[2] = (float)ss; loss[3] = (float)loss_p;
-    loss[0] = (float)(cfg.w_l1 * l1 + cfg.w_ssim * ss + cfg.w_pearson * loss_p);
-  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss) loss_scalars(cfg, sums, HW, loss);
+}
+
+void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s) {
+  const int nrows = ((cfg.W + LT - 1) / LT) * ((cfg.H + LT - 1) / LT);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, nrows, sums, cfg.w_pearson != 0.f ? 1 : 0, cfg.pearson_invert);
 }
 
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,

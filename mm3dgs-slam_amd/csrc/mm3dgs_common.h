@@ -200,8 +200,6 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s);
 void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
                          const int32_t* radii_or_null, hipStream_t s, bool scatter_only = false);
-// sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
-void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s);
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
                           float* out_color, hipStream_t s);
 void launch_composite_bwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,

@@ -260,3 +260,34 @@ def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists):
     assert torch.equal(a[2], b[2])
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("pearson", [False, True])
+def test_tracking_loss_folded_into_the_compositors_matches_the_loss_kernels(pearson, monkeypatch):
+    """mm3dgs_slam_track folds an SSIM-free loss into the forward epilogue / backward prologue; the pose trajectory must
+    match the three-kernel loss path (same arithmetic per pixel, only the summation order of the tile sums differs)."""
+    from mm3dgs_slam_amd import _lib
+    from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
+    cfg, g, R, pose0, color, depth = _setup(P=20000, H=120, W=168, seed=4)
+    with torch.no_grad():
+        gt = torch.cat([R.render(g, pose0)["render"]], 0).contiguous()
+        ref = R.render(g, pose0)["depth"][0].contiguous()
+    results = []
+    for no_fold in ("1", "0"):
+        monkeypatch.setenv("MM3DGS_NO_FOLDED_LOSS", no_fold)
+        eng = FusedEngine(R)
+        eng.max_tile_len = 100                       # "short lists" hint: the fused sort kernel (required for folding)
+        pose = (pose0 + torch.tensor([0.0, 0.004, -0.003, 0.002, 0.01, -0.008, 0.012], device=DEV)).contiguous()
+        m, v = torch.zeros(7, device=DEV), torch.zeros(7, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.05 if pearson else 0.0, 1, 1 if pearson else 0, 1, 0.99)
+        ad = _lib.Mm3dgsPoseAdam()
+        ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
+        ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = 0.002, 0.002, 0.9, 0.999, 1e-8
+        eng.track_loop(12, pose, g, lcfg, gt, ref if pearson else None, ad)
+        torch.cuda.synchronize()
+        results.append((pose.clone(), eng.loss.clone(), int(step)))
+    (pa, la, sa), (pb, lb, sb) = results
+    assert sa == sb == 12
+    assert (pa - pb).abs().max() < 2e-5, (pa, pb)
+    assert (la - lb).abs().max() < 1e-5 * max(1.0, float(la.abs().max())), (la, lb)
