@@ -71,18 +71,23 @@ class FusedEngine:
 
     def _ensure(self, P, need_grads):
         if P != self.P:
-            u8 = dict(dtype=torch.uint8, device=self.dev)
-            self.geom = torch.empty(self.lib.mm3dgs_geom_bytes(P), **u8)
-            self.radii = torch.empty(P, dtype=torch.int32, device=self.dev)
+            # the map grows by a few percent per keyframe: buffers are sized for 1.25 P and re-used until outgrown (a fresh
+            # hipMalloc of the ~0.5 GB scratch at every keyframe cost ~10 ms of the frame)
+            if P > getattr(self, "_cap_P", -1):
+                self._cap_P = int(P * 1.25) + 1024
+                u8 = dict(dtype=torch.uint8, device=self.dev)
+                self.geom = torch.empty(self.lib.mm3dgs_geom_bytes(self._cap_P), **u8)
+                self._radii_buf = torch.empty(self._cap_P, dtype=torch.int32, device=self.dev)
+                self.n_cap = 0
+            self.radii = self._radii_buf[:P]
             self.P = P
-            self.n_cap = 0
             self.grads = None
         want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + 65536
         if want > self.n_cap or (self.ratio is not None and self.n_cap > 4 * want):
             u8 = dict(dtype=torch.uint8, device=self.dev)
-            self.n_cap = want
+            self.n_cap = int(want * 1.25) if self.ratio is not None else want
             self.binning = torch.empty(self.lib.mm3dgs_binning_bytes(self.n_cap), **u8)
-            self.scratch = torch.empty(self.lib.mm3dgs_backward_scratch_bytes(P, self.n_cap), **u8)
+            self.scratch = torch.empty(self.lib.mm3dgs_backward_scratch_bytes(self._cap_P, self.n_cap), **u8)
         if need_grads and self.grads is None:
             # one flat buffer [xyz 3P | f_dc 3P | opacity P | scaling 3P | rotation 4P | accum P | denom P]: the multi-GPU
             # window all-reduces it in a single collective (window_parallel.py)

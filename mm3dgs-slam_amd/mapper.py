@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from .loss_utils import l1_loss, pearson_loss, ssim
-from .pose_utils import get_camera_from_tensor
+from .pose_utils import apply_rigid, get_camera_from_tensor, rigid_inverse
 from .sh_utils import RGB2SH
 
 
@@ -58,15 +58,14 @@ class Mapper:
         fx, fy, cx, cy = self._intr()
         z = depth[sampled_indices[:, 0], sampled_indices[:, 1]]
         cam = torch.stack(((sampled_indices[:, 1] - cx) / fx * z, (sampled_indices[:, 0] - cy) / fy * z, z), -1)
-        c2w = torch.linalg.inv(w2c)
-        pts = cam @ c2w[:3, :3].t() + c2w[:3, 3]
+        pts = apply_rigid(cam, rigid_inverse(w2c))
         keep = torch.round(pts, decimals=4).abs().sum(1) > 0          # drop points at the world origin
         return pts[keep]
 
     def is_covisible(self, depth_pcd, camera_pose, height, width, threshold=0.9):
         fx, fy, cx, cy = self._intr()
         w2c = get_camera_from_tensor(camera_pose)
-        p = depth_pcd @ w2c[:3, :3].t() + w2c[:3, 3]
+        p = apply_rigid(depth_pcd, w2c)
         z = p[:, 2] + 1e-5
         u, v = (fx * p[:, 0] + cx * p[:, 2]) / z, (fy * p[:, 1] + cy * p[:, 2]) / z
         inside = (u < width) & (u > 0) & (v < height) & (v > 0) & (z > 0)
@@ -135,8 +134,7 @@ class Mapper:
         v, u = torch.meshgrid(torch.arange(H, device=dev).float(), torch.arange(W, device=dev).float(), indexing="ij")
         z = depth.reshape(-1)
         cam = torch.stack(((u.reshape(-1) - cx) / fx * z, (v.reshape(-1) - cy) / fy * z, z), -1)
-        c2w = torch.linalg.inv(w2c)
-        pts = cam @ c2w[:3, :3].t() + c2w[:3, 3]
+        pts = apply_rigid(cam, rigid_inverse(w2c))
         cld = torch.cat((pts, color.permute(1, 2, 0).reshape(-1, 3)), -1)
         msd = (z / ((fx + fy) / 2)) ** 2
         return (cld, msd) if mask is None else (cld[mask], msd[mask])

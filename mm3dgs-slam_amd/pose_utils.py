@@ -115,3 +115,20 @@ def propagate_imu(camm1, camm2, imu_meas_list, c2i, dt_cam, dt_imu) -> torch.Ten
         delta[:3, 3] = dpos
         i2w = i2w @ delta
     return get_tensor_from_camera(torch.linalg.inv(i2w @ c2i))
+
+
+def rigid_inverse(M: torch.Tensor) -> torch.Tensor:
+    """Inverse of a rigid 4x4 [R|t; 0 1] in closed form ([R^T | -R^T t]): no solver call (the first ``torch.linalg.inv`` on
+    the device costs tens of milliseconds of library initialisation inside a SLAM frame)."""
+    R, t = M[:3, :3], M[:3, 3]
+    Rt = R.t()
+    top = torch.cat([Rt, -(Rt * t[None, :]).sum(1, keepdim=True)], 1)
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=M.dtype, device=M.device)
+    return torch.cat([top, bottom], 0)
+
+
+def apply_rigid(pts: torch.Tensor, M: torch.Tensor) -> torch.Tensor:
+    """[n,3] points through the rigid 4x4 M (x -> R x + t) with broadcast arithmetic instead of a BLAS call (differentiable)."""
+    R, t = M[:3, :3], M[:3, 3]
+    return pts[:, 0:1] * R[:, 0] + pts[:, 1:2] * R[:, 1] + pts[:, 2:3] * R[:, 2] + t
+

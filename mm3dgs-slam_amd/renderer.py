@@ -23,14 +23,14 @@ from __future__ import annotations
 import torch
 
 from .graphics_utils import getProjectionMatrix2
-from .pose_utils import get_camera_from_tensor
+from .pose_utils import apply_rigid, get_camera_from_tensor
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from .sh_utils import eval_sh
 
 
 def get_depth_and_silhouette(means3D, w2c):
     """[z_cam, 1, z_cam^2] per Gaussian, evaluated at its centre (``slam/renderer.py:26-43``)."""
-    z = means3D @ w2c[2, :3] + w2c[2, 3]
+    z = (means3D * w2c[2, :3]).sum(1) + w2c[2, 3]      # (no BLAS: a [P,3] x [3] product is a 100 us gemv launch)
     return torch.stack([z, torch.ones_like(z), z * z], 1)
 
 
@@ -66,7 +66,7 @@ class Renderer:
             w2c = self._eye
             projmatrix = self.projection_matrix
             camera_pos = torch.zeros(3, device=xyz.device)
-            means3D = xyz @ rel_w2c[:3, :3].t() + rel_w2c[:3, 3]
+            means3D = apply_rigid(xyz, rel_w2c)
         else:
             w2c = rel_w2c.t()
             projmatrix = w2c @ self.projection_matrix
