@@ -198,14 +198,23 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
   for (int k = 0; k < NPOSE; k++) cg[k] = 0.f;
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   int rad = 0;
+  float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;   // first 32 bytes of this Gaussian's splat record (xy, conic, opacity)
   {
     uint32_t goff = 0;
     int area = 0;
-    if (idx < P) rad = radii[idx];
-    if (rad > 0) {
-      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+    // one round of independent loads for everything the gather needs (this kernel is a chain of memory latencies: every
+    // dependent step costs ~2 us).  A culled Gaussian has rect = 0 (and an unwritten splat record, read but never used).
+    uint32_t r0 = 0, r1 = 0, toff = 0, boff = 0, btile = 0, bblk = 0;
+    if (idx < P) {
+      rad = radii[idx];
+      r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
+      toff = g.tileoff[idx]; boff = g.blkoff[idx]; btile = g.block_tiles[idx >> 8]; bblk = g.block_blk[idx >> 8];
+      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
+      sA = spl[0]; sB = spl[1];
+    }
+    if (r1 != r0) {   // <=> radii > 0
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
-      goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
+      goff = btile + toff;
     }
     // Gradient records: one per (splat, 4x4 block), dense and contiguous per Gaussian (row-major over its block rectangle,
     // mm3dgs_common.h).  Validity comes from the 16-bit block masks of its (Gaussian, tile) pairs: each lane walks ITS OWN
@@ -215,11 +224,9 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     BlkRect br = {0, 0, 0, 0};
     uint32_t rec0 = 0;
     int tminx = 0, tminy = 0, tw = 1;
-    if (rad > 0) {
-      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
-      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
-      br = block_rect(spl[0], spl[1], r0, r1);
-      rec0 = g.block_blk[idx >> 8] + g.blkoff[idx];
+    if (area > 0) {
+      br = block_rect(sA, sB, r0, r1);
+      rec0 = bblk + boff;
       tminx = r0 & 0xffff; tminy = r0 >> 16; tw = max((int)(r1 & 0xffff) - tminx, 1);
     }
     // M: block masks of up to four pairs; (ox[p], oy[p]) = block coordinates of pair p's tile relative to the block rectangle
@@ -316,8 +323,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     }
     if (rad > 0) {
       // moments -> d/dxy (pixel units) and d/dconic, with this splat's conic (composite.hip record layout)
-      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
-      const float4 sp0 = spl[0], sp1 = spl[1];
+      const float4 sp0 = sA, sp1 = sB;
       const float qa = sp0.z, qb = sp0.w, qc = sp1.x;
       // record layouts of composite.hip's SepReduce:  mapping [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy],  tracking [M0 Mx Mxx cz | My Mxy Myy]
       const float M0 = acc0.x, m_x = acc0.y, m_xx = acc0.z;
