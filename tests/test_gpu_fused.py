@@ -291,3 +291,27 @@ def test_tracking_loss_folded_into_the_compositors_matches_the_loss_kernels(pear
     assert sa == sb == 12
     assert (pa - pb).abs().max() < 2e-5, (pa, pb)
     assert (la - lb).abs().max() < 1e-5 * max(1.0, float(la.abs().max())), (la, lb)
+
+
+def test_fused_path_with_huge_splats_matches_torch_graph():
+    """Same for the native SLAM path: a map whose Gaussians each cover dozens of tiles (wave-cooperative gather of the
+    dense gradient records, block rectangles far larger than a tile)."""
+    from mm3dgs_slam_amd.fused import FusedEngine
+    cfg, g, R, pose, color, depth = _setup(P=300, H=128, W=160, seed=6)
+    with torch.no_grad():
+        g._scaling += 3.0
+    eng = FusedEngine(R)
+    si = eng.forward(pose, g, need_grads=True)
+    eng.check_capacity()
+    p = pose.clone().requires_grad_(True)
+    res = R.render(g, p)
+    ref = torch.cat([res["render"], res["depth"]], 0)
+    assert int((res["radii"] > 40).sum()) > 100       # the case really has huge splats
+    assert pu.rel_l2(eng.out, ref) < 1e-5
+    w = torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    (ref * w).sum().backward()
+    eng.dL.copy_(w)
+    eng.backward(si, grads=eng.grads, dpose=eng.dpose)
+    assert pu.rel_l2(eng.dpose, p.grad) < 5e-4, (eng.dpose, p.grad)
+    for name, param in (("xyz", g._xyz), ("f_dc", g._features_dc), ("opacity", g._opacity), ("scaling", g._scaling)):
+        assert pu.rel_l2(eng.grads[name], param.grad) < 5e-4, name

@@ -57,6 +57,13 @@ def test_long_tile_lists_sort_tiers():
     _check(m, grad_tol=5e-4)
 
 
+def test_huge_splats_take_the_wave_cooperative_paths():
+    """Splats covering more than 32 tiles are counted / scattered / gathered by a whole wave (block rectangles of hundreds
+    of 4x4 blocks, gradient records spread over many tiles): 160x128 px = 80 tiles, every splat touches most of them."""
+    m = pu.compare(pu.make_case(P=120, H=128, W=160, seed=31, log_scale=-0.9, spread=0.8, extras=3), verbose=True)
+    _check(m)
+
+
 def test_tracker_mode_skips_gaussian_grads():
     case = pu.make_case(P=2000, H=80, W=112, seed=12, posed=True)
     _, _, _, g_o = pu.run_oracle(case)
