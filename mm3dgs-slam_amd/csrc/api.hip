@@ -235,6 +235,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
                               const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl) {
+  PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
+  if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!geom_state || !image_state || !binning_state || !dL_dout || !backward_scratch || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -275,7 +277,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr); }
   return check_launch("slam_backward");
 }
 
@@ -334,14 +336,17 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
     tl.gt = gt_color; tl.ref = ref; tl.out = out_color; tl.sums = (const double*)w;
     tl.partial = (double*)(w + 256 + align_up((size_t)9 * loss_cfg->H * loss_cfg->W * 4, 256));
     tl.loss4 = loss4;
+    tl.defer_scale = loss_cfg->w_pearson == 0.f ? 1 : 0;   // masked L1 only: no loss-finish launch, 1/n goes to the pose gradient
     if (loss_cfg->H != cam->image_height || loss_cfg->W != cam->image_width) return fail(-1, "loss and camera image sizes differ");
   }
   for (int it = 0; it < n_iter; it++) {
     int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr);
     if (rc) return rc;
     if (fold) {
-      ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
-      launch_loss_finish(tl.cfg, (double*)loss_work, tl.partial, (hipStream_t)stream);
+      if (!tl.defer_scale) {
+        ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
+        launch_loss_finish(tl.cfg, (double*)loss_work, tl.partial, (hipStream_t)stream);
+      }
     } else {
       rc = mm3dgs_loss(loss_cfg, out_color, gt_color, ref, loss_work, dL_dout, loss4, stream);
       if (rc) return rc;

@@ -407,12 +407,12 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       if (inside) {
         const float sil = tl.out[4 * HW + pix];
         const bool smask = sil > tl.cfg.sil_thr;
-        const float l1s = loss_l1_scale(tl.cfg, tl.sums);
+        const float l1s = tl.defer_scale ? tl.cfg.w_l1 / 3.f : loss_l1_scale(tl.cfg, tl.sums);   // deferred: 1/n applied to the pose gradient
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) dL[ch] = loss_px_l1_grad(tl.cfg, tl.out[ch * HW + pix], tl.gt[ch * HW + pix], smask, l1s);
         if (tl.cfg.w_pearson != 0.f) dL[3] = loss_px_pearson_grad(tl.cfg, sil, tl.out[3 * HW + pix], tl.ref[pix], tl.sums);
       }
-      if (tile == 0 && threadIdx.x == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
+      if (!tl.defer_scale && tile == 0 && threadIdx.x == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
       dl_done = true;
     }
   }

@@ -475,12 +475,12 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 // R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
 // betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
 __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
-                                        float* __restrict__ dpose, PoseAdam ad) {
+                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls) {
   // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
   // added in a fixed order (deterministic, double precision)
   __shared__ double part[64][16];
   __shared__ double part8[8][16];
-  __shared__ double tot[NPOSE];
+  __shared__ double tot[16];
   const int k = threadIdx.x;
   // lane 0's pose / Adam state: requested first, lands while the rows are summed (this kernel is pure latency)
   float pin[4] = {1.f, 0.f, 0.f, 0.f}, pcur[7], am[7], av[7];
@@ -503,6 +503,9 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       int r = grp;
       for (; r + 64 < nrows; r += 128) { a0 += (double)posepartial[(size_t)r * 32 + col]; a1 += (double)posepartial[(size_t)(r + 64) * 32 + col]; }
       if (r < nrows) a0 += (double)posepartial[(size_t)r * 32 + col];
+    } else if (pls.rows && col < NPOSE + 2) {
+      // deferred masked-L1 normalisation: columns 12 / 13 sum the loss rows' L1 sum / pixel count
+      for (int r = grp; r < pls.nrows; r += 64) a0 += pls.rows[(size_t)r * 12 + (col - NPOSE)];
     }
     part[grp][col] = a0 + a1;
   }
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     part8[k >> 4][k & 15] = acc;
   }
   __syncthreads();
-  if (k < NPOSE) {
+  if (k < 16) {
     double acc = 0.0;
 #pragma unroll
     for (int gq = 0; gq < 8; gq++) acc += part8[gq][k];
@@ -523,6 +526,16 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   }
   __syncthreads();
   if (k == 0) {
+    if (pls.rows) {
+      // dL/d(image) was left unnormalised (sign * w_l1 / 3 on the masked pixels): the pose gradient is linear in it
+      const double npx = tot[NPOSE + 1];
+      const double sc = npx > 0.0 ? 1.0 / npx : 0.0;
+      for (int i = 0; i < NPOSE; i++) tot[i] *= sc;
+      if (pls.loss4) {
+        const double l1 = npx > 0.0 ? tot[NPOSE] / (3.0 * npx) : 0.0;
+        pls.loss4[0] = (float)(pls.w_l1 * l1); pls.loss4[1] = (float)l1; pls.loss4[2] = 0.f; pls.loss4[3] = 0.f;
+      }
+    }
     const float w0 = pin[0], x0 = pin[1], y0 = pin[2], z0 = pin[3];
     const float n = sqrtf(w0 * w0 + x0 * x0 + y0 * y0 + z0 * z0), inv = 1.f / n;
     const float r = w0 * inv, x = x0 * inv, y = y0 * inv, z = z0 * inv;
@@ -562,7 +575,8 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 }
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
-                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s) {
+                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
+                                const PoseLossScale* pls) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
@@ -575,7 +589,11 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
                          bw.dsub, partial, out, ma);
   }
   if (want_pose)
-    hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad);
+  {
+    PoseLossScale none = {nullptr, 0, 0.f, nullptr};
+    hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad,
+                       pls ? *pls : none);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

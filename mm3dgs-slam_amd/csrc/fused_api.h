@@ -33,12 +33,17 @@ struct TrackLoss {
   double* partial;      // [tiles][12]
   const double* sums;   // finished sums (loss_finish_kernel)
   float* loss4;         // {total, l1, 1-ssim, 1-rho} or NULL
+  int defer_scale;      // 1: masked-L1 only -- the 1/(3 n) normalisation is applied to the pose gradient by the pose
+                        //    finishing kernel (the gradient is linear in dL), so no loss-finish launch is needed at all
 };
+// the loss partial rows the pose finishing kernel sums when the normalisation is deferred (see TrackLoss::defer_scale)
+struct PoseLossScale { const double* rows; int nrows; float w_l1; float* loss4; };
 void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s);
 
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
-                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s);
+                                BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
+                                const PoseLossScale* pls = nullptr);
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
                                float* dsub, hipStream_t s, const TrackLoss* tl = nullptr);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
