@@ -486,7 +486,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
       const bool valid = row_on && (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       float tot = 0.f;
       n_visit++;
-      if (__ballot(valid) != 0ull) {
+      if (MODE != 0 || __ballot(valid) != 0ull) {   // SLAM modes: four rows with different splats -- a whole-wave miss is rare, the vote is not worth its cost
         n_red++;
         const float a_eff = valid ? alpha : 0.f;
         const float G_eff = valid ? G : 0.f;
