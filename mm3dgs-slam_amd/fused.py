@@ -220,6 +220,14 @@ class FusedTracker(Tracker):
 
 
 class FusedMapper(Mapper):
+    def _render_depth_sil(self, pose):
+        # the keyframe test renders once per frame: one native forward instead of the ~40 torch launches of Renderer.render
+        if not FusedEngine.eligible(self.cfg, self.gaussians):
+            return super()._render_depth_sil(pose)
+        eng = _engine(self.renderer)
+        eng.forward(pose.detach().float().contiguous(), self.gaussians)
+        return eng.out[3], eng.out[4]
+
     def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]

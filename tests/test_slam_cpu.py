@@ -64,3 +64,40 @@ def test_prune_step_is_a_noop_for_adam_like_the_reference():
     assert after.shape[0] <= before.shape[0]
     keep = ~((torch.sigmoid(slam.gaussians._opacity.detach()) < 0.005).squeeze(-1))
     assert torch.equal(after, before[: after.shape[0]]) or after.shape[0] < before.shape[0]
+
+
+def test_dense_covisibility_ratio_equals_the_index_list_formulation():
+    """Mapper.covisibility_ratio_dense (masks over the whole image) vs get_depth_pointcloud + is_covisible (the reference's
+    nonzero / gather formulation, slam/mapper.py:141-216): identical ratio."""
+    import torch
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    from mm3dgs_slam_amd.mapper import Mapper
+    from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
+    H, W = 40, 56
+    cfg = default_config(device="cpu", height=H, width=W)
+    mp = Mapper(cfg, GaussianModel(cfg), renderer=None, estimate_pose_list=[None])
+    gen = torch.Generator().manual_seed(3)
+    depth = torch.rand(H, W, generator=gen) * 3 + 0.5
+    sil = torch.rand(H, W, generator=gen) * 0.2 + 0.85          # ~1/3 of the pixels fail the 0.99 silhouette test
+    depth[5:9, 7:20] = 0.0
+    kf_pose = torch.tensor([0.99, 0.05, -0.03, 0.02, 0.1, -0.05, 0.2])
+    for cur in (torch.tensor([0.98, 0.1, 0.08, -0.05, 0.6, 0.2, -0.3]), kf_pose.clone(), torch.tensor([0.7, 0.0, 0.7, 0.0, 1.5, 0.0, 1.0])):
+        d = depth.clone()
+        d[~(sil > 0.99)] = 0
+        idx = torch.stack(torch.where(d > 0), dim=1)
+        pts = mp.get_depth_pointcloud(d, get_camera_from_tensor(kf_pose), idx)
+        fx, fy, cx, cy = mp._intr()
+        w2c = get_camera_from_tensor(cur)
+        p = pts @ w2c[:3, :3].t() + w2c[:3, 3]
+        z = p[:, 2] + 1e-5
+        u, v = (fx * p[:, 0] + cx * p[:, 2]) / z, (fy * p[:, 1] + cy * p[:, 2]) / z
+        want = ((u < W) & (u > 0) & (v < H) & (v > 0) & (z > 0)).sum() / max(p.shape[0], 1)
+        got = mp.covisibility_ratio_dense(depth, sil, kf_pose, cur)
+        # points that reproject within 1e-3 px of the image border (pixel row / column 0 seen from the same pose) are
+        # decided by float rounding in either formulation: allow exactly those
+        edge = ((u.abs() < 1e-3) | ((u - W).abs() < 1e-3) | (v.abs() < 1e-3) | ((v - H).abs() < 1e-3)).sum()
+        assert abs(float(got) - float(want)) <= (float(edge) + 1e-3) / max(p.shape[0], 1), (got, want, edge)
+        for thr in (0.1, 0.5, 0.95):
+            if abs(float(want) - thr) > 0.02:
+                assert bool(got > thr) == bool(mp.is_covisible(pts, cur, H, W, threshold=thr))
