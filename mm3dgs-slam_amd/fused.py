@@ -286,14 +286,19 @@ class FusedMapper(Mapper):
                 si = eng.forward(pose, g, need_grads=True)
                 eng.loss_call(lcfg, gt_color, ref)
                 if multi:
-                    # each rank rendered a different keyframe: sum gradients and statistics over the window
-                    eng.stat_delta[0].zero_(); eng.stat_delta[1].zero_(); eng.stat_delta[2].zero_()
-                    eng.backward(si, grads=eng.grads, stats=eng.stat_delta if densify else None)
-                    self.window.reduce_flat(eng.flat, eng.stat_delta[0])
+                    # each rank rendered a different keyframe: sum gradients (and, while densifying, the statistics) over the
+                    # window -- one flat all-reduce; the statistics tail [14P, 16P) and the radii max-reduce only when consumed
+                    P = eng.P
                     if densify:
+                        eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
+                        eng.backward(si, grads=eng.grads, stats=eng.stat_delta)
+                        self.window.reduce_flat(eng.flat, eng.stat_delta[0])
                         g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
                         g.xyz_gradient_accum += eng.stat_delta[1]
                         g.denom += eng.stat_delta[2]
+                    else:
+                        eng.backward(si, grads=eng.grads, stats=None)
+                        self.window.reduce_flat(eng.flat[:14 * P])
                     prune_now = prune_at(iteration)
                     if not prune_now:
                         self._adam_step(eng)
@@ -335,9 +340,21 @@ class FusedMapper(Mapper):
     def _adam_step(self, eng):
         g = self.gaussians
         opt = g.optimizer
+        # the group table only changes when a tensor is replaced (prune / densify): cache it on the pointers
+        key = (g._xyz.data_ptr(), eng.grads["xyz"].data_ptr(), int(g._xyz.shape[0]))
+        cache = getattr(self, "_adam_cache", None)
+        if cache is not None and cache[0] == key and all(float(gr["lr"]) == lr for gr, lr in zip(cache[3], cache[4])):
+            _, table, n, groups, _, states = cache
+            for st in states:
+                st["step"] += 1
+            step_val = int(states[0]["step"].item())
+            b1, b2 = opt.param_groups[0]["betas"]
+            _lib.check(eng.lib.mm3dgs_adam(table, n, step_val, float(b1), float(b2), float(opt.param_groups[0]["eps"]), _stream()))
+            return
         table = (_lib.Mm3dgsAdamGroup * 8)()
         n = 0
         step_val = None
+        used_groups, used_states = [], []
         for group in opt.param_groups:
             name = group["name"]
             if name not in eng.grads:
@@ -354,6 +371,8 @@ class FusedMapper(Mapper):
             e.param, e.grad = p.data_ptr(), eng.grads[name].data_ptr()
             e.exp_avg, e.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             e.n, e.lr = p.numel(), float(group["lr"])
+            used_groups.append(group); used_states.append(st)
             n += 1
+        self._adam_cache = (key, table, n, used_groups, [float(gr["lr"]) for gr in used_groups], used_states)
         b1, b2 = opt.param_groups[0]["betas"]
         _lib.check(eng.lib.mm3dgs_adam(table, n, step_val, float(b1), float(b2), float(opt.param_groups[0]["eps"]), _stream()))

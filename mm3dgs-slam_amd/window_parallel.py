@@ -56,8 +56,10 @@ class WindowParallel:
             off += n
         return flat[:, off:off + 1], flat[:, off + 1:off + 2], rmax
 
-    def reduce_flat(self, flat, rmax):
-        """Native-loop variant: `flat` is the engine's single gradient+statistics buffer (sum), `rmax` the radii (max)."""
+    def reduce_flat(self, flat, rmax=None):
+        """Native-loop variant: `flat` is (a prefix of) the engine's single gradient+statistics buffer (sum), `rmax` the radii
+        (max; None outside the densification phase, when neither the statistics columns nor the radii are consumed)."""
         if self.world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
+            if rmax is not None:
+                dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
