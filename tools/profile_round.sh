@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG; mkdir -p $OUT
-python bench.py --steps 3 --warmup 1 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
+python bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile 2 > $OUT/bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
