@@ -503,9 +503,17 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       int r = grp;
       for (; r + 64 < nrows; r += 128) { a0 += (double)posepartial[(size_t)r * 32 + col]; a1 += (double)posepartial[(size_t)(r + 64) * 32 + col]; }
       if (r < nrows) a0 += (double)posepartial[(size_t)r * 32 + col];
-    } else if (pls.rows && col < NPOSE + 2) {
+    } else if (pls.rows) {   // columns 12, 13 and their helpers 14, 15 (odd row groups): L1 sum, pixel count
       // deferred masked-L1 normalisation: columns 12 / 13 sum the loss rows' L1 sum / pixel count
-      for (int r = grp; r < pls.nrows; r += 64) a0 += pls.rows[(size_t)r * 12 + (col - NPOSE)];
+      // (four independent accumulators: 19 dependent loads in a row cost ~6 us of latency in this one-workgroup kernel)
+      const double* lr = pls.rows + ((col - NPOSE) & 1);
+      double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+      int r = grp + 64 * ((col - NPOSE) >> 1);      // columns 12/13 take rows grp + 128 k, columns 14/15 rows grp + 64 + 128 k
+      for (; r + 384 < pls.nrows; r += 512) {
+        b0 += lr[(size_t)r * 12]; b1 += lr[(size_t)(r + 128) * 12]; b2 += lr[(size_t)(r + 256) * 12]; b3 += lr[(size_t)(r + 384) * 12];
+      }
+      for (; r < pls.nrows; r += 128) b0 += lr[(size_t)r * 12];
+      a0 = (b0 + b1) + (b2 + b3);
     }
     part[grp][col] = a0 + a1;
   }
@@ -528,6 +536,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   if (k == 0) {
     if (pls.rows) {
       // dL/d(image) was left unnormalised (sign * w_l1 / 3 on the masked pixels): the pose gradient is linear in it
+      tot[NPOSE] += tot[NPOSE + 2]; tot[NPOSE + 1] += tot[NPOSE + 3];
       const double npx = tot[NPOSE + 1];
       const double sc = npx > 0.0 ? 1.0 / npx : 0.0;
       for (int i = 0; i < NPOSE; i++) tot[i] *= sc;
