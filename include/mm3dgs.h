@@ -65,7 +65,7 @@ typedef struct Mm3dgsHeader {
 /* ---- buffer sizing (pure host arithmetic) ------------------------------------------------------------- */
 size_t mm3dgs_geom_bytes(int P);                       /* per-Gaussian screen-space state               */
 size_t mm3dgs_image_bytes(int H, int W);               /* header + per-tile counters/ranges + per-pixel */
-size_t mm3dgs_binning_bytes(size_t N_capacity);        /* (depth,id) keys + sub-tile lists + slot maps  */
+size_t mm3dgs_binning_bytes(size_t N_capacity);        /* (depth,id) keys + 4x4-block lists + block masks */
 size_t mm3dgs_backward_scratch_bytes(int P, size_t N_capacity); /* per-(sub-tile,splat) gradient records + camera */
 
 /* ---- forward ------------------------------------------------------------------------------------------

@@ -3,13 +3,15 @@
 //   2. scan_tiles: one workgroup turns tile_count into ranges[T+1] (num_rendered = ranges[T]) and seeds cursor[T];
 //   3. scatter: every visible Gaussian drops a 64-bit key (depth_bits << 32 | id) into each overlapped tile's bin
 //      (slot = returning atomic on the tile cursor) -- order inside a bin is arbitrary at this point;
-//   4. sort_tiles: one workgroup per tile sorts its bin in LDS (bitonic, keys unique => deterministic).  Ordering ==
-//      (depth, Gaussian index), the order a stable sort on the lineage's (tile | depth) keys produces.  The same
-//      workgroup then splits the tile's list into four depth-ordered 8x8 sub-tile lists: a splat is listed for a
-//      sub-tile only if the axis-aligned bound of { alpha >= 1/255 } reaches it (conservative, so compositing the
-//      sub-list equals compositing the full tile list), and records for every pair (Gaussian, tile) the slot the
-//      backward pass will find it under (its Gaussian-major pair index, stored next to the id) and which sub-tiles hold it.
-// HBM traffic is ~45 B/pair, versus 24 B/pair x 6 passes for a global radix sort of 64-bit keys.
+//   4. sort_tiles (sort_tile.h): one workgroup per tile sorts its bin in LDS (register bitonic runs + rank merge, keys
+//      unique => deterministic).  Ordering == (depth, Gaussian index), the order a stable sort on the lineage's
+//      (tile | depth) keys produces.  The same workgroup then splits the tile's list into sixteen depth-ordered lists, one
+//      per 4x4-pixel block: a splat is listed for a block only if the bound of { alpha >= 1/255 } reaches it (conservative,
+//      so compositing the block lists equals compositing the full tile list); every entry carries the index of the
+//      gradient record the backward pass writes for that (splat, block), and submask[pair] says which blocks list a
+//      (Gaussian, tile) pair.  In the SLAM path steps 2-3 are one launch (scatter_scan_kernel) and step 4 runs inside the
+//      forward compositing launch (composite.hip).
+// HBM traffic is ~60 B/pair touched, versus 24 B/pair x 6 passes for a global radix sort of 64-bit keys.
 #include "mm3dgs_common.h"
 #include "sort_tile.h"
 
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
     iv.hdr->overflow = 0;
   }
   __syncthreads();
-  // tiles touched per preprocess workgroup -> exclusive prefix (start of each workgroup's span in gslot)
+  // tiles touched per preprocess workgroup -> exclusive prefix (first pair index of each workgroup's Gaussians)
   uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
   if (threadIdx.x == 0) g.block_tiles[nblocks] = tot2;
   __syncthreads();

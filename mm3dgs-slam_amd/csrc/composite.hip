@@ -1,21 +1,23 @@
 // Alpha compositing (forward) and its per-pixel reverse traversal (backward) for gfx950 (wave64).
 //
-// Work decomposition: ONE WAVE PER 8x8 SUB-TILE, fully autonomous -- no workgroup barriers, no atomics.  A 256-lane
-// workgroup still maps to a 16x16 tile (its four waves are the four sub-tiles) but the waves never synchronise.
-// Each wave walks the depth-ordered list of ITS sub-tile (built by sort_tiles_kernel: exactly the tile's list minus
-// the splats whose { alpha >= 1/255 } bound cannot reach the sub-tile, so the result equals the reference rule applied
-// to every (pixel, splat) pair of the 16x16 tile):
+// Work decomposition: one 256-lane workgroup per 16x16 tile, ONE WAVE PER 8x8 SUB-TILE, ONE 16-LANE ROW PER 4x4 BLOCK --
+// fully autonomous waves: no workgroup barriers, no atomics.  Each row walks the depth-ordered list of ITS block (built by
+// sort_tile_body: exactly the tile's list minus the splats whose { alpha >= 1/255 } bound cannot reach the block, so the
+// result equals the reference rule applied to every (pixel, splat) pair of the tile):
 //   alpha = min(0.99, o * exp(power)); skip power > 0 or alpha < 1/255; stop before the splat that would push T
 //   below 1e-4; out = sum c alpha T + T_final * bg        (SURVEY.md Appendix A).
-// The list is consumed 64 entries at a time through a software pipeline: {id,i} pairs are fetched two chunks ahead,
-// the 48-byte splat records one chunk ahead (one record per lane), so the dependent gathers are in flight while the
-// current chunk is composited.  A chunk is parked in a wave-private LDS slice and broadcast-read one splat at a time
-// (the next splat's record is prefetched into registers while the current one is evaluated).
+// A wave step therefore evaluates up to four different splats (SLAM splats cover ~40 pixels; with one list per 8x8
+// sub-tile 85 % of the lanes of a step were outside the splat).  The lists are consumed 16 entries per row at a time
+// through a software pipeline: {id, record} entries are fetched two chunks ahead, the 48-byte splat records one chunk ahead
+// (one record per lane), so the dependent gathers are in flight while the current chunk is composited.  A chunk is parked
+// in a wave-private LDS slice (field-major) and read row-uniformly one splat at a time (the next splat's record is
+// prefetched into registers while the current one is evaluated).  In the SLAM path the same workgroup first sorts its
+// tile (sort_composite_fwd_kernel).
 //
-// Backward: the per-lane gradient terms of one splat (2 mean + 3 conic + 1 opacity + C colour values) are reduced
-// over the wave with a multi-value DPP butterfly (~3 VALU ops per value) and the wave -- the only writer of that
-// (sub-tile, splat) record -- stores the 48-byte record with one plain store.  preprocess_bwd later sums a
-// Gaussian's records in a fixed order, which makes the whole backward deterministic.
+// Backward: the per-lane gradient terms of one splat are reduced over the 16-lane row with DPP butterflies (generic:
+// 6 + C values, halving; SLAM modes: separable moments, 10 / 7 floats) and the row -- the only writer of that (block, splat)
+// record -- stores it with one plain store.  preprocess_bwd later sums a Gaussian's records (dense, contiguous) in a
+// fixed order, which makes the whole backward deterministic.
 #include <type_traits>
 #include "mm3dgs_common.h"
 #include "sort_tile.h"
@@ -351,19 +353,12 @@ struct SepReduce {
   }
 };
 
-__device__ __forceinline__ float xrow_sum(float v) {
-  // add the four 16-lane rows lane-wise: xor 16 through the LDS crossbar (ds_swizzle), xor 32 with permlane32_swap
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-  return __int_as_float(r[0]) + __int_as_float(r[1]);
-}
-
-// Record written per (sub-tile, splat); m = (m_x, m_y, m_xx, m_xy, m_yy) are the moments sum_p u_p (dx, dy, dx^2, dx dy, dy^2)
-// of u = dL/dG * G over the sub-tile's pixels (d/dxy and d/dconic follow from them with the splat's conic).
-// MODE 0: generic, record = m(5) dopacity(1) dcolour(C).
-// MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): record = m(5) dopacity drgb(3) dz(1) with
-//         dz = sum w (dL_3 + 2 z dL_5) -- the chain rule of the depth bundle folded into the reduction (10 values, not 12).
-// MODE 2: SLAM tracking: record = m(5) dz (6 values): opacity / colour gradients are never consumed.
+// Record written per (4x4 block, splat); the moments m = sum_p u_p (1, dx, dy, dx^2, dx dy, dy^2) of u = dL/dG * G over the
+// block's pixels give d/dxy and d/dconic with the splat's conic (preprocess_bwd).
+// MODE 0: generic, record = [m_x m_y m_xx m_xy m_yy | dopacity | dcolour(C)].
+// MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy] with cz = sum w (dL_3 + 2 z dL_5)
+//         -- the chain rule of the depth bundle folded into the reduction -- and dopacity = M0 / opacity (10 floats, not 12).
+// MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
 template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,

@@ -100,7 +100,7 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   {
     const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
     const int w = maxx - minx, area = w * (maxy - miny);
-    {  // workgroup-local exclusive scan of tiles touched (start of this Gaussian's span in gslot)
+    {  // workgroup-local exclusive scan of tiles touched (this Gaussian's first pair index)
       __shared__ uint32_t wtot[PP_BLOCK / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
       __shared__ uint32_t wtot2[PP_BLOCK / 64];
@@ -175,7 +175,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   const bool skip_g = (flags & MM3DGS_BWD_SKIP_GAUSSIAN_GRADS) != 0;
   const int nsh = shs ? 3 : 0;
   const int ne = C - nsh;
-  // ---- gather this Gaussian's screen-space gradient: sum of the records its (sub-tile, splat) pairs wrote, in a
+  // ---- gather this Gaussian's screen-space gradient: sum of the records its (block, splat) pairs wrote, in a
   // fixed order (deterministic).  A Gaussian covering more than 32 tiles is summed by the whole wave.
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   {
