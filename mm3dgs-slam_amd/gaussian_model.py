@@ -132,11 +132,20 @@ class GaussianModel:
         return out
 
     def prune_points(self, mask):
-        keep = ~mask
-        self._assign(self._rebuild_groups(lambda n, p: p[keep], lambda n, s: s[keep]))
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
+        # ONE nonzero (one host sync) shared by the ~24 tensors instead of a boolean-mask gather (= nonzero + sync) per
+        # tensor; nothing to prune (the common case in SLAM: two pruning steps per frame) leaves every tensor, parameter
+        # object and Adam moment in place -- the same values the rebuild would produce
+        idx = torch.nonzero(~mask, as_tuple=False).squeeze(1)
+        if idx.numel() == mask.numel():
+            # the rebuild would hand the optimiser fresh parameters WITHOUT gradients, which is what makes the reference's
+            # optimizer.step() of a pruning iteration a no-op: keep that
+            for group in self.optimizer.param_groups:
+                group["params"][0].grad = None
+            return
+        self._assign(self._rebuild_groups(lambda n, p: p.index_select(0, idx), lambda n, s: s.index_select(0, idx)))
+        self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, idx)
+        self.denom = self.denom.index_select(0, idx)
+        self.max_radii2D = self.max_radii2D.index_select(0, idx)
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling,
                               new_rotation, new_rgb):
