@@ -18,7 +18,7 @@ import time
 import torch
 
 from .loss_utils import pearson_loss, rel_pose_loss
-from .pose_utils import propagate_const_vel, propagate_imu
+from .pose_utils import propagate_const_vel, propagate_const_vel_np, propagate_imu
 
 
 class _FrozenMap:
@@ -118,8 +118,8 @@ class Tracker:
             if idx - 2 >= 0:
                 # 7-float algebra: one device->host copy and host arithmetic instead of ~100 one-element device kernels
                 # (2.5 ms per frame on MI355X); run_frame moves the prediction back to the device
-                both = torch.stack([poses[idx - 1].detach(), poses[idx - 2].detach()]).cpu()
-                cam = propagate_const_vel(both[0], both[1])
+                both = torch.stack([poses[idx - 1].detach(), poses[idx - 2].detach()]).cpu().numpy()
+                cam = torch.from_numpy(propagate_const_vel_np(both[0], both[1])).float()
         elif model == "imu":
             assert imu_meas is not None, "IMU measurements must be provided"
             if idx - 2 >= 0:

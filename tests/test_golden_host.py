@@ -114,3 +114,21 @@ def test_g7_seeding_pointcloud():
     mask = (d["depth"] > 0).reshape(-1)
     cld, msd = m.get_pointcloud(d["color"], d["depth"], pose_utils.get_camera_from_tensor(d["pose"]), mask=mask)
     close(cld, d["cld"], 2e-5); close(msd, d["msd"]); close(torch.log(torch.sqrt(msd)), d["log_scale"])
+
+
+def test_numpy_constant_velocity_prediction_matches_the_torch_one():
+    """Tracker.predict_pose runs propagate_const_vel_np on the host; it must agree with propagate_const_vel (itself pinned to
+    the reference's utils/pose_utils.py:203-216 by the G1 fixture) for every quaternion branch."""
+    import numpy as np
+    import torch
+    from mm3dgs_slam_amd.pose_utils import propagate_const_vel, propagate_const_vel_np
+    gen = torch.Generator().manual_seed(11)
+    for _ in range(200):
+        a = torch.randn(7, generator=gen); b = a + 0.05 * torch.randn(7, generator=gen)
+        a[:4] = a[:4] / a[:4].norm() * (0.5 + torch.rand(1, generator=gen)); b[:4] = b[:4] / b[:4].norm()
+        want = propagate_const_vel(a.double(), b.double()).numpy()
+        got = propagate_const_vel_np(a.numpy(), b.numpy())
+        # q and -q are the same rotation: compare up to the sign convention of the branch
+        if np.dot(want[:4], got[:4]) < 0:
+            got = np.concatenate([-got[:4], got[4:]])
+        assert np.abs(want - got).max() < 1e-5, (want, got)
