@@ -250,7 +250,16 @@ class FusedMapper(Mapper):
                 stack = list(keyframe_idx_list)
             return stack.pop(randint(0, len(stack) - 1))
 
+        view_cache = {}
+
         def view_of(k):
+            # the window holds a handful of distinct views; the ~150 picks of a frame reuse their (pose, target, reference)
+            # tensors instead of re-deriving them with torch calls while the GPU waits for the next run to be enqueued
+            if k not in view_cache:
+                view_cache[k] = _view_of(k)
+            return view_cache[k]
+
+        def _view_of(k):
             if k == -1:
                 pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
             else:
