@@ -259,7 +259,12 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       }
     };
     auto mask_of = [&](uint32_t gi, bool have) -> unsigned long long { return (have && gi < N_cap) ? (unsigned long long)bn.submask[gi] : 0ull; };
-    if (area <= 32) {
+    // Small splats (<= 8 tiles, <= 32 blocks: nearly all of a SLAM map) are summed by their own lane; the rest go through
+    // the wave's flat work list below -- one lane walking the hundreds of records of a 30-pixel splat alone was a
+    // 60 us tail on a 20 us kernel once a few dozen such splats had grown in the map.
+    const int nblk = br.bw * br.bh;
+    const bool isbig = area > 8 || nblk > 32;
+    if (!isbig) {
       // four pairs (64 mask bits) per round; the first round covers almost every SLAM splat
       int tx = 0, ty = 0;   // tile of pair k0 inside the splat's tile rectangle (row-major, width tw)
       for (int k0 = 0; __ballot(k0 < area) != 0ull; k0 += 4) {
@@ -274,34 +279,104 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
         drain(M, ox, oy, br.bw, rec0);
       }
     }
-    unsigned long long big = __ballot(area > 32);
-    const int lane = threadIdx.x & 63;
-    while (big) {
-      const int src = __ffsll((long long)big) - 1;
-      big &= big - 1;
-      const int sarea = __builtin_amdgcn_readlane(area, src);
-      const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
-      const float4 k0 = acc0, k1 = acc1, k2 = acc2;
-      acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
-      // the whole wave sums the big splat `src`: its rectangle / record base are broadcast, lane l takes pairs l, l + 64, ...
-      BlkRect sq;
-      sq.bx0 = __builtin_amdgcn_readlane(br.bx0, src); sq.by0 = __builtin_amdgcn_readlane(br.by0, src);
-      sq.bw = __builtin_amdgcn_readlane(br.bw, src); sq.bh = __builtin_amdgcn_readlane(br.bh, src);
-      const uint32_t srec0 = __builtin_amdgcn_readlane(rec0, src);
-      const int smnx = __builtin_amdgcn_readlane(tminx, src), smny = __builtin_amdgcn_readlane(tminy, src), stw = __builtin_amdgcn_readlane(tw, src);
-      for (int kb = 0; kb < sarea; kb += 64) {     // wave-uniform trip count (drain votes across the wave)
-        const int k = kb + lane, kty = k / stw, ktx = k - kty * stw;
-        const int ox[4] = {(smnx + ktx) * 4 - sq.bx0, 0, 0, 0}, oy[4] = {(smny + kty) * 4 - sq.by0, 0, 0, 0};
-        drain(mask_of(sgoff + (uint32_t)k, k < sarea), ox, oy, sq.bw, srec0);
-      }
-      float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
+    // ---- flat work list of the wave's big splats: item = one 4x4 block of a big splat's block rectangle (its records are
+    // contiguous: record = rec0 + position).  The S items of the wave are cut into 64 equal contiguous spans, one per lane;
+    // a lane sums the records of its span (validity from the block masks) and adds the partial sums of each owner it
+    // crosses to that owner's accumulator in LDS.  Same code, same data, same lane order every run -> deterministic.
+    const int lane = threadIdx.x & 63, wvq = threadIdx.x >> 6;
+    if (__ballot(isbig && area > 0) != 0ull) {
+      __shared__ int s_par[FB / 64][64][8];
+      __shared__ uint32_t s_pref[FB / 64][64];
+      __shared__ float s_acc[FB / 64][64][12];
+      const bool own = isbig && area > 0;
+      uint32_t incl = own ? (uint32_t)nblk : 0u;
 #pragma unroll
-      for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
-      if (lane == src) {
-        acc0 = make_float4(v[0], v[1], v[2], v[3]); acc1 = make_float4(v[4], v[5], v[6], v[7]);
-        acc2 = make_float4(v[8], v[9], v[10], v[11]);
-      } else {
-        acc0 = k0; acc1 = k1; acc2 = k2;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+      }
+      const uint32_t S = __builtin_amdgcn_readlane(incl, 63);
+      s_pref[wvq][lane] = incl;
+      int* par = s_par[wvq][lane];
+      par[0] = (int)rec0; par[1] = br.bw; par[2] = br.bx0; par[3] = br.by0; par[4] = tminx; par[5] = tminy; par[6] = tw; par[7] = (int)goff;
+#pragma unroll
+      for (int qv = 0; qv < 12; qv++) s_acc[wvq][lane][qv] = 0.f;
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t cpl = (S + 63u) / 64u;                       // items per lane
+      const uint32_t i0 = min(S, (uint32_t)lane * cpl), i1 = min(S, i0 + cpl);
+      int owner = 0;
+      {   // first owner: smallest o with pref[o] > i0
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+          const int mid = (lo + hi) >> 1;
+          if (s_pref[wvq][mid] > i0) hi = mid; else lo = mid + 1;
+        }
+        owner = min(lo, 63);
+      }
+      float pa[12];
+#pragma unroll
+      for (int qv = 0; qv < 12; qv++) pa[qv] = 0.f;
+      int cur = owner;
+      auto flush = [&](int o) {
+#pragma unroll
+        for (int qv = 0; qv < (TRACK ? 8 : 12); qv++) atomicAdd(&s_acc[wvq][o][qv], pa[qv]);
+#pragma unroll
+        for (int qv = 0; qv < 12; qv++) pa[qv] = 0.f;
+      };
+      constexpr int UF = 4;                                         // items in flight per lane
+      for (uint32_t t0 = 0; t0 < cpl; t0 += UF) {                  // wave-uniform trip count
+        int ow[UF];
+        uint32_t recq[UF];
+        uint32_t mk[UF];
+        int Lq[UF];
+        bool have[UF];
+#pragma unroll
+        for (int u = 0; u < UF; u++) {
+          const uint32_t i = i0 + t0 + (uint32_t)u;
+          have[u] = i < i1;
+          while (have[u] && owner < 63 && i >= s_pref[wvq][owner]) owner++;
+          ow[u] = owner;
+          const int* pp = s_par[wvq][owner];
+          const uint32_t excl = owner ? s_pref[wvq][owner - 1] : 0u;
+          const int j = have[u] ? (int)(i - excl) : 0;
+          const int bw = max(pp[1], 1);
+          int by = (int)(((float)j + 0.5f) / (float)bw);
+          if (by * bw > j) by--;
+          if ((by + 1) * bw <= j) by++;
+          const int bx = j - by * bw;
+          const int ax = pp[2] + bx, ay = pp[3] + by;                 // global block coordinates
+          const int k = ((ay >> 2) - pp[5]) * pp[6] + ((ax >> 2) - pp[4]);
+          Lq[u] = 4 * ((((ay >> 1) & 1) * 2) + ((ax >> 1) & 1)) + (ay & 1) * 2 + (ax & 1);
+          recq[u] = (uint32_t)pp[0] + (uint32_t)j;
+          const uint32_t gi = (uint32_t)pp[7] + (uint32_t)k;
+          mk[u] = (have[u] && gi < N_cap) ? (uint32_t)bn.submask[gi] : 0u;
+        }
+        float4 a[UF], b4[UF], c4[UF];
+        bool on[UF];
+#pragma unroll
+        for (int u = 0; u < UF; u++) {
+          on[u] = (mk[u] >> Lq[u]) & 1u;
+          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)recq[u] * (TRACK ? 8 : SPLAT_F) : (size_t)0));
+          a[u] = r[0]; b4[u] = r[1];
+          if (!TRACK) c4[u] = r[2];
+        }
+#pragma unroll
+        for (int u = 0; u < UF; u++) {
+          if (have[u] && ow[u] != cur) { flush(cur); cur = ow[u]; }
+          if (on[u]) {
+            pa[0] += a[u].x; pa[1] += a[u].y; pa[2] += a[u].z; pa[3] += a[u].w;
+            pa[4] += b4[u].x; pa[5] += b4[u].y; pa[6] += b4[u].z; pa[7] += b4[u].w;
+            if (!TRACK) { pa[8] += c4[u].x; pa[9] += c4[u].y; pa[10] += c4[u].z; pa[11] += c4[u].w; }
+          }
+        }
+      }
+      if (i0 < i1) flush(cur);
+      __builtin_amdgcn_wave_barrier();
+      if (own) {
+        const float* sa = s_acc[wvq][lane];
+        acc0 = make_float4(sa[0], sa[1], sa[2], sa[3]); acc1 = make_float4(sa[4], sa[5], sa[6], sa[7]);
+        acc2 = make_float4(sa[8], sa[9], sa[10], sa[11]);
       }
     }
   }
