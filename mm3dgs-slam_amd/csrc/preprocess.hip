@@ -10,6 +10,7 @@
 #include "mm3dgs_common.h"
 
 #include "mm3dgs_math.h"
+#include "gather_records.h"
 
 __global__ void __launch_bounds__(PP_BLOCK)
 preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
@@ -179,70 +180,23 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   // fixed order (deterministic).  A Gaussian covering more than 32 tiles is summed by the whole wave.
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   {
-    uint32_t goff = 0;
+    // one round of independent loads, then the shared gather (gather_records.h: small splats per lane, big ones through the
+    // wave's flat work list)
+    uint32_t goff = 0, r0 = 0, r1 = 0, rec_first = 0;
     int area = 0;
-    if (idx < P && radii[idx] > 0) {
-      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
-      area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
-      goff = g.block_tiles[idx >> 8] + g.tileoff[idx];
-    }
-    // gradient records: dense and contiguous per Gaussian (row-major over its block rectangle, mm3dgs_common.h); the 16-bit
-    // block mask of each (Gaussian, tile) pair says which blocks of that tile hold one
-    BlkRect br = {0, 0, 0, 0};
-    uint32_t rec0 = 0;
-    int tminx = 0, tminy = 0, tw = 1;
-    if (area > 0) {
+    float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;
+    if (idx < P) {
+      r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
+      const uint32_t toff = g.tileoff[idx], boff = g.blkoff[idx], btile = g.block_tiles[idx >> 8], bblk = g.block_blk[idx >> 8];
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
-      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
-      br = block_rect(spl[0], spl[1], r0, r1);
-      rec0 = g.block_blk[idx >> 8] + g.blkoff[idx];
-      tminx = r0 & 0xffff; tminy = r0 >> 16; tw = max((int)(r1 & 0xffff) - tminx, 1);
-    }
-    // pair k of a splat with tile rectangle origin (mnx, mny), width w, block rectangle q, first record base
-    auto add_pair = [&](uint32_t gi, int k, const BlkRect& q, uint32_t base, int mnx, int mny, int w) {
-      if (gi >= N_cap) return;
-      const uint32_t m = bn.submask[gi];
-      if (!m) return;
-      const int ty = k / w, tx = k - ty * w;
-      const int ox = (mnx + tx) * 4 - q.bx0, oy = (mny + ty) * 4 - q.by0;
-      for (int Lb = 0; Lb < NLIST; Lb++) {   // one record per 4x4 block that lists the splat
-        if (m & (1u << Lb)) {
-          const int bx = ox + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oy + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
-          const float4* r = (const float4*)(dsub + (size_t)(base + (uint32_t)(by * q.bw + bx)) * SPLAT_F);
-          const float4 a = r[0], b = r[1], c = r[2];
-          acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
-          acc1.x += b.x; acc1.y += b.y; acc1.z += b.z; acc1.w += b.w;
-          acc2.x += c.x; acc2.y += c.y; acc2.z += c.z; acc2.w += c.w;
-        }
-      }
-    };
-    if (area <= 32)
-      for (int k = 0; k < area; k++) add_pair(goff + (uint32_t)k, k, br, rec0, tminx, tminy, tw);
-    unsigned long long big = __ballot(area > 32);
-    const int lane = threadIdx.x & 63;
-    while (big) {
-      const int src = __ffsll((long long)big) - 1;
-      big &= big - 1;
-      const int sarea = __builtin_amdgcn_readlane(area, src);
-      const uint32_t sgoff = __builtin_amdgcn_readlane(goff, src);
-      const float4 k0 = acc0, k1 = acc1, k2 = acc2;  // keep this lane's own sum
-      acc0 = make_float4(0.f, 0.f, 0.f, 0.f); acc1 = acc0; acc2 = acc0;
-      BlkRect sq;
-      sq.bx0 = __builtin_amdgcn_readlane(br.bx0, src); sq.by0 = __builtin_amdgcn_readlane(br.by0, src);
-      sq.bw = __builtin_amdgcn_readlane(br.bw, src); sq.bh = __builtin_amdgcn_readlane(br.bh, src);
-      const uint32_t srec0 = __builtin_amdgcn_readlane(rec0, src);
-      const int smnx = __builtin_amdgcn_readlane(tminx, src), smny = __builtin_amdgcn_readlane(tminy, src), stw = __builtin_amdgcn_readlane(tw, src);
-      for (int k = lane; k < sarea; k += 64) add_pair(sgoff + (uint32_t)k, k, sq, srec0, smnx, smny, stw);
-      float v[12] = {acc0.x, acc0.y, acc0.z, acc0.w, acc1.x, acc1.y, acc1.z, acc1.w, acc2.x, acc2.y, acc2.z, acc2.w};
-#pragma unroll
-      for (int q = 0; q < 12; q++) v[q] = wave_sum(v[q]);
-      if (lane == src) {
-        acc0 = make_float4(v[0], v[1], v[2], v[3]); acc1 = make_float4(v[4], v[5], v[6], v[7]);
-        acc2 = make_float4(v[8], v[9], v[10], v[11]);
-      } else {
-        acc0 = k0; acc1 = k1; acc2 = k2;
+      sA = spl[0]; sB = spl[1];
+      if (r1 != r0) {   // <=> radii > 0
+        area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
+        goff = btile + toff;
+        rec_first = bblk + boff;
       }
     }
+    gather_records<3, SPLAT_F, PP_BLOCK>(area, goff, r0, r1, sA, sB, rec_first, dsub, bn, N_cap, acc0, acc1, acc2);
   }
   if (idx < P) {
     float dmean[3] = {0.f, 0.f, 0.f};
