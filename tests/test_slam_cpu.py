@@ -101,3 +101,64 @@ def test_dense_covisibility_ratio_equals_the_index_list_formulation():
         for thr in (0.1, 0.5, 0.95):
             if abs(float(want) - thr) > 0.02:
                 assert bool(got > thr) == bool(mp.is_covisible(pts, cur, H, W, threshold=thr))
+
+
+def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeypatch):
+    """FusedMapper.optimize_map hands runs of iterations to the C loop (mm3dgs_slam_map) and keeps the pruning iterations
+    in Python: check the grouping against the per-iteration rule of slam/mapper.py:887-942 with a recording fake engine
+    (control flow only -- the kernels are covered by the GPU suite)."""
+    import torch
+    from mm3dgs_slam_amd import fused
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+
+    class FakeEngine:
+        H, W = 24, 32
+        def __init__(self):
+            self.calls, self.P = [], 0
+            self.grads = {}
+        def forward(self, pose, g, need_grads=False):
+            self.P = g._xyz.shape[0]
+            self.calls.append(("forward",))
+            return "si"
+        def loss_call(self, *a):
+            self.calls.append(("loss",))
+        def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None, map_adam=None):
+            self.calls.append(("backward", grads is not None, stats is not None, map_adam is not None))
+        def map_loop(self, views, g, lcfg, stats, map_adam):
+            self.calls.append(("map_loop", len(views), stats is not None, int(map_adam.step)))
+        def check_capacity(self):
+            self.calls.append(("check",))
+
+    for (d_from, d_until, interval, iters) in ((0, 50, 50, 150), (10, 30, 10, 45), (0, 0, 50, 7), (5, 100, 4, 12)):
+        cfg = default_config(device="cpu", height=24, width=32,
+                             mapping={"iters": iters, "densify_from_iter": d_from, "densify_until_iter": d_until, "pruning_interval": interval})
+        g = GaussianModel(cfg); g.training_setup()
+        n = 50
+        g.densification_postfix(torch.randn(n, 3), torch.randn(n, 1, 3), torch.zeros(n, 0, 3), torch.zeros(n, 1), torch.full((n, 3), -3.0),
+                                torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1), torch.rand(n, 3))
+        eng = FakeEngine()
+        monkeypatch.setattr(fused.FusedEngine, "eligible", staticmethod(lambda cfg, gaussians: True))
+        monkeypatch.setattr(fused, "_engine", lambda renderer: eng)
+        mp = fused.FusedMapper(cfg, g, renderer=None, estimate_pose_list=[None])
+        mp.camera_extent = 10.0
+        pose = torch.tensor([1.0, 0, 0, 0, 0, 0, 0])
+        mp.optimize_map(3, iters, [-1], None, pose, torch.rand(3, 24, 32), torch.rand(24, 32), torch.rand(24, 32))
+        # expected sequence from the per-iteration rule
+        prune = lambda it: it <= d_until and it >= d_from and it % interval == 0
+        want, it, step = [], 0, 1
+        while it < iters:
+            densify = it <= d_until
+            if prune(it):
+                want += [("forward",), ("loss",), ("backward", True, densify, False)]     # gradients only: the Adam step is a no-op
+                it += 1
+                continue
+            m = 1
+            while it + m < iters and not prune(it + m) and ((it + m) <= d_until) == densify:
+                m += 1
+            want.append(("map_loop", m, densify, step))
+            step += m
+            it += m
+        want.append(("check",))
+        assert eng.calls == want, (d_from, d_until, interval, iters, eng.calls, want)
+        assert sum(c[1] for c in eng.calls if c[0] == "map_loop") + sum(1 for c in eng.calls if c[0] == "backward") == iters
