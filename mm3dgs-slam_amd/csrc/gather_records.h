@@ -55,11 +55,11 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
       }
     };
     auto mask_of = [&](uint32_t gi, bool have) -> unsigned long long { return (have && gi < N_cap) ? (unsigned long long)bn.submask[gi] : 0ull; };
-    // Small splats (<= 8 tiles, <= 32 blocks: nearly all of a SLAM map) are summed by their own lane; the rest go through
+    // Small splats (<= 4 tiles, <= 20 blocks: nearly all of a SLAM map; thresholds measured) are summed by their own lane; the rest go through
     // the wave's flat work list below -- one lane walking the hundreds of records of a 30-pixel splat alone was a
     // 60 us tail on a 20 us kernel once a few dozen such splats had grown in the map.
     const int nblk = br.bw * br.bh;
-    const bool isbig = area > 8 || nblk > 32;
+    const bool isbig = area > 4 || nblk > 20;
     if (!isbig) {
       // four pairs (64 mask bits) per round; the first round covers almost every SLAM splat
       int tx = 0, ty = 0;   // tile of pair k0 inside the splat's tile rectangle (row-major, width tw)
