@@ -175,13 +175,15 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
 /* n_iter mapping iterations enqueued back to back from C (the loop of slam/mapper.py:803-950 between two pruning steps):
  * iteration i renders view i of the window (its pose, colour target, optional reference depth), takes the mapping loss and
  * the backward pass with the map's Adam step inside (map_adam->step = step number of iteration 0, +1 per iteration);
- * `stats` (may be NULL): only max_radii2D / grad_accum / denom are used, the densification statistics of
- * slam/mapper.py:887-899.  `in->pose` is ignored.  No host synchronisation; `views` is read on the host during the call. */
+ * `grads_stats` (may be NULL): max_radii2D / grad_accum / denom = the densification statistics of slam/mapper.py:887-899;
+ * its d_* pointers, when set, receive the parameter gradients of the LAST iteration (map_adam may then be NULL: a window
+ * rank that all-reduces gradients before a common Adam step runs n_iter = 1 this way).  `in->pose` is ignored.  No host
+ * synchronisation; `views` is read on the host during the call. */
 typedef struct Mm3dgsMapView { const float* pose; const float* gt_color; const float* ref_depth_or_null; } Mm3dgsMapView;
 int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in,
                     float* out_color, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
                     size_t N_capacity, int fwd_flags, const struct Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout,
-                    float* loss4, void* backward_scratch, const Mm3dgsSlamGrads* stats, const Mm3dgsMapAdam* map_adam,
+                    float* loss4, void* backward_scratch, const Mm3dgsSlamGrads* grads_stats, const Mm3dgsMapAdam* map_adam,
                     void* stream);
 
 /* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:856-873,

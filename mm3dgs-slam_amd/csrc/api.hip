@@ -361,13 +361,16 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
 int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color,
                     int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags,
                     const Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout, float* loss4, void* backward_scratch,
-                    const Mm3dgsSlamGrads* stats, const Mm3dgsMapAdam* map_adam, void* stream) {
+                    const Mm3dgsSlamGrads* grads_stats, const Mm3dgsMapAdam* map_adam, void* stream) {
   if (n_iter < 0) return fail(-1, "n_iter < 0");
-  if (n_iter > 0 && (!views || !in || !map_adam)) return fail(-1, "NULL argument");
+  if (n_iter > 0 && (!views || !in)) return fail(-1, "NULL argument");
+  if (n_iter > 0 && !map_adam && !(grads_stats && grads_stats->d_xyz)) return fail(-1, "neither an Adam state nor gradient outputs");
   Mm3dgsSlamGrads sg;
   memset(&sg, 0, sizeof(sg));
-  if (stats) { sg.max_radii2D = stats->max_radii2D; sg.grad_accum = stats->grad_accum; sg.denom = stats->denom; }
-  Mm3dgsMapAdam ad = *map_adam;
+  if (grads_stats) sg = *grads_stats;
+  Mm3dgsMapAdam ad;
+  memset(&ad, 0, sizeof(ad));
+  if (map_adam) ad = *map_adam;
   Mm3dgsSlamInputs si = *in;
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
@@ -377,7 +380,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
     rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
     if (rc) return rc;
     rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
-                              nullptr, nullptr, &ad, stream);
+                              nullptr, nullptr, map_adam ? &ad : nullptr, stream);
     if (rc) return rc;
     ad.step++;
   }

@@ -125,8 +125,9 @@ class FusedEngine:
                                               _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
                                               C.byref(pose_adam), _stream()))
 
-    def map_loop(self, views, g, lcfg, stats, map_adam):
-        """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...]."""
+    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+        """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...].  With `grads`
+        (and map_adam None) the gradients of the last view are written out instead of stepped (multi-GPU window)."""
         P = int(g._xyz.shape[0])
         self._ensure(P, True)
         si = self.inputs(views[0][0], g)
@@ -134,15 +135,19 @@ class FusedEngine:
         for i, (pose, gt_color, ref) in enumerate(views):
             arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
         sg = None
-        if stats is not None:
+        if stats is not None or grads is not None:
             sg = _lib.Mm3dgsSlamGrads()
-            sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
+            if stats is not None:
+                sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
+            if grads is not None:
+                sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
+                sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
         flags = 1 | (2 if self.max_tile_len <= 1400 else 0)
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
                                             _p(self.dL), _p(self.loss), _p(self.scratch), C.byref(sg) if sg is not None else None,
-                                            C.byref(map_adam), _stream()))
+                                            C.byref(map_adam) if map_adam is not None else None, _stream()))
 
     def check_capacity(self):
         """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
@@ -292,6 +297,23 @@ class FusedMapper(Mapper):
                     continue
                 k = self.window.take(pop) if self.window is not None else pop()
                 pose, gt_color, ref = view_of(k)
+                if multi and not prune_at(iteration):
+                    # this rank's view of the window step: forward, loss and backward in one C call, then the all-reduce
+                    P = int(g._xyz.shape[0])
+                    eng._ensure(P, True)
+                    if densify:
+                        eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
+                        eng.map_loop([(pose, gt_color, ref)], g, lcfg, eng.stat_delta, None, grads=eng.grads)
+                        self.window.reduce_flat(eng.flat, eng.stat_delta[0])
+                        g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
+                        g.xyz_gradient_accum += eng.stat_delta[1]
+                        g.denom += eng.stat_delta[2]
+                    else:
+                        eng.map_loop([(pose, gt_color, ref)], g, lcfg, None, None, grads=eng.grads)
+                        self.window.reduce_flat(eng.flat[:14 * P])
+                    self._adam_step(eng)
+                    iteration += 1
+                    continue
                 si = eng.forward(pose, g, need_grads=True)
                 eng.loss_call(lcfg, gt_color, ref)
                 if multi:
