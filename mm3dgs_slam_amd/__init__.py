@@ -1,12 +1,8 @@
-"""Importable alias of the ``mm3dgs-slam_amd/`` source directory (a hyphen cannot appear in a Python module name).
+"""mm3dgs_slam_amd -- MI355X-native differentiable 3D-Gaussian rasterizer + pose/map optimisation hot path
+behind MM3DGS-SLAM's render boundary (reference: slam/renderer.py, slam/tracker.py, slam/mapper.py).
 
-``import mm3dgs_slam_amd`` executes ``mm3dgs-slam_amd/__init__.py`` with this package's ``__path__`` pointing at
-that directory, so ``mm3dgs_slam_amd.rasterizer`` etc. resolve to the files stored there.
+The compute path is the C-ABI library ``csrc/libmm3dgs_hip.so`` (hand-written HIP for gfx950).  There is no CPU or
+PyTorch fallback: importing ``mm3dgs_slam_amd.rasterizer`` works without the library (so host logic can be unit
+tested), but any render call raises if the library is missing or the tensors are not on a GPU.
 """
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mm3dgs-slam_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+__version__ = "0.1.0"
