@@ -13,6 +13,16 @@ G5 covariance        utils/general_utils.py: build_scaling_rotation -> strip_sym
 G6 render glue       slam/renderer.py Renderer.render with a recording stub rasterizer: the exact kwargs / settings
                      the reference hands to the rasterizer for transform_means_python x force_isotropic
 G7 seeding           slam/mapper.py get_pointcloud + the scale/opacity/rotation initialisation on a 32x24 RGB-D
+G8 losses            utils/loss_utils.py: l1_loss (:64-68, with and without mask), ssim (:95-154) and their autograd
+                     gradients w.r.t. the rendered image, the mapping photometric loss 0.8 L1 + 0.2 (1 - SSIM)
+                     (slam/mapper.py:856-858) with its gradient, rel_pose_loss (:20-40) values and gradients, and
+                     pearson_loss (:43-61).  torchmetrics is not installed here: the reference's `pearson_corrcoef`
+                     import is bound to scipy.stats.pearsonr (an independent third-party implementation of the same
+                     textbook definition torchmetrics.functional.regression.pearson_corrcoef computes), so the
+                     Pearson rows pin the reference's masking / min-of-two-targets logic, not torchmetrics' arithmetic.
+
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py g8         # only the named fixture(s)
 """
 import os
 import sys
@@ -63,7 +73,10 @@ def stub_modules():
         m = types.ModuleType(name)
         sys.modules.setdefault(name, m)
     sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = object
-    sys.modules["torchmetrics.functional.regression"].pearson_corrcoef = lambda a, b: None
+    def _pearson(a, b):
+        from scipy.stats import pearsonr
+        return torch.tensor(pearsonr(a.detach().double().numpy().ravel(), b.detach().double().numpy().ravel())[0], dtype=torch.float64)
+    sys.modules["torchmetrics.functional.regression"].pearson_corrcoef = _pearson
     return calls
 
 
@@ -71,10 +84,69 @@ def t2n(x):
     return x.detach().cpu().numpy()
 
 
+def make_g8():
+    """Loss fixture: the reference's own loss functions on seeded 48x64 images / poses."""
+    from utils import loss_utils
+    g = torch.Generator().manual_seed(8)
+    H, W = 48, 64
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    base = torch.stack([0.5 + 0.4 * torch.sin(xx / 7.0 + c) * torch.cos(yy / 5.0 - c) for c in range(3)])
+    gt = (base + 0.05 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    img = (base + 0.08 * torch.randn(3, H, W, generator=g) + 0.03).clamp(0, 1)
+    sil = (torch.rand(H, W, generator=g) * 0.2 + 0.85).clamp(0, 1)
+    depth = 2.0 + 0.5 * torch.sin(xx / 9.0) + 0.02 * torch.randn(H, W, generator=g)
+    ref_depth = depth + 0.05 * torch.randn(H, W, generator=g) + 0.1 * torch.cos(yy / 6.0)
+    ref_depth[torch.rand(H, W, generator=g) < 0.08] = 0
+    out = dict(img=t2n(img), gt=t2n(gt), sil=t2n(sil), depth=t2n(depth), ref_depth=t2n(ref_depth))
+    mask = sil > 0.99
+    x = img.clone().requires_grad_(True)
+    l1 = loss_utils.l1_loss(x, gt); l1.backward()
+    out["l1"], out["d_l1"] = t2n(l1), t2n(x.grad)
+    x = img.clone().requires_grad_(True)
+    l1m = loss_utils.l1_loss(x, gt, mask); l1m.backward()
+    out["l1_masked"], out["d_l1_masked"] = t2n(l1m), t2n(x.grad)
+    x = img.clone().requires_grad_(True)
+    s = loss_utils.ssim(x, gt); s.backward()
+    out["ssim"], out["d_ssim"] = t2n(s), t2n(x.grad)
+    out["ssim_per_image"] = t2n(loss_utils.ssim(img[None], gt[None], size_average=False))
+    x = img.clone().requires_grad_(True)
+    lam = 0.2
+    photo = (1.0 - lam) * loss_utils.l1_loss(x, gt) + lam * (1.0 - loss_utils.ssim(x, gt)); photo.backward()
+    out["map_photo"], out["d_map_photo"], out["lambda_dssim"] = t2n(photo), t2n(x.grad), np.float32(lam)
+    # Pearson: values only (the stub is not differentiable); both call patterns of the reference
+    out["pearson_track_est"] = t2n(loss_utils.pearson_loss(depth, ref_depth.clamp_min(0.5), mask=mask, invert_estimate=True))
+    out["pearson_track_gt"] = t2n(loss_utils.pearson_loss(depth, ref_depth, mask=mask & (ref_depth > 0), invert_estimate=True))
+    out["pearson_map_est"] = t2n(loss_utils.pearson_loss(depth, ref_depth.clamp_min(0.5), invert_estimate=False))
+    out["pearson_map_gt"] = t2n(loss_utils.pearson_loss(depth, ref_depth, mask=ref_depth > 0, invert_estimate=False))
+    # rel_pose_loss (slam/tracker.py:146-155 call pattern: current pose with grad, initial pose constant)
+    poses = torch.randn(16, 7, generator=g)
+    poses[:, :4] = torch.nn.functional.normalize(poses[:, :4], dim=1)
+    cur = poses.clone()
+    cur[:, :4] = torch.nn.functional.normalize(cur[:, :4] + 0.05 * torch.randn(16, 4, generator=g), dim=1) * (0.9 + 0.2 * torch.rand(16, 1, generator=g))
+    cur[:, 4:] += 0.03 * torch.randn(16, 3, generator=g)
+    tl, ql, dt, dq = [], [], [], []
+    for c, i in zip(cur, poses):
+        c1 = c.clone().requires_grad_(True)
+        t_l, q_l = loss_utils.rel_pose_loss(c1, i)
+        tl.append(t_l.detach()); ql.append(q_l.detach())
+        t_l.backward(retain_graph=True); dt.append(c1.grad.clone()); c1.grad = None
+        q_l.backward(); dq.append(c1.grad.clone())
+    out.update(rel_cur=t2n(cur), rel_init=t2n(poses), rel_t=t2n(torch.stack(tl)), rel_q=t2n(torch.stack(ql)),
+               rel_dt=t2n(torch.stack(dt)), rel_dq=t2n(torch.stack(dq)))
+    np.savez(os.path.join(OUT, "g8_loss.npz"), **out)
+
+
 def main():
     calls = stub_modules()
     torch.manual_seed(0)
     from utils import general_utils, graphics_utils, pose_utils, sh_utils
+    only = [a.lower() for a in sys.argv[1:]]
+    if only:
+        with _CpuMode():
+            for name in only:
+                {"g8": make_g8}[name]()
+        print("written:", only)
+        return
 
     with _CpuMode():
         # ---- G1
@@ -174,6 +246,7 @@ def main():
         cld, msd = ref_mapper.Mapper.get_pointcloud(fake, color, depth, w2c, mask=mask, compute_mean_sq_dist=True)
         np.savez(os.path.join(OUT, "g7_seed.npz"), color=t2n(color), depth=t2n(depth), pose=t2n(pose), cld=t2n(cld), msd=t2n(msd),
                  log_scale=t2n(torch.log(torch.sqrt(msd))), intr=np.array([25.9, 25.8, 15.9, 12.7]))
+        make_g8()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

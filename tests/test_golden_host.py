@@ -132,3 +132,52 @@ def test_numpy_constant_velocity_prediction_matches_the_torch_one():
         if np.dot(want[:4], got[:4]) < 0:
             got = np.concatenate([-got[:4], got[4:]])
         assert np.abs(want - got).max() < 1e-5, (want, got)
+
+
+def test_g8_losses_match_the_reference():
+    """utils/loss_utils.py l1_loss / ssim / mapping photometric loss: values and autograd gradients (G8)."""
+    from mm3dgs_slam_amd import loss_utils
+    d = load("g8_loss.npz")
+    img, gt, mask = d["img"], d["gt"], d["sil"] > 0.99
+
+    def val_grad(fn):
+        x = img.clone().requires_grad_(True)
+        v = fn(x)
+        v.backward()
+        return v.detach(), x.grad
+
+    for fn, kv, kg in ((lambda x: loss_utils.l1_loss(x, gt), "l1", "d_l1"),
+                       (lambda x: loss_utils.l1_loss(x, gt, mask), "l1_masked", "d_l1_masked"),
+                       (lambda x: loss_utils.ssim(x, gt), "ssim", "d_ssim"),
+                       (lambda x: 0.8 * loss_utils.l1_loss(x, gt) + 0.2 * (1.0 - loss_utils.ssim(x, gt)), "map_photo", "d_map_photo")):
+        v, g = val_grad(fn)
+        close(v, d[kv], 2e-6)
+        assert (g.double() - d[kg].double()).norm() <= 2e-5 * d[kg].double().norm(), kg
+    close(loss_utils.ssim(img[None], gt[None], size_average=False), d["ssim_per_image"], 2e-6)
+
+
+def test_g8_pearson_call_patterns():
+    """pearson_loss (utils/loss_utils.py:43-61) as slam/tracker.py:127-144 and slam/mapper.py:859-873 call it."""
+    from mm3dgs_slam_amd import loss_utils
+    d = load("g8_loss.npz")
+    depth, ref, mask = d["depth"], d["ref_depth"], d["sil"] > 0.99
+    close(loss_utils.pearson_loss(depth, ref.clamp_min(0.5), mask=mask, invert_estimate=True), d["pearson_track_est"].float(), 2e-5)
+    close(loss_utils.pearson_loss(depth, ref, mask=mask & (ref > 0), invert_estimate=True), d["pearson_track_gt"].float(), 2e-5)
+    close(loss_utils.pearson_loss(depth, ref.clamp_min(0.5), invert_estimate=False), d["pearson_map_est"].float(), 2e-5)
+    close(loss_utils.pearson_loss(depth, ref, mask=ref > 0, invert_estimate=False), d["pearson_map_gt"].float(), 2e-5)
+
+
+def test_g8_rel_pose_loss():
+    """rel_pose_loss (utils/loss_utils.py:20-40): values and gradients w.r.t. the current pose (slam/tracker.py:146-155)."""
+    from mm3dgs_slam_amd import loss_utils
+    d = load("g8_loss.npz")
+    for i in range(d["rel_cur"].shape[0]):
+        c = d["rel_cur"][i].clone().requires_grad_(True)
+        t_l, q_l = loss_utils.rel_pose_loss(c, d["rel_init"][i])
+        close(t_l.detach(), d["rel_t"][i], 1e-6)
+        close(q_l.detach(), d["rel_q"][i], 2e-5)
+        t_l.backward(retain_graph=True)
+        close(c.grad, d["rel_dt"][i], 1e-5)
+        c.grad = None
+        q_l.backward()
+        close(c.grad, d["rel_dq"][i], 2e-4)

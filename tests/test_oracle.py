@@ -94,3 +94,71 @@ def test_argument_validation():
         rasterize_ref(case["means3D"], None, case["opacities"], None, None, case["scales"], case["rotations"], None, s)
     with pytest.raises(ValueError):
         rasterize_ref(case["means3D"], None, case["opacities"], None, case["colors"], None, None, None, s)
+
+
+# ---- the oracle's own pieces against the fixtures the reference's Python produced (tests/golden/make_golden.py) ---------
+def _golden(name):
+    import os
+    import numpy as np
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", name)).items()}
+
+
+def test_oracle_sh_basis_matches_reference_eval_sh():
+    """sh_to_rgb_ref (the basis the rasterizer oracle evaluates) == utils/sh_utils.py eval_sh, degrees 0..3 (G3)."""
+    from oracle.raster_ref import sh_to_rgb_ref
+    d = _golden("g3_sh.npz")
+    sh = d["sh"].double().permute(0, 2, 1)[:, :16]            # reference layout [P,3,25] -> oracle layout [P,M,3]
+    for deg in range(4):
+        got = sh_to_rgb_ref(deg, sh, d["dirs"].double())
+        assert (got - d[f"deg{deg}"].double()).abs().max() < 2e-6, deg
+
+
+def test_oracle_rotation_and_covariance_match_reference_helpers():
+    """quat_to_rot_ref / cov3d_ref == utils/general_utils.py build_rotation / build_scaling_rotation -> strip_symmetric (G5)."""
+    from oracle.raster_ref import cov3d_ref, cov6_to_mat, quat_to_rot_ref
+    d = _golden("g5_cov.npz")
+    qn = torch.nn.functional.normalize(d["r"].double(), dim=1)      # the reference normalises inside build_rotation
+    assert (quat_to_rot_ref(qn) - d["R"].double()).abs().max() < 2e-6
+    S = cov3d_ref(d["s"].double(), qn, 1.0)
+    assert (S - cov6_to_mat(d["cov6"].double())).abs().max() < 1e-5 * d["cov6"].abs().max()
+    L = d["L"].double()
+    assert (S - L @ L.transpose(1, 2)).abs().max() < 1e-5 * d["cov6"].abs().max()
+
+
+def test_oracle_rotation_matches_reference_pose_algebra():
+    """quat_to_rot_ref == the rotation block of utils/pose_utils.py get_camera_from_tensor (G1: 64 poses)."""
+    from oracle.raster_ref import quat_to_rot_ref
+    d = _golden("g1_pose.npz")
+    qn = torch.nn.functional.normalize(d["poses"][:, :4].double(), dim=1)
+    assert (quat_to_rot_ref(qn) - d["w2c"][:, :3, :3].double()).abs().max() < 2e-6
+
+
+def test_oracle_projection_conventions_match_reference_glue():
+    """The oracle fed with exactly what the reference's Renderer hands its rasterizer (G6, transform_means_python false:
+    viewmatrix = w2c^T, projmatrix = viewmatrix @ P^T, campos) projects the means where the reference's own
+    pose + projection matrix put them (utils/graphics_utils.py:85-94, slam/renderer.py:117-124)."""
+    from oracle.raster_ref import RefSettings, preprocess_ref
+    d = _golden("g6_glue.npz")
+    g4 = _golden("g4_proj.npz")
+    H, W = 48, 64
+    tag = "tm0_iso0"
+    dt = torch.float64
+    s = RefSettings(H, W, float(d[f"{tag}_tanfov"][0]), float(d[f"{tag}_tanfov"][1]), torch.zeros(3, dtype=dt), 1.0,
+                    d[f"{tag}_view"].to(dt), d[f"{tag}_proj"].to(dt), 0, d[f"{tag}_campos"].to(dt))
+    means = d[f"{tag}_means3D"].to(dt)
+    P = means.shape[0]
+    pre = preprocess_ref(means, None, d[f"{tag}_opacities"].to(dt), None, torch.zeros(P, 3, dtype=dt), d[f"{tag}_scales"].to(dt),
+                         d[f"{tag}_rotations"].to(dt), None, s)
+    # independent statement with the reference's pose algebra (G1-pinned) and pinhole intrinsics
+    from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
+    w2c = get_camera_from_tensor(d["pose"]).to(dt)
+    cam = means @ w2c[:3, :3].t() + w2c[:3, 3]
+    fx, fy, cx, cy = 51.73, 51.65, 31.86, 25.53
+    u = fx * cam[:, 0] / cam[:, 2] + cx
+    v = fy * cam[:, 1] / cam[:, 2] + cy
+    vis = cam[:, 2] > 0.2
+    assert (pre["depth"][vis] - cam[vis, 2]).abs().max() < 1e-6
+    # ndc -> pixel: ((ndc + 1) * S - 1) / 2 is the pixel-centre convention of a pinhole with principal point (cx, cy) - 0.5
+    assert (pre["xy"][vis, 0] - (u[vis] - 0.5)).abs().max() < 2e-4
+    assert (pre["xy"][vis, 1] - (v[vis] - 0.5)).abs().max() < 2e-4
+    assert g4["P"].shape[0] == 4
