@@ -52,9 +52,11 @@ typedef struct Mm3dgsCamera {
 /* Header at offset 0 of the image-state buffer; counters are written by the device. */
 typedef struct Mm3dgsHeader {
   uint32_t num_rendered; /* N = sum of tiles touched (the reference lineage's `num_rendered`) */
-  uint32_t overflow;     /* 1 if N exceeded the binning capacity of the call (output then incomplete) */
-  uint32_t max_tile_len; /* longest per-tile list */
-  uint32_t reserved0;
+  uint32_t overflow;     /* 1 if N exceeded the binning capacity of a call (output then incomplete).  STICKY in the fused
+                            SLAM path (persistent state, MM3DGS_FWD_STATE_CLEAN): set by any forward since the host last
+                            cleared it, so one read after a whole optimisation loop sees an overflow of ANY iteration */
+  uint32_t max_tile_len; /* longest per-tile list (fused SLAM path: maximum since the host last cleared it) */
+  uint32_t max_num_rendered; /* fused SLAM path: maximum N since the host last cleared it (capacity model) */
   /* diagnostics, only counted when the environment variable MM3DGS_STATS=1 (adds atomics; not for timing runs) */
   uint32_t fwd_wave_iters; /* (wave, splat) evaluations executed by the forward compositor  */
   uint32_t bwd_wave_iters; /* (wave, splat) evaluations that reached the gradient reduction */
@@ -148,6 +150,11 @@ typedef struct Mm3dgsMapAdam {
 
 typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
   float* pose; float* m; float* v; int32_t* step; float lr_q, lr_t, beta1, beta2, eps;
+  /* optional IMU relative-pose residual added to the tracking loss (utils/loss_utils.py:20-40 rel_pose_loss, used at
+   * slam/tracker.py:146-155): w_t * |t - t0|^2 + w_q * 2 acos(|normalize(q (x) conj(q0))_w|), (q0, t0) = prior_pose[7]
+   * (device; the pose the optimisation started from).  NULL or both weights 0: no residual.  At q == q0 the angle term's
+   * autograd gradient is NaN in the reference (acos'(1) = -inf times 0); here it is taken as 0 there. */
+  const float* prior_pose; float prior_w_t, prior_w_q;
 } Mm3dgsPoseAdam;
 
 /* flags for mm3dgs_slam_forward */

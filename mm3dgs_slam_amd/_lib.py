@@ -20,7 +20,7 @@ class Mm3dgsCamera(C.Structure):
 
 class Mm3dgsHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("max_tile_len", C.c_uint32),
-                ("reserved0", C.c_uint32), ("fwd_wave_iters", C.c_uint32), ("bwd_wave_iters", C.c_uint32),
+                ("max_num_rendered", C.c_uint32), ("fwd_wave_iters", C.c_uint32), ("bwd_wave_iters", C.c_uint32),
                 ("bwd_wave_visits", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
@@ -45,7 +45,8 @@ class Mm3dgsMapView(C.Structure):
 
 class Mm3dgsPoseAdam(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_float),
-                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("prior_pose", C.c_void_p), ("prior_w_t", C.c_float), ("prior_w_q", C.c_float)]
 
 
 class Mm3dgsLossConfig(C.Structure):

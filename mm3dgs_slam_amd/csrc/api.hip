@@ -215,7 +215,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
-  if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s); }
+  if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
   const bool fused_sort = slam_fused_sort(flags);
   if (tl && !fused_sort) return fail(-1, "internal: folded tracking loss needs the fused sort path");
@@ -234,7 +234,8 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
 static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
-                              const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl) {
+                              const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl,
+                              float* prior_loss4 = nullptr) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
@@ -260,6 +261,9 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     if (!pose_adam->m || !pose_adam->v || !pose_adam->step) return fail(-2, "pose Adam state missing");
     pa.pose = pose_adam->pose; pa.m = pose_adam->m; pa.v = pose_adam->v; pa.step = pose_adam->step;
     pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = pose_adam->eps;
+    if (pose_adam->prior_pose && (pose_adam->prior_w_t != 0.f || pose_adam->prior_w_q != 0.f)) {
+      pa.prior = pose_adam->prior_pose; pa.prior_w_t = pose_adam->prior_w_t; pa.prior_w_q = pose_adam->prior_w_q;
+    }
   }
   MapAdam ma;
   memset(&ma, 0, sizeof(ma));
@@ -277,7 +281,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4); }
   return check_launch("slam_backward");
 }
 
@@ -352,7 +356,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
       if (rc) return rc;
     }
     rc = slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                            nullptr, pose_adam, nullptr, stream, fold ? &tl : nullptr);
+                            nullptr, pose_adam, nullptr, stream, fold ? &tl : nullptr, loss4);
     if (rc) return rc;
   }
   return 0;

@@ -50,7 +50,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t* src, uint32_t* dst
   return *carry_s;
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nblocks, GeomView g, ImageView iv) {
+// sticky: persistent state buffers (fused SLAM path) -- overflow / max_tile_len / max_num_rendered accumulate over forwards
+// until the host clears them, so one header read after an optimisation loop sees an overflow of any of its iterations
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nblocks, GeomView g, ImageView iv, int sticky) {
   __shared__ uint32_t wave_tot[SCAN_BLOCK / 64];
   __shared__ uint32_t carry_s;
   __shared__ uint32_t maxlen_s;
@@ -59,8 +61,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
   if (threadIdx.x == 0) {
     iv.ranges[T] = total;
     iv.hdr->num_rendered = total;
-    iv.hdr->max_tile_len = maxlen_s;
-    iv.hdr->overflow = 0;
+    iv.hdr->max_tile_len = sticky ? max(iv.hdr->max_tile_len, maxlen_s) : maxlen_s;
+    iv.hdr->max_num_rendered = sticky ? max(iv.hdr->max_num_rendered, total) : total;
+    if (!sticky) iv.hdr->overflow = 0;
   }
   __syncthreads();
   // tiles touched per preprocess workgroup -> exclusive prefix (first pair index of each workgroup's Gaussians)
@@ -71,8 +74,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
   uint32_t tot3 = block_excl_scan(g.block_blk, g.block_blk, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
   if (threadIdx.x == 0) g.block_blk[nblocks] = tot3;
 }
-void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s) {
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, (P + 255) / 256, g, iv);
+void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, int sticky) {
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, (P + 255) / 256, g, iv, sticky);
 }
 
 // ---- 3. scatter -----------------------------------------------------------------------------------------------
@@ -192,8 +195,10 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
     if (tid == 0) {
       iv.ranges[T] = total;
       iv.hdr->num_rendered = total;
-      iv.hdr->max_tile_len = maxlen_s;
-      iv.hdr->overflow = total > N_cap ? 1u : 0u;
+      // sticky (this kernel only runs on persistent state): the host clears these three after it has read them
+      iv.hdr->max_tile_len = max(iv.hdr->max_tile_len, maxlen_s);
+      iv.hdr->max_num_rendered = max(iv.hdr->max_num_rendered, total);
+      if (total > N_cap) iv.hdr->overflow = 1u;
     }
   }
   if (blockIdx.x == (gridDim.x > 1 ? 1 : 0)) {

@@ -389,7 +389,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 // R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
 // betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
 __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
-                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls) {
+                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4) {
   // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
   // added in a fixed order (deterministic, double precision)
   __shared__ double part[64][16];
@@ -397,13 +397,19 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   __shared__ double tot[16];
   const int k = threadIdx.x;
   // lane 0's pose / Adam state: requested first, lands while the rows are summed (this kernel is pure latency)
-  float pin[4] = {1.f, 0.f, 0.f, 0.f}, pcur[7], am[7], av[7];
+  float pin[4] = {1.f, 0.f, 0.f, 0.f}, pcur[7], am[7], av[7], prior[7], ptr_in[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 7; i++) { pcur[i] = 0.f; am[i] = 0.f; av[i] = 0.f; }
+  for (int i = 0; i < 7; i++) { pcur[i] = 0.f; am[i] = 0.f; av[i] = 0.f; prior[i] = 0.f; }
   int step0 = 0;
   if (k == 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) pin[i] = pose_in[i];    // the quaternion the render used (chain rule)
+    if (ad.prior) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) prior[i] = ad.prior[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) ptr_in[i] = pose_in[4 + i];
+    }
     if (ad.pose) {
 #pragma unroll
       for (int i = 0; i < 7; i++) { pcur[i] = ad.pose[i]; am[i] = ad.m[i]; av[i] = ad.v[i]; }
@@ -478,6 +484,31 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     float grad[7];
     for (int i = 0; i < 4; i++) grad[i] = (dq[i] - qn[i] * dot) * inv;
     for (int i = 0; i < 3; i++) grad[4 + i] = (float)tot[9 + i];
+    if (ad.prior) {
+      // IMU relative-pose residual (utils/loss_utils.py:20-40, slam/tracker.py:146-155), on the RAW pose like the reference:
+      //   w_t |t - t0|^2 + w_q 2 acos(|d_w|),  d = normalize(q (x) conj(q0))   (Hamilton product, utils/pose_utils.py:219-237)
+      const float w2 = prior[0], x2 = -prior[1], y2 = -prior[2], z2 = -prior[3];
+      const float d0 = w0 * w2 - x0 * x2 - y0 * y2 - z0 * z2, d1 = w0 * x2 + x0 * w2 + y0 * z2 - z0 * y2;
+      const float d2 = w0 * y2 - x0 * z2 + y0 * w2 + z0 * x2, d3 = w0 * z2 + x0 * y2 - y0 * x2 + z0 * w2;
+      const float dn = fmaxf(sqrtf(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3), 1e-12f), idn = 1.f / dn;
+      const float u0 = d0 * idn, u1 = d1 * idn, u2 = d2 * idn, u3 = d3 * idn;
+      const float s2 = 1.f - u0 * u0;
+      float t_l = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; i++) { const float e = ptr_in[i] - prior[4 + i]; t_l += e * e; grad[4 + i] += ad.prior_w_t * 2.f * e; }
+      const float ang = 2.f * acosf(fminf(fabsf(u0), 1.f));
+      if (s2 > 0.f) {     // at q == q0 the reference's autograd yields NaN (acos'(1) = -inf times 0); taken as 0 here
+        const float coef = ad.prior_w_q * -2.f * (u0 < 0.f ? -1.f : 1.f) / sqrtf(s2);
+        // dL/dd = coef (e_w - u_w u) / |d|, then through the (linear) Hamilton product
+        const float g0 = coef * (1.f - u0 * u0) * idn, g1 = coef * (-u0 * u1) * idn, g2 = coef * (-u0 * u2) * idn, g3 = coef * (-u0 * u3) * idn;
+        grad[0] += g0 * w2 + g1 * x2 + g2 * y2 + g3 * z2;
+        grad[1] += -g0 * x2 + g1 * w2 - g2 * z2 + g3 * y2;
+        grad[2] += -g0 * y2 + g1 * z2 + g2 * w2 - g3 * x2;
+        grad[3] += -g0 * z2 - g1 * y2 + g2 * x2 + g3 * w2;
+      }
+      float* l4 = pls.loss4 ? pls.loss4 : ad_loss4;
+      if (l4) l4[0] += ad.prior_w_t * t_l + ad.prior_w_q * ang;    // after the image terms were written (same stream)
+    }
     if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
     if (ad.pose) {
       const int t = step0 + 1;
@@ -499,7 +530,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls) {
+                                const PoseLossScale* pls, float* loss4) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
@@ -515,7 +546,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
   {
     PoseLossScale none = {nullptr, 0, 0.f, nullptr};
     hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad,
-                       pls ? *pls : none);
+                       pls ? *pls : none, loss4);
   }
 }
 

@@ -11,7 +11,7 @@ struct SlamGrads {
   float* max_radii2D; float* grad_accum; float* denom;
 };
 struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float lr[5]; float beta1, beta2, eps, bc1, bc2s; int on; };
-struct PoseAdam { float* pose; float* m; float* v; int* step; float lr_q, lr_t, beta1, beta2, eps; };
+struct PoseAdam { float* pose; float* m; float* v; int* step; float lr_q, lr_t, beta1, beta2, eps; const float* prior; float prior_w_t, prior_w_q; };
 struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float lr; };
 struct AdamArgs { AdamGroup grp[8]; int ngroups; float beta1, beta2, eps, bc1, bc2s; };
 struct LossCfg {
@@ -43,7 +43,7 @@ void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial,
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls = nullptr);
+                                const PoseLossScale* pls = nullptr, float* loss4 = nullptr);
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
                                float* dsub, hipStream_t s, const TrackLoss* tl = nullptr);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)

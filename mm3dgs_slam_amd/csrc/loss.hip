@@ -114,7 +114,7 @@ loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __re
     const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
     loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);   // acc[2] (SSIM) untouched
   }
-  block_sums<12>(acc, red);
+  block_sums<12>(acc, red, cfg.w_pearson != 0.f);
   // one row of partial sums per workgroup (plain stores): 14k double atomics on two cache lines cost ~90 us
   if (threadIdx.x == 0) {
     double* row = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;

@@ -6,15 +6,24 @@
 #include "mm3dgs_common.h"
 #include "fused_api.h"
 
-// sum of NR per-lane values over the 256-lane workgroup: float DPP reduction inside each wave (<= 64 addends), the four
-// wave totals are combined in double by lane 0 (valid in lane 0 only)
-template <int NR>
-__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR]) {
+// sum of NR per-lane values over the 256-lane workgroup (valid in lane 0 only).  Entries < NF (sums of non-negative terms:
+// L1 sum / count, SSIM sum) take a float DPP reduction inside each wave (<= 64 addends); entries >= NF (the Pearson moments
+// n, x, xx, t, tt, xt: the covariances are later formed as stt - st^2 / n, where mean^2 / variance reaches 1e5 on the
+// 1 / (ref + 200) branch, so a 1e-7 relative rounding of the sums would become 1e-2 on the correlation) stay in double.
+template <int NR, int NF = 3>
+__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR], bool tail_on = true) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NR; k++) {
-    const float t = wave_sum_to_lane63((float)v[k]);
-    if (lane == 63) sh[wv][k] = (double)t;
+    if (k < NF) {
+      const float t = wave_sum_to_lane63((float)v[k]);
+      if (lane == 63) sh[wv][k] = (double)t;
+    } else if (tail_on) {       // workgroup-uniform: the Pearson term is off in most tracking configurations (all zeros then)
+      const double t = wave_sum_to_lane63_f64(v[k]);
+      if (lane == 63) sh[wv][k] = t;
+    } else if (lane == 63) {
+      sh[wv][k] = 0.0;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0)

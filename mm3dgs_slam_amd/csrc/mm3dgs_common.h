@@ -115,13 +115,14 @@ static inline BinView bin_view(void* base, size_t N) {
 
 struct BwdView {
   float* dsub;        // [16*N_cap][12] per-(4x4 block, splat) screen-space gradient records
-  float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums
+  float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums (SLAM path: float rows; generic path:
+                      // the same region read as double rows -- it is sized for doubles)
   int nrows;
 };
 static inline int bwd_rows(int P) { return (P + 255) / 256; }
 static inline size_t bwd_bytes_impl(int P, size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * NLIST * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 4, 256);
+  return align_up(N * NLIST * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 8, 256);
 }
 static inline BwdView bwd_view(void* base, int P, size_t N) {
   if (N < 1) N = 1;
@@ -197,7 +198,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
 void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* means3D, const float* shs,
                            const float* colors, const float* opac, const float* scales, const float* rots,
                            const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
-void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s);
+void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, int sticky = 0);
 void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
                          const int32_t* radii_or_null, hipStream_t s, bool scatter_only = false);
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,
@@ -227,6 +228,24 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   v += dpp_f<0x118, 0xf, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
   v += dpp_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1,3
   v += dpp_f<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2,3
+  return v;
+}
+// the same reduction on doubles (DPP on the two 32-bit halves + v_add_f64): for sums that cancel (camera gradients, Pearson
+// moments), where a float reduction's 1e-7 relative error would be amplified by |terms| / |total|
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63_f64(double v) {
+  v += dpp_d<0x111, 0xf, 0xf>(v);
+  v += dpp_d<0x112, 0xf, 0xf>(v);
+  v += dpp_d<0x114, 0xf, 0xf>(v);
+  v += dpp_d<0x118, 0xf, 0xf>(v);
+  v += dpp_d<0x142, 0xa, 0xf>(v);
+  v += dpp_d<0x143, 0xc, 0xf>(v);
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {

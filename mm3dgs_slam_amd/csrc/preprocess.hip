@@ -369,17 +369,20 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     }
   }
   if (want_cam) {
-    __shared__ float red[4][NCAM];
+    // double precision from the per-Gaussian terms up: the camera gradient is a sum of P terms of both signs, and the float
+    // error of workgroup-level partial sums showed up as 2.6e-5 on dL/dproj (bar: 1e-5); not a hot path (the SLAM loops
+    // take the pose gradient through slam_preprocess_bwd_kernel)
+    __shared__ double red[4][NCAM];
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NCAM; k++) {
-      float v = wave_sum_to_lane63(cg[k]);
+      double v = wave_sum_to_lane63_f64((double)cg[k]);
       if (lane == 63) red[wv][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < NCAM) {
       int k = threadIdx.x;
-      campartial[(size_t)blockIdx.x * 32 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      ((double*)campartial)[(size_t)blockIdx.x * 32 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     }
   }
 }
@@ -387,13 +390,13 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
 // 256 lanes: lane = 32 * rowgroup + column (27 used); strided row sums, then the 8 row groups are added in a fixed order
 // in double precision (deterministic).
 __global__ void __launch_bounds__(256)
-camgrad_finish_kernel(const float* __restrict__ campartial, int nrows, float* __restrict__ dview, float* __restrict__ dproj,
+camgrad_finish_kernel(const double* __restrict__ campartial, int nrows, float* __restrict__ dview, float* __restrict__ dproj,
                       float* __restrict__ dcampos) {
   __shared__ double part[8][32];
   const int t = threadIdx.x, col = t & 31, grp = t >> 5;
   double acc = 0.0;
   if (col < NCAM)
-    for (int r = grp; r < nrows; r += 8) acc += (double)campartial[(size_t)r * 32 + col];
+    for (int r = grp; r < nrows; r += 8) acc += campartial[(size_t)r * 32 + col];
   part[grp][col] = acc;
   __syncthreads();
   const int k = t;
@@ -430,7 +433,7 @@ void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* 
 }
 
 void launch_camgrad_finish(BwdView bw, float* dview, float* dproj, float* dcampos, hipStream_t s) {
-  hipLaunchKernelGGL(camgrad_finish_kernel, dim3(1), dim3(256), 0, s, bw.campartial, bw.nrows, dview,
+  hipLaunchKernelGGL(camgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)bw.campartial, bw.nrows, dview,
                      dproj, dcampos);
 }
 

@@ -37,6 +37,7 @@ def _p(t):
 
 class FusedEngine:
     """Owns the reusable device buffers of the fused render (state, output, gradients) for one Renderer."""
+    MIN_PAIRS = 65536      # floor of the binning capacity (pairs)
 
     def __init__(self, renderer):
         self.r = renderer
@@ -82,7 +83,7 @@ class FusedEngine:
             self.radii = self._radii_buf[:P]
             self.P = P
             self.grads = None
-        want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + 65536
+        want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + self.MIN_PAIRS
         if want > self.n_cap or (self.ratio is not None and self.n_cap > 4 * want):
             u8 = dict(dtype=torch.uint8, device=self.dev)
             self.n_cap = int(want * 1.25) if self.ratio is not None else want
@@ -92,6 +93,7 @@ class FusedEngine:
             # one flat buffer [xyz 3P | f_dc 3P | opacity P | scaling 3P | rotation 4P | accum P | denom P]: the multi-GPU
             # window all-reduces it in a single collective (window_parallel.py)
             self.flat = torch.zeros(16 * P, device=self.dev)
+            self.acc = torch.zeros(14 * P, device=self.dev)      # window-batch mode: sum of the local views' gradients
             o = [0, 3 * P, 6 * P, 7 * P, 10 * P, 14 * P, 15 * P, 16 * P]
             v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
             self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))
@@ -150,15 +152,18 @@ class FusedEngine:
                                             C.byref(map_adam) if map_adam is not None else None, _stream()))
 
     def check_capacity(self):
-        """Synchronises: reads the header of the last forward, updates the capacity model, raises on overflow."""
+        """Synchronises: reads the image-state header.  Its overflow / max_tile_len / max_num_rendered words are STICKY on the
+        device (binning.hip: set by any forward since they were last cleared), so one read after a whole optimisation loop
+        covers every iteration and every view of it.  Updates the capacity model from the LARGEST pair count seen, clears the
+        sticky words, and returns False if any forward overflowed (its tile lists were clamped, so the loop's results are
+        invalid: the caller restores its state and re-runs with the capacity this call has already raised)."""
         h = self.img_state[:16].view(torch.int32).cpu()
-        n, overflow = int(h[0]), int(h[1])
+        overflow, n_max = int(h[1]), int(h[3])
         self.max_tile_len = int(h[2])
-        self.ratio = max(self.ratio or 0.0, n / max(self.P, 1))
-        if overflow:
-            raise RuntimeError(f"mm3dgs fused render overflowed its binning capacity ({n} > {self.n_cap}); results of the "
-                               f"last optimisation loop are invalid -- capacity raised, re-run the frame")
-        return n
+        self.img_state[4:16].zero_()
+        self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
+        self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
+        return not overflow
 
     def loss_call(self, cfg, gt_color, ref):
         _lib.check(self.lib.mm3dgs_loss(C.byref(cfg), _p(self.out), _p(gt_color), _p(ref), _p(self.loss_work), _p(self.dL),
@@ -196,28 +201,37 @@ def _engine(renderer):
 class FusedTracker(Tracker):
     def optimize_cam(self, idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth=None, est_depth=None):
         trk = self.cfg["tracking"]
-        if (num_iter == 0 or self.keep_best_candidate or trk["use_imu_loss"] or not FusedEngine.eligible(self.cfg, self.gaussians)):
+        if (num_iter == 0 or self.keep_best_candidate or not FusedEngine.eligible(self.cfg, self.gaussians)):
             return super().optimize_cam(idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth, est_depth)
         eng = _engine(self.renderer)
         dev = eng.dev
         with torch.no_grad():
-            pose = torch.cat([camera_tensor_q.detach(), camera_tensor_T.detach()]).float().contiguous().clone()
-            m, v = torch.zeros(7, device=dev), torch.zeros(7, device=dev)
-            step = torch.zeros(1, dtype=torch.int32, device=dev)
+            pose0 = torch.cat([camera_tensor_q.detach(), camera_tensor_T.detach()]).float().contiguous().clone()
             w_p, pmask, ref = 0.0, 0, None
             if trk["use_depth_estimate_loss"]:
                 w_p = float(trk["pearson_weight"])
                 pmask, ref = (1, est_depth) if not self.cfg["use_gt_depth"] else (3, gt_depth)
             lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, w_p, 1, pmask, 1, 0.99)
-            ad = _lib.Mm3dgsPoseAdam()
-            ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
-            ad.lr_q, ad.lr_t = float(trk["rotation_lr"]), float(trk["position_lr"])
-            ad.beta1, ad.beta2, ad.eps = 0.9, 0.999, 1e-8
             gt_color = gt_color.contiguous()
             ref = None if ref is None else ref.contiguous()
             g = self.gaussians
-            eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
-            eng.check_capacity()
+            for attempt in range(4):
+                # everything the loop mutates (pose, Adam moments, step) is rebuilt from the starting pose, so a binning
+                # overflow anywhere in the loop (sticky header flag) is answered by re-running it with the raised capacity
+                pose = pose0.clone()
+                m, v = torch.zeros(7, device=dev), torch.zeros(7, device=dev)
+                step = torch.zeros(1, dtype=torch.int32, device=dev)
+                ad = _lib.Mm3dgsPoseAdam()
+                ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
+                ad.lr_q, ad.lr_t = float(trk["rotation_lr"]), float(trk["position_lr"])
+                ad.beta1, ad.beta2, ad.eps = 0.9, 0.999, 1e-8
+                if trk["use_imu_loss"]:      # rel_pose_loss against the pose the optimisation starts from (slam/tracker.py:87,146-155)
+                    ad.prior_pose, ad.prior_w_t, ad.prior_w_q = pose0.data_ptr(), float(trk["imu_T_weight"]), float(trk["imu_q_weight"])
+                eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
+                if eng.check_capacity():
+                    break
+            else:
+                raise RuntimeError("mm3dgs: tracking loop kept overflowing its binning capacity")
             camera_tensor_q.data.copy_(pose[:4])
             camera_tensor_T.data.copy_(pose[4:])
             self.tracking_iter_count += num_iter
@@ -230,8 +244,11 @@ class FusedMapper(Mapper):
         if not FusedEngine.eligible(self.cfg, self.gaussians):
             return super()._render_depth_sil(pose)
         eng = _engine(self.renderer)
-        eng.forward(pose.detach().float().contiguous(), self.gaussians)
-        return eng.out[3], eng.out[4]
+        for _ in range(4):
+            eng.forward(pose.detach().float().contiguous(), self.gaussians)
+            if eng.check_capacity():       # (the keyframe test synchronises on its result anyway)
+                return eng.out[3], eng.out[4]
+        raise RuntimeError("mm3dgs: render kept overflowing its binning capacity")
 
     def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                      curr_gt_depth=None, curr_est_depth=None):
@@ -278,8 +295,28 @@ class FusedMapper(Mapper):
         def prune_at(it):
             return it <= m["densify_until_iter"] and it >= m["densify_from_iter"] and it % m["pruning_interval"] == 0
 
+        import random as _random
+        multi = self.window is not None and self.window.views_per_step > 1
+        # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
+        # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
+        # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
+        snap, rng_state = g.snapshot(), _random.getstate()
+        for attempt in range(4):
+            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
+            ok = eng.check_capacity()
+            if self.window is not None and self.window.world > 1:
+                ok = not self.window.any_flag(not ok, device=eng.dev)
+            if ok:
+                break
+            g.restore(snap)
+            _random.setstate(rng_state)
+            stack = None
+        else:
+            raise RuntimeError("mm3dgs: mapping loop kept overflowing its binning capacity")
+        self.mapping_iter_count += num_iter
+
+    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
         with torch.no_grad():
-            multi = self.window is not None and self.window.world > 1
             iteration = 0
             while iteration < num_iter:
                 densify = iteration <= m["densify_until_iter"]
@@ -295,55 +332,43 @@ class FusedMapper(Mapper):
                     eng.map_loop(views, g, lcfg, stats, self._inline_adam(n))
                     iteration += n
                     continue
-                k = self.window.take(pop) if self.window is not None else pop()
-                pose, gt_color, ref = view_of(k)
-                if multi and not prune_at(iteration):
-                    # this rank's view of the window step: forward, loss and backward in one C call, then the all-reduce
-                    P = int(g._xyz.shape[0])
-                    eng._ensure(P, True)
-                    if densify:
-                        eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
-                        eng.map_loop([(pose, gt_color, ref)], g, lcfg, eng.stat_delta, None, grads=eng.grads)
-                        self.window.reduce_flat(eng.flat, eng.stat_delta[0])
-                        g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
-                        g.xyz_gradient_accum += eng.stat_delta[1]
-                        g.denom += eng.stat_delta[2]
-                    else:
-                        eng.map_loop([(pose, gt_color, ref)], g, lcfg, None, None, grads=eng.grads)
-                        self.window.reduce_flat(eng.flat[:14 * P])
-                    self._adam_step(eng)
-                    iteration += 1
-                    continue
-                si = eng.forward(pose, g, need_grads=True)
-                eng.loss_call(lcfg, gt_color, ref)
+                # one optimiser step over this rank's share of the window batch (a single view without a window)
+                ids = self.window.take(pop) if self.window is not None else [pop()]
+                P = int(g._xyz.shape[0])
+                eng._ensure(P, True)
+                prune_now = prune_at(iteration)
                 if multi:
-                    # each rank rendered a different keyframe: sum gradients (and, while densifying, the statistics) over the
-                    # window -- one flat all-reduce; the statistics tail [14P, 16P) and the radii max-reduce only when consumed
-                    P = eng.P
+                    # forward, loss and backward of each view in one C call (gradients written out, not stepped); more than
+                    # one local view (window-batch mode): summed in view order; then ONE flat all-reduce over the ranks carries
+                    # every parameter gradient and, while densifying, the statistics tail [14P, 16P) (+ a max-reduce of the radii)
                     if densify:
                         eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
-                        eng.backward(si, grads=eng.grads, stats=eng.stat_delta)
+                    for j, k in enumerate(ids):
+                        eng.map_loop([view_of(k)], g, lcfg, eng.stat_delta if densify else None, None, grads=eng.grads)
+                        if len(ids) > 1:
+                            if j == 0:
+                                eng.acc[:14 * P].copy_(eng.flat[:14 * P])
+                            else:
+                                eng.acc[:14 * P].add_(eng.flat[:14 * P])
+                    if len(ids) > 1:
+                        eng.flat[:14 * P].copy_(eng.acc[:14 * P])
+                    if densify:
                         self.window.reduce_flat(eng.flat, eng.stat_delta[0])
                         g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
                         g.xyz_gradient_accum += eng.stat_delta[1]
                         g.denom += eng.stat_delta[2]
                     else:
-                        eng.backward(si, grads=eng.grads, stats=None)
                         self.window.reduce_flat(eng.flat[:14 * P])
-                    prune_now = prune_at(iteration)
                     if not prune_now:
                         self._adam_step(eng)
                 else:
                     # a pruning iteration: gradients + statistics only (the reference prunes BEFORE optimizer.step(): the
                     # parameters are replaced, so that step is a no-op)
-                    prune_now = True
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
-                    eng.backward(si, grads=eng.grads, stats=stats)
+                    eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads)
                 if prune_now:
                     g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
                 iteration += 1
-            eng.check_capacity()
-        self.mapping_iter_count += num_iter
 
     def _inline_adam(self, n=1):
         """Mm3dgsMapAdam over the optimiser's own state tensors (created like torch.optim.Adam would on its first step);
@@ -372,7 +397,7 @@ class FusedMapper(Mapper):
         g = self.gaussians
         opt = g.optimizer
         # the group table only changes when a tensor is replaced (prune / densify): cache it on the pointers
-        key = (g._xyz.data_ptr(), eng.grads["xyz"].data_ptr(), int(g._xyz.shape[0]))
+        key = (g.generation, g._xyz.data_ptr(), eng.grads["xyz"].data_ptr(), int(g._xyz.shape[0]))
         cache = getattr(self, "_adam_cache", None)
         if cache is not None and cache[0] == key and all(float(gr["lr"]) == lr for gr, lr in zip(cache[3], cache[4])):
             _, table, n, groups, _, states = cache

@@ -42,6 +42,7 @@ class GaussianModel:
         self.optimizer = None
         self.percent_dense = 0
         self.spatial_lr_scale = 0
+        self.generation = 0        # bumped whenever the parameter tensors are replaced (prune / densify / restore)
 
     # ---- activations --------------------------------------------------------------------------------------------
     scaling_activation = staticmethod(torch.exp)
@@ -119,6 +120,7 @@ class GaussianModel:
         """Replace every group's parameter by ``transform_param(old)`` (a new leaf) and carry the Adam moments
         through ``transform_state`` -- the reference's cat/prune surgery."""
         out = {}
+        self.generation += 1
         for group in self.optimizer.param_groups:
             old = group["params"][0]
             state = self.optimizer.state.pop(old, None)
@@ -130,6 +132,34 @@ class GaussianModel:
             group["params"][0] = new
             out[group["name"]] = new
         return out
+
+    # ---- snapshot / restore (overflow recovery of the native mapping loop, fused.py) -----------------------------------
+    def snapshot(self):
+        """Copies of everything a mapping loop mutates: parameters, Adam moments and step counters, learning rates, the
+        densification statistics.  ~24 device copies (26 MB at 150 k Gaussians)."""
+        groups = []
+        for group in self.optimizer.param_groups:
+            p = group["params"][0]
+            st = self.optimizer.state.get(p, {})
+            groups.append((group["name"], p.detach().clone(), {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}, group["lr"]))
+        return dict(groups=groups, stats=(self.xyz_gradient_accum.clone(), self.denom.clone(), self.max_radii2D.clone()))
+
+    def restore(self, snap):
+        """Back to a ``snapshot()`` (which stays valid: tensors are copied again)."""
+        by_name = {name: (p, st, lr) for name, p, st, lr in snap["groups"]}
+        out = {}
+        self.generation += 1
+        for group in self.optimizer.param_groups:
+            self.optimizer.state.pop(group["params"][0], None)
+            p, st, lr = by_name[group["name"]]
+            new = nn.Parameter(p.clone().requires_grad_(True))
+            if st:
+                self.optimizer.state[new] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+            group["params"][0] = new
+            group["lr"] = lr
+            out[group["name"]] = new
+        self._assign(out)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = (t.clone() for t in snap["stats"])
 
     def prune_points(self, mask):
         # ONE nonzero (one host sync) shared by the ~24 tensors instead of a boolean-mask gather (= nonzero + sync) per

@@ -66,9 +66,16 @@ def pearson_loss(render, estimate, mask=None, invert_estimate=True):
     return 1 - pearson_corrcoef(e, r)
 
 
-def rel_pose_loss(camera_pose, initial_pose):
-    """(squared translation error, rotation angle of the relative quaternion)."""
+def rel_pose_loss(camera_pose, initial_pose, safe: bool = False):
+    """(squared translation error, rotation angle of the relative quaternion) -- utils/loss_utils.py:20-40.
+
+    ``safe=False`` is the literal reference: at ``camera_pose[:4] == initial_pose[:4]`` (which is exactly the first
+    tracking iteration, slam/tracker.py:87) the angle is acos(1) and autograd returns NaN (-inf times 0).  ``safe=True``
+    takes the gradient of the angle term as 0 where |cos| >= 1, which is what the native tracking loop does."""
     t_err = ((camera_pose[4:] - initial_pose[4:]) ** 2).sum()
     conj = initial_pose[:4].detach() * torch.tensor([1.0, -1.0, -1.0, -1.0], device=initial_pose.device)
     diff = F.normalize(quadmultiply(camera_pose[:4], conj)[None], dim=1)[0]
-    return t_err, 2 * torch.acos(diff[0].abs())
+    c = diff[0].abs()
+    if safe:
+        c = torch.where(c < 1.0, c, c.detach().clamp(max=1.0))
+    return t_err, 2 * torch.acos(c)

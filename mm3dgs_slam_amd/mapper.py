@@ -139,9 +139,44 @@ class Mapper:
                 self.covisibility_graph[key].add(kid)
                 self.covisibility_graph[kid].add(key)
 
+    def _overlap_window(self, camera_pose, gt_depth):
+        """method == 'splatam' (slam/mapper.py:289-372): rank the earlier keyframes by the fraction of 1600 randomly sampled
+        surface points of the current view (ground-truth depth, or the rendered depth where the silhouette is > 0.99) that
+        project at least 20 px inside them; keep those with a non-zero fraction, cap the window with a random subset and
+        append the most recent keyframe."""
+        if self.cfg["use_gt_depth"]:
+            depth = gt_depth
+        else:
+            d, sil = self._render_depth_sil(camera_pose)
+            depth = torch.where(sil > 0.99, d, torch.zeros_like(d))
+        H, W = depth.shape
+        valid = torch.stack(torch.where(depth > 0), dim=1)
+        if valid.shape[0] == 0:
+            scores = []
+        else:
+            pick = valid[torch.randint(valid.shape[0], (1600,)).to(valid.device)]
+            pts = self.get_depth_pointcloud(depth, get_camera_from_tensor(camera_pose), pick)
+            fx, fy, cx, cy = self._intr()
+            edge = 20
+            scores = []
+            for kid, kf in enumerate(self.keyframes[:-1]):
+                p = apply_rigid(pts, get_camera_from_tensor(kf.pose))
+                z = p[:, 2:3] + 1e-5
+                u, v = (fx * p[:, 0:1] + cx * p[:, 2:3]) / z, (fy * p[:, 1:2] + cy * p[:, 2:3]) / z
+                inside = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & (z > 0)
+                scores.append((kid, float(inside.sum()) / max(p.shape[0], 1)))
+        scores.sort(key=lambda t: t[1], reverse=True)          # (stable, like the reference's sorted())
+        keep = np.array([kid for kid, frac in scores if frac > 0.0], dtype=np.int64)
+        selected = [int(k) for k in np.random.permutation(keep)[: self.cfg["mapping"]["kf_window_size"] - 2]]
+        if self.keyframes:
+            selected.append(len(self.keyframes) - 1)
+        return selected, [self.keyframes[k].idx for k in selected]
+
     def get_covisible_set(self, idx, camera_pose, gt_color, gt_depth=None, N=1):
         if idx == 0:
             return [], []
+        if self.cfg["method"].lower() == "splatam":
+            return self._overlap_window(camera_pose, gt_depth)
         cur = len(self.keyframes) - 1
         covisible = {cur}
         for _ in range(N):
@@ -247,19 +282,27 @@ class Mapper:
                 if not stack:
                     stack = list(keyframe_idx_list)
                 return stack.pop(randint(0, len(stack) - 1))
-            k = self.window.take(pop) if self.window is not None else pop()
-            if k == -1:
-                q, T, gt_color, gt_depth, est_depth = cur_q, cur_T, curr_gt_color, curr_gt_depth, curr_est_depth
-            else:
-                kf = self.keyframes[k]
-                q, T, gt_color, gt_depth, est_depth = kf.pose[:4], kf.pose[4:], kf.gt_color, kf.gt_depth, kf.est_depth
-            result = self.renderer.render(g, camera_pose=torch.cat([q, T]))
-            loss = self._loss(result, gt_color, gt_depth, est_depth)
-            loss.backward()
+            # one optimiser step = one view (the reference, slam/mapper.py:803-807) or, with a window, this rank's share of the
+            # world x batch views of the step: autograd accumulates their gradients in .grad
+            ids = self.window.take(pop) if self.window is not None else [pop()]
+            wstats = None
+            for k in ids:
+                if k == -1:
+                    q, T, gt_color, gt_depth, est_depth = cur_q, cur_T, curr_gt_color, curr_gt_depth, curr_est_depth
+                else:
+                    kf = self.keyframes[k]
+                    q, T, gt_color, gt_depth, est_depth = kf.pose[:4], kf.pose[4:], kf.gt_color, kf.gt_depth, kf.est_depth
+                result = self.renderer.render(g, camera_pose=torch.cat([q, T]))
+                loss = self._loss(result, gt_color, gt_depth, est_depth)
+                loss.backward()
+                if self.window is not None:
+                    with torch.no_grad():
+                        wstats = self.window.merge_stats(wstats, self.window.view_stats(result["viewspace_points"], result["visibility_filter"],
+                                                                                        result["radii"]))
             with torch.no_grad():
                 reduced = None
                 if self.window is not None:
-                    reduced = self.window.reduce(g, result["viewspace_points"], result["visibility_filter"], result["radii"])
+                    reduced = self.window.reduce(g, wstats)
                 if cfg["method"].lower() == "splatam":
                     if iteration <= 20 and iteration % 20 == 0:
                         g.prune(m["min_opacity"], self.camera_extent)
@@ -284,6 +327,9 @@ class Mapper:
                 g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
                 if do_ba:
+                    if self.window is not None and self.window.world > 1:
+                        # every replica must take the identical pose step: sum the pose gradients of the ranks' views
+                        self.window.reduce_pose_grads(qs + Ts)
                     pose_opt.step()
                     pose_opt.zero_grad(set_to_none=True)
             if stats:

@@ -74,7 +74,8 @@ class Tracker:
                 loss = loss + trk["pearson_weight"] * pearson_loss(depth, gt_depth, mask=presence & (gt_depth > 0),
                                                                    invert_estimate=True)
         if trk["use_imu_loss"]:
-            t_l, q_l = rel_pose_loss(torch.cat([q, T]), initial_pose)
+            # (the reference's literal rel_pose_loss is NaN at its own starting point; tracking.imu_loss_literal restores that)
+            t_l, q_l = rel_pose_loss(torch.cat([q, T]), initial_pose, safe=not trk.get("imu_loss_literal", False))
             loss = loss + trk["imu_T_weight"] * t_l + trk["imu_q_weight"] * q_l
         return loss
 

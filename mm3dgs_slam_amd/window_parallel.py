@@ -19,29 +19,45 @@ _ORDER = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_ro
 
 
 class WindowParallel:
-    def __init__(self, rank: int, world: int, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    """``world`` ranks x ``batch`` views per rank = the window batch G of one optimiser step.
+    ``WindowParallel(0, 1, batch=G)`` is the single-GPU "window-batch = G" mode: the parity baseline of a G-rank run (the same
+    G views per step, gradients summed locally instead of by the all-reduce)."""
+
+    def __init__(self, rank: int, world: int, group=None, batch: int = 1):
+        self.rank, self.world, self.group, self.batch = rank, world, group, int(batch)
+
+    @property
+    def views_per_step(self):
+        return self.world * self.batch
 
     def take(self, pop):
-        """Pop ``world`` keyframe ids with the shared RNG; return this rank's."""
-        ids = [pop() for _ in range(self.world)]
-        return ids[self.rank]
+        """Pop ``world * batch`` keyframe ids with the shared RNG; return this rank's ``batch`` of them (a list)."""
+        ids = [pop() for _ in range(self.world * self.batch)]
+        return ids[self.rank * self.batch:(self.rank + 1) * self.batch]
 
-    def reduce(self, gaussians, viewspace_points, visibility, radii):
-        """Sum parameter gradients and densification statistics over the ranks (in place); returns
-        (grad_norm_sum[P,1], visible_count[P,1], max_radii[P])."""
+    @staticmethod
+    def view_stats(viewspace_points, visibility, radii):
+        """Densification statistics of ONE rendered view: (||d means2D|| on visible, visible as 0/1, radii on visible)."""
+        norm = torch.norm(viewspace_points.grad[:, :2], dim=-1, keepdim=True) * visibility[:, None]
+        return norm, visibility[:, None].to(norm.dtype), torch.where(visibility, radii, torch.zeros_like(radii)).to(torch.float32)
+
+    @staticmethod
+    def merge_stats(a, b):
+        return b if a is None else (a[0] + b[0], a[1] + b[1], torch.max(a[2], b[2]))
+
+    def reduce(self, gaussians, stats):
+        """Sum the parameter gradients (``.grad``, already accumulated over this rank's views by autograd) and the
+        densification statistics ``stats = (norm_sum[P,1], visible_count[P,1], max_radii[P])`` over the ranks (in place);
+        returns the reduced statistics."""
         P = gaussians._xyz.shape[0]
-        dev = gaussians._xyz.device
         cols = []
         for name in _ORDER:
             p = getattr(gaussians, name)
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             cols.append(g.reshape(P, -1))
-        vs = viewspace_points.grad
-        norm = torch.norm(vs[:, :2], dim=-1, keepdim=True) * visibility[:, None]
-        cols += [norm, visibility[:, None].to(norm.dtype)]
+        norm, count, rmax = stats
+        cols += [norm, count]
         flat = torch.cat(cols, 1).contiguous()
-        rmax = torch.where(visibility, radii, torch.zeros_like(radii)).to(torch.float32)
         if self.world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
@@ -55,6 +71,28 @@ class WindowParallel:
                 p.grad = flat[:, off:off + n].reshape(p.shape).clone()
             off += n
         return flat[:, off:off + 1], flat[:, off + 1:off + 2], rmax
+
+    def reduce_pose_grads(self, tensors):
+        """Bundle adjustment with a sharded window: each rank holds the pose gradients of ITS view only; sum them (missing
+        gradients count as zero) so that the keyframe-pose Adam step is identical on every replica."""
+        if self.world <= 1 or not tensors:
+            return
+        flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.grad = flat[off:off + n].reshape(t.shape).clone()
+            off += n
+
+    def any_flag(self, flag: bool, device="cpu") -> bool:
+        """Logical OR of a host flag over the ranks (a rank-local event such as a binning overflow must lead to the same
+        decision -- re-run the loop -- on every replica)."""
+        if self.world <= 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
 
     def reduce_flat(self, flat, rmax=None):
         """Native-loop variant: `flat` is (a prefix of) the engine's single gradient+statistics buffer (sum), `rmax` the radii

@@ -106,7 +106,7 @@ def test_native_engine_agrees_with_generic_path_at_full_size(name):
     pose = torch.tensor([0.999, 0.01, -0.02, 0.015, 0.02, -0.01, 0.03], device=DEV)
     eng = FusedEngine(R)
     si = eng.forward(pose, g, need_grads=True)
-    eng.check_capacity()
+    assert eng.check_capacity()
     p = pose.clone().requires_grad_(True)
     res = R.render(g, p)
     ref = torch.cat([res["render"], res["depth"]], 0)

@@ -7,12 +7,16 @@ from tests import parity_util as pu
 pytestmark = pytest.mark.gpu
 
 
-def _check(m, img_tol=pu.IMG_TOL, grad_tol=pu.GRAD_TOL, radii_slack=0):
+CAMERA_GRADS = ("d_view", "d_proj", "d_campos")
+
+
+def _check(m, img_tol=pu.IMG_TOL, grad_tol=pu.GRAD_TOL, radii_slack=0, pose_tol=pu.POSE_TOL):
+    """Image <= 1e-4 rel-L2, camera ("pose") gradients <= 1e-5 (north_star), per-Gaussian gradients <= GRAD_TOL."""
     assert m["img"] <= img_tol, m
     assert m["radii_mismatch"] <= radii_slack, m
     for k, v in m.items():
         if k.startswith("d_"):
-            assert v <= grad_tol, (k, m)
+            assert v <= (pose_tol if k in CAMERA_GRADS else grad_tol), (k, m)
 
 
 def test_library_loads_on_gpu():
@@ -71,7 +75,7 @@ def test_tracker_mode_skips_gaussian_grads():
     assert g_h["opacities"] is None and g_h["scales"] is None
     assert pu.rel_l2(g_h["means3D"], g_o["means3D"]) <= pu.GRAD_TOL
     assert pu.rel_l2(g_h["colors"], g_o["colors"]) <= pu.GRAD_TOL
-    assert pu.rel_l2(g_h["view"], g_o["view"]) <= pu.GRAD_TOL
+    assert pu.rel_l2(g_h["view"], g_o["view"]) <= pu.POSE_TOL
 
 
 def test_empty_and_all_culled():

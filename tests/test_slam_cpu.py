@@ -125,10 +125,13 @@ def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeyp
             self.calls.append(("loss",))
         def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None, map_adam=None):
             self.calls.append(("backward", grads is not None, stats is not None, map_adam is not None))
-        def map_loop(self, views, g, lcfg, stats, map_adam):
-            self.calls.append(("map_loop", len(views), stats is not None, int(map_adam.step)))
+        def _ensure(self, P, need_grads):
+            pass
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+            self.calls.append(("map_loop", len(views), stats is not None, int(map_adam.step) if map_adam is not None else None, grads is not None))
         def check_capacity(self):
             self.calls.append(("check",))
+            return True
 
     for (d_from, d_until, interval, iters) in ((0, 50, 50, 150), (10, 30, 10, 45), (0, 0, 50, 7), (5, 100, 4, 12)):
         cfg = default_config(device="cpu", height=24, width=32,
@@ -150,15 +153,114 @@ def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeyp
         while it < iters:
             densify = it <= d_until
             if prune(it):
-                want += [("forward",), ("loss",), ("backward", True, densify, False)]     # gradients only: the Adam step is a no-op
+                want.append(("map_loop", 1, densify, None, True))     # gradients + statistics only: the Adam step is a no-op
                 it += 1
                 continue
             m = 1
             while it + m < iters and not prune(it + m) and ((it + m) <= d_until) == densify:
                 m += 1
-            want.append(("map_loop", m, densify, step))
+            want.append(("map_loop", m, densify, step, False))
             step += m
             it += m
         want.append(("check",))
         assert eng.calls == want, (d_from, d_until, interval, iters, eng.calls, want)
-        assert sum(c[1] for c in eng.calls if c[0] == "map_loop") + sum(1 for c in eng.calls if c[0] == "backward") == iters
+        assert sum(c[1] for c in eng.calls if c[0] == "map_loop") == iters
+
+
+def test_native_mapper_restores_and_reruns_after_a_binning_overflow(monkeypatch):
+    """A forward that overflows its binning capacity anywhere in the mapping loop is reported by the sticky header flag at
+    the loop's single read-back; FusedMapper must then put the map, the optimiser state, the statistics and the
+    keyframe-pick RNG back and run the same loop again (previously it raised after the Adam steps were applied)."""
+    import random
+    import torch
+    from mm3dgs_slam_amd import fused
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+
+    class FakeEngine:
+        H, W = 24, 32
+        dev = "cpu"
+        def __init__(self, fail_first):
+            self.fail, self.picks, self.seen_xyz, self.grads = fail_first, [[]], [], {}
+        def forward(self, pose, g, need_grads=False):
+            self.picks[-1].append(float(pose[4])); return "si"
+        def loss_call(self, *a):
+            pass
+        def backward(self, si, grads=None, stats=None, dpose=None, pose_adam=None, map_adam=None):
+            pass
+        def _ensure(self, P, need_grads):
+            pass
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+            self.picks[-1] += [float(v[0][4]) for v in views]
+            self.seen_xyz.append(g._xyz.detach().clone())
+            with torch.no_grad():                     # what the in-kernel Adam would do: the map moves
+                g._xyz += 1.0
+                g.xyz_gradient_accum += 1.0
+        def check_capacity(self):
+            self.picks.append([])
+            if self.fail:
+                self.fail -= 1
+                return False
+            return True
+
+    cfg = default_config(device="cpu", height=24, width=32, mapping={"iters": 20, "densify_until_iter": 10, "pruning_interval": 50})
+    g = GaussianModel(cfg); g.training_setup()
+    n = 40
+    g.densification_postfix(torch.randn(n, 3), torch.randn(n, 1, 3), torch.zeros(n, 0, 3), torch.zeros(n, 1), torch.full((n, 3), -3.0),
+                            torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1), torch.rand(n, 3))
+    xyz0 = g._xyz.detach().clone()
+    eng = FakeEngine(fail_first=2)
+    monkeypatch.setattr(fused.FusedEngine, "eligible", staticmethod(lambda cfg, gaussians: True))
+    monkeypatch.setattr(fused, "_engine", lambda renderer: eng)
+    mp = fused.FusedMapper(cfg, g, renderer=None, estimate_pose_list=[None])
+    mp.camera_extent = 10.0
+    kfs = []
+    for i in range(4):      # four keyframes told apart by their tx
+        kfs.append(fused.Mapper.add_keyframe.__globals__["KeyFrame"](i, torch.rand(3, 24, 32), torch.tensor([1.0, 0, 0, 0, float(i + 1), 0, 0]),
+                                                                     torch.rand(24, 32), torch.rand(24, 32)))
+    mp.keyframes = kfs
+    random.seed(3)
+    mp.optimize_map(3, 20, [0, 1, 2, 3, -1], None, torch.tensor([1.0, 0, 0, 0, 0, 0, 0]), torch.rand(3, 24, 32), torch.rand(24, 32), torch.rand(24, 32))
+    attempts = [p for p in eng.picks if p]
+    assert len(attempts) == 3                                   # two overflowing runs + the good one
+    assert attempts[0] == attempts[1] == attempts[2]            # same keyframe picks every time (RNG restored)
+    assert len(attempts[0]) == 20
+    first_of_attempt = [x for i, x in enumerate(eng.seen_xyz) if i % (len(eng.seen_xyz) // 3) == 0]
+    assert all(torch.equal(x, xyz0) for x in first_of_attempt)  # every attempt started from the restored map
+    assert mp.mapping_iter_count == 20
+
+
+def test_rel_pose_loss_safe_variant_is_finite_at_the_start_and_literal_elsewhere():
+    import torch
+    from mm3dgs_slam_amd.loss_utils import rel_pose_loss
+    p0 = torch.tensor([0.9, 0.1, -0.2, 0.3, 0.5, -0.4, 1.0])
+    c = p0.clone().requires_grad_(True)
+    t_l, q_l = rel_pose_loss(c, p0, safe=True)
+    (t_l + q_l).backward()
+    assert torch.isfinite(c.grad).all() and float(q_l) == 0.0
+    c2 = (p0 + torch.tensor([0.02, -0.03, 0.01, 0.04, 0.1, 0.0, -0.1])).requires_grad_(True)
+    a = rel_pose_loss(c2, p0, safe=True)
+    ga = torch.autograd.grad(a[0] + a[1], c2)[0]
+    b = rel_pose_loss(c2, p0, safe=False)
+    gb = torch.autograd.grad(b[0] + b[1], c2)[0]
+    assert torch.equal(ga, gb) and torch.equal(a[1], b[1])
+
+
+def test_splatam_window_ranks_keyframes_by_projected_overlap():
+    """method == 'splatam': get_covisible_set is the depth-overlap selection of slam/mapper.py:289-372, not the graph walk."""
+    import numpy as np
+    import torch
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.mapper import KeyFrame, Mapper
+    cfg = default_config(device="cpu", height=96, width=128, method="splatam", mapping={"kf_window_size": 4})
+    mp = Mapper(cfg, gaussians=None, renderer=None, estimate_pose_list=[None] * 8)
+    depth = torch.full((96, 128), 2.0)
+    ident = torch.tensor([1.0, 0, 0, 0, 0, 0, 0])
+    far = torch.tensor([1.0, 0, 0, 0, 50.0, 0, 0])                 # looks at nothing the current frame sees
+    poses = [ident, far, torch.tensor([1.0, 0, 0, 0, 0.05, 0, 0]), far, torch.tensor([1.0, 0, 0, 0, -0.05, 0.02, 0]), ident]
+    mp.keyframes = [KeyFrame(10 * i, torch.zeros(3, 96, 128), p, depth) for i, p in enumerate(poses)]
+    torch.manual_seed(0); np.random.seed(0)
+    sel, times = mp.get_covisible_set(7, ident, torch.zeros(3, 96, 128), depth)
+    assert sel[-1] == len(poses) - 1 and times == [10 * k for k in sel]
+    assert len(sel) == 3                                           # kf_window_size - 2 overlapping ones + the last keyframe
+    assert set(sel[:-1]) <= {0, 2, 4}                              # never the two that see nothing

@@ -25,6 +25,13 @@ def _build(window):
     return SLAM(cfg, seq, rasterizer_cls=RefRasterizer, window=window)
 
 
+def _state(slam):
+    g = slam.gaussians
+    return {"xyz": g._xyz.detach(), "op": g._opacity.detach(), "scaling": g._scaling.detach(), "f_dc": g._features_dc.detach(),
+            "acc": g.xyz_gradient_accum.clone(), "denom": g.denom.clone(), "radii": g.max_radii2D.clone(),
+            "poses": torch.stack(slam.estimate_pose_list[:3])}
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,8 +40,7 @@ def _worker(rank, world, port, out):
     slam = _build(WindowParallel(rank, world))
     for i in range(3):
         slam.step(i)
-    torch.save({"xyz": slam.gaussians._xyz.detach(), "op": slam.gaussians._opacity.detach(),
-                "poses": torch.stack(slam.estimate_pose_list[:3])}, os.path.join(out, f"r{rank}.pt"))
+    torch.save(_state(slam), os.path.join(out, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,6 +51,22 @@ def test_two_rank_window_matches_across_ranks(tmp_path):
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert a["xyz"].shape == b["xyz"].shape and a["xyz"].shape[0] > 0
     assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["op"], b["op"]) and torch.equal(a["poses"], b["poses"])
+    # ... and what they agree on is the right thing: the single-process window-batch = 2 run (the same two views per optimiser
+    # step, gradients summed locally instead of by the all-reduce -- SURVEY.md 8e's parity baseline for a G-rank run)
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    torch.set_num_threads(2)
+    one = _build(WindowParallel(0, 1, batch=2))
+    for i in range(3):
+        one.step(i)
+    ref = _state(one)
+    for k in ref:
+        assert ref[k].shape == a[k].shape, k
+        assert torch.allclose(ref[k], a[k], rtol=1e-5, atol=1e-7), (k, (ref[k] - a[k]).abs().max())
+    # the batch really changes the optimisation (guards against a test that compares two single-view runs)
+    single = _build(WindowParallel(0, 1))
+    for i in range(3):
+        single.step(i)
+    assert not torch.allclose(_state(single)["xyz"], ref["xyz"], rtol=1e-5, atol=1e-7)
 
 
 def test_window_reduce_single_rank_is_identity():
@@ -56,7 +78,8 @@ def test_window_reduce_single_rank_is_identity():
     res = slam.renderer.render(g, pose)
     (res["render"].sum() + res["depth"].sum()).backward()
     before = g._xyz.grad.clone()
-    n, c, r = slam.mapper.window.reduce(g, res["viewspace_points"], res["visibility_filter"], res["radii"])
+    w = slam.mapper.window
+    n, c, r = w.reduce(g, w.view_stats(res["viewspace_points"], res["visibility_filter"], res["radii"]))
     assert torch.equal(before, g._xyz.grad)
     assert torch.allclose(c[:, 0], res["visibility_filter"].float()) and n.shape == (g._xyz.shape[0], 1)
     assert torch.equal(r, torch.where(res["visibility_filter"], res["radii"], torch.zeros_like(res["radii"])).float())
