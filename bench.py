@@ -50,7 +50,29 @@ def parse():
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
                     "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=50000)
+    ap.add_argument("--workload", default="slam", choices=["slam", "c5"],
+                    help="slam = BASELINE.json configs[1] (the headline line); c5 = configs[4]: synthetic 1920x1080, 3 M Gaussians, SH degree 3, "
+                         "rasterizer forward+backward sweep (a step = one render + backward of one view)")
+    ap.add_argument("--steady-frames", type=int, default=100,
+                    help="slam, 1 GPU: after the timed region keep running this many more frames and report them as `steady_state` (0 = skip)")
+    ap.add_argument("--full-seed-steps", type=int, default=10,
+                    help="slam, 1 GPU: a second run with the reference-faithful seeding (one Gaussian per valid frame-0 pixel, ~292 k), "
+                         "this many timed frames, reported as `full_seed` (0 = skip)")
+    ap.add_argument("--window-batch", type=int, default=1, help="views per rank and optimiser step in the mapping window (SURVEY 8e)")
     return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU ourselves (the contract's torchrun line does the
+    same from outside).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def instrument_phases(slam):
@@ -142,24 +164,83 @@ def pmc_traffic():
     MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950).  None when no such summary is committed."""
     import csv
     import glob
-    vals = {}
+    vals, used = {}, []
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_slam_pmc_{c}.csv")))
         if not files:
-            return None
-        rows = [r for r in csv.DictReader(open(files[-1])) if "composite_bwd_kernel<6, 1>" in r["kernel"]]
+            return None, None
+        rows = [r for r in csv.DictReader(open(files[-1])) if "composite_bwd" in r["kernel"] and ("<6, 1>" in r["kernel"] or "map" in r["kernel"])]
         if not rows:
-            return None
+            return None, None
         vals[c] = float(rows[0]["mean_counter_value"]) * 1024.0
-    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+        used.append(os.path.relpath(files[-1], ROOT))
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "replayed from " + ", ".join(used) + " (separate rocprofv3 --pmc passes; not measured in this run)"
+
+
+def c5_workload(args, rank, world, dev):
+    """BASELINE.json configs[4]: synthetic 1920x1080, 3 M Gaussians, SH degree 3 (M = 16 view-dependent coefficients, sigma 0.1),
+    forward + backward throughput of the rasterizer through the C ABI (generic path: SH colour in-kernel, all input gradients).
+    A step = one render + backward of one view; N ranks render N different views of the same map (independent: "weak")."""
+    import ctypes as C
+    from mm3dgs_slam_amd import _lib, synthetic as syn
+    from mm3dgs_slam_amd.rasterizer import GaussianRasterizationSettings, _camera, _ptr, _stream
+    lib = _lib.load()
+    H, W, P, deg = 1080, 1920, args.gaussians if args.gaussians != 150000 else 3000000, 3
+    fov = 60.0
+    import math
+    fx = fy = (W / 2) / math.tan(math.radians(fov) / 2)
+    cx, cy = W / 2 - 0.5, H / 2 - 0.5
+    color, depth = syn.rgbd_frame(H, W, seed=1)
+    G = {k: v.to(dev) for k, v in syn.seed_gaussians(color, depth, fx, fy, cx, cy, P, seed=1, isotropic=False).items()}
+    gen = torch.Generator().manual_seed(2)
+    shs = torch.cat([G["f_dc"], (torch.randn(P, 15, 3, generator=gen) * 0.1).to(dev)], 1).contiguous()
+    view, proj, campos, tx, ty = syn.camera_matrices(H, W, fx, fy, cx, cy, w2c=syn.small_pose(3 + rank, angle=0.03, trans=0.05))
+    view, proj, campos = view.to(dev), proj.to(dev), campos.to(dev)
+    bg = torch.zeros(3, device=dev)
+    rs = GaussianRasterizationSettings(H, W, tx, ty, bg, 1.0, view, proj, deg, campos, False, False)
+    cam = _camera(rs, bg, view, proj, campos)
+    means, opac = G["xyz"].contiguous(), torch.sigmoid(G["opacity"]).contiguous()
+    scales, rots = torch.exp(G["scaling"]).contiguous(), torch.nn.functional.normalize(G["rotation"]).contiguous()
+    u8 = dict(dtype=torch.uint8, device=dev)
+    out = torch.empty(3, H, W, device=dev); radii = torch.empty(P, dtype=torch.int32, device=dev)
+    geom = torch.empty(lib.mm3dgs_geom_bytes(P), **u8); img = torch.empty(lib.mm3dgs_image_bytes(H, W), **u8)
+    host_n = torch.empty(4, dtype=torch.int32).pin_memory()
+    M, Cn = 16, 3
+    fargs = (P, M, Cn, _ptr(means), _ptr(shs), None, _ptr(opac), _ptr(scales), _ptr(rots), None)
+    _lib.check(lib.mm3dgs_forward_geom(C.byref(cam), *fargs, _ptr(radii), _ptr(geom), _ptr(img), C.c_void_p(host_n.data_ptr()), _stream()))
+    torch.cuda.synchronize()
+    N = int(host_n[0]); n_cap = int(N * 1.05) + 65536
+    binning = torch.empty(lib.mm3dgs_binning_bytes(n_cap), **u8)
+    scratch = torch.empty(lib.mm3dgs_backward_scratch_bytes(P, n_cap), **u8)
+    dL = torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    d = dict(means=torch.empty(P, 3, device=dev), m2d=torch.empty(P, 3, device=dev), shs=torch.empty(P, M, 3, device=dev),
+             opac=torch.empty(P, 1, device=dev), scales=torch.empty(P, 3, device=dev), rots=torch.empty(P, 4, device=dev))
+
+    def step():
+        _lib.check(lib.mm3dgs_forward(C.byref(cam), *fargs, _ptr(out), _ptr(radii), _ptr(geom), _ptr(img), _ptr(binning), n_cap, _stream()))
+        _lib.check(lib.mm3dgs_backward(C.byref(cam), P, M, Cn, _ptr(means), _ptr(shs), None, _ptr(opac), _ptr(scales), _ptr(rots), None,
+                                       _ptr(radii), _ptr(geom), _ptr(img), _ptr(binning), n_cap, _ptr(dL), _ptr(scratch), _ptr(d["means"]),
+                                       _ptr(d["m2d"]), _ptr(d["shs"]), None, _ptr(d["opac"]), _ptr(d["scales"]), _ptr(d["rots"]), None, None,
+                                       None, None, 0, _stream()))
+    Pv = int((radii > 0).sum())
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    r = -(-(32 + (T - 1).bit_length()) // 8)
+    alg_fwd = P * (44 + 12 * M) + Pv * (36 + 4 * Cn) + 8 * P + 12 * N + 24 * N * r + 8 * N + (8 * N + 8 * T) + N * (28 + 4 * Cn) + H * W * (4 * Cn + 8)
+    alg_bwd = N * (28 + 4 * Cn) + H * W * (4 * Cn + 8) + N * (24 + 4 * Cn) + Pv * (96 + 12 * M + 4 * Cn) + Pv * (44 + 12 * M)
+    return step, dict(H=H, W=W, P=P, Pv=Pv, N=N, M=M, C=Cn, alg_fwd=alg_fwd, alg_bwd=alg_bwd,
+                      workload=f"synthetic {W}x{H}, fov {fov:.0f} deg, {P} Gaussians seeded like the reference's first frame (anisotropic jitter), "
+                               f"SH degree 3 (16 coefficients, sigma 0.1), rasterizer forward + backward with all input gradients through the "
+                               f"C ABI (generic path), {N} (tile, splat) pairs, {Pv} visible")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
     if os.environ.get("MM3DGS_BENCH_SINGLE_DEVICE"):      # plumbing test of the N > 1 path on a 1-GPU box (with --backend gloo)
@@ -182,18 +263,71 @@ def main():
     rasterizer.set_binning_policy(args.policy)
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def finish(out):
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    if args.workload == "c5":
+        step, info = c5_workload(args, rank, world, dev)
+        for _ in range(max(args.warmup, 1)):
+            step()
+        _lib.profile_read(); _lib.profile_enable(1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        _lib.profile_enable(0)
+        prof = _lib.profile_read()
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kus = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
+        gpu_s = sum(kus.values()) * 1e-6
+        H, W = info["H"], info["W"]
+        out = {"metric": "raster Mpix/s (forward + backward), synthetic 1920x1080, 3M Gaussians, SH3", "value": H * W * args.steps * world / elapsed / 1e6,
+               "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": info["workload"], "gaussians": info["P"], "image": [H, W]},
+               "kernel_us": kus,
+               "roofline": {"bound": "hbm", "kernel": "whole forward + backward pass (sum of its kernels)",
+                            "achieved": (info["alg_fwd"] + info["alg_bwd"]) / gpu_s / 1e9 if gpu_s else None, "peak": 8000.0, "unit": "GB/s",
+                            "frac": (info["alg_fwd"] + info["alg_bwd"]) / gpu_s / 1e9 / 8000.0 if gpu_s else None, "traffic": None,
+                            "algorithmic_bytes_fwd": info["alg_fwd"], "algorithmic_bytes_bwd": info["alg_bwd"],
+                            "note": "algorithmic bytes per SURVEY.md 8d (forward incl. the contract's 6-pass global radix sort term) with the measured "
+                                    "Pv and N; duration = sum of the HIP-event kernel times of one pass"}}
+        finish(out)
+        return
+
     # the reference seeds one Gaussian per valid frame-0 pixel (~292k at 640x480); BASELINE.json's configs[1] is quoted
     # at ~150k Gaussians, so the seeding is thinned to hit that count (stated in config.workload)
     frac = args.seed_fraction or min(1.0, args.gaussians / (0.95 * args.height * args.width))
-    cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
-                         mapping={"iters": args.map_iters, "seed_fraction": frac})
-    n_frames = args.warmup + args.steps + 1
+    extras = world == 1 and rank == 0
+    steady = args.steady_frames if extras else 0
+
+    def build(frac_, n_frames, n_target):
+        cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
+                             mapping={"iters": args.map_iters, "seed_fraction": frac_})
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        seq = SyntheticSequence(cfg, n_frames, n_target, seed=0)        # untimed: builds the RGB-D frames on the GPU
+        window = WindowParallel(rank, world, batch=args.window_batch) if (world > 1 or args.window_batch > 1) else None
+        return SLAM(cfg, seq, render_mode=args.render_mode, window=window)
+
     log("process warm-up (6-frame SLAM run with a few iterations per frame: loads every operator once)")
     prewarm(dev, args.height, args.width, args.gaussians, frac)
-    torch.manual_seed(0); random.seed(0); np.random.seed(0)
     log("building the synthetic RGB-D sequence")
-    seq = SyntheticSequence(cfg, n_frames, args.gaussians, seed=0)        # untimed: builds the RGB-D frames on the GPU
-    slam = SLAM(cfg, seq, render_mode=args.render_mode, window=WindowParallel(rank, world) if world > 1 else None)
+    slam = build(frac, args.warmup + args.steps + 1 + steady, args.gaussians)
     log("frame 0 (seeding + first mapping, untimed)")
     slam.step(0)                                                          # untimed: seeds the map from frame 0 (+ first mapping)
     torch.cuda.synchronize()
@@ -201,12 +335,6 @@ def main():
     torch.manual_seed(0); random.seed(0); np.random.seed(0)              # identical keyframe picks on every rank
     for i in range(1, 1 + args.warmup):
         slam.step(i)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     phases = instrument_phases(slam) if args.phases else None
     _lib.profile_read()
@@ -237,11 +365,12 @@ def main():
     N = hdr["num_rendered"]
     H, W, C = args.height, args.width, 6 if args.render_mode == "fused" else 3
     views_per_frame = args.track_iters + args.map_iters
-    frame_equiv = (args.track_iters + args.map_iters * world) / views_per_frame
+    vps = world * args.window_batch
+    frame_equiv = (args.track_iters + args.map_iters * vps) / views_per_frame
     value = args.steps * frame_equiv / elapsed
     passes = 1 if args.render_mode == "fused" else 2
     renders = args.steps * views_per_frame
-    mpix = H * W * passes * renders * (world if world > 1 else 1) / elapsed / 1e6
+    mpix = H * W * passes * renders * frame_equiv / elapsed / 1e6
 
     out = {
         "metric": "SLAM frames/sec (track+map), TUM fr1/desk-shaped 640x480", "value": value, "unit": "frames/s",
@@ -250,11 +379,13 @@ def main():
         "config": {"workload": f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, "
                                f"full track+map per frame: {args.track_iters} tracking + {args.map_iters} mapping iterations "
                                f"(reference budget), frame-0 seeding thinned to {frac:.2f} of the pixels, render_mode={args.render_mode}, "
-                               f"binning={args.policy}",
+                               f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
+                               f"the same run, `full_seed` = a second run seeded like the reference (one Gaussian per valid frame-0 pixel)",
                    "gaussians": P_now, "image": [H, W], "iterations_per_frame": views_per_frame,
-                   "multi_gpu": "mapping window sharded over ranks + all-reduce of Gaussian gradients; tracking replicated" if world > 1 else "single GPU"},
+                   "multi_gpu": (f"mapping window sharded: {world} rank(s) x {args.window_batch} view(s) per optimiser step, one all-reduce of the "
+                                 f"Gaussian gradients per step; tracking replicated") if vps > 1 else "single GPU"},
         "raster_mpix_per_s_fwd_bwd": mpix,
-        "render_iterations_per_s": renders * (frame_equiv if world > 1 else 1) / elapsed,
+        "render_iterations_per_s": renders * frame_equiv / elapsed,
         "num_rendered_pairs": N,
     }
     # ---- roofline of the dominant kernel (backward compositor) ----------------------------------------------------
@@ -263,8 +394,9 @@ def main():
         alg_bytes = N * (28 + 4 * C) + H * W * (4 * C + 8) + N * (24 + 4 * C)      # SURVEY.md 8d "Backward" composite terms
         dur = ms_bwd / n_bwd * 1e-3
         ach = alg_bytes / dur / 1e9
+        traffic, traffic_src = pmc_traffic()
         out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                           "frac": ach / 8000.0, "traffic": pmc_traffic(), "algorithmic_bytes_per_launch": alg_bytes,
+                           "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                            "avg_launch_us": dur * 1e6, "timed_launches": n_bwd,   # every 16th launch of the timed region carries an event pair
                            # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any
                            # early-out, ~25 flop + 1 exp each (SURVEY's figure), against the dense f32 VALU peak.  This
@@ -273,15 +405,41 @@ def main():
                                     "flop_per_evaluation": 25, "achieved_tflops": 256 * N * 25 / dur / 1e12,
                                     "peak_tflops": 157.3, "frac": 256 * N * 25 / dur / 1e12 / 157.3}}
         out["kernel_us"] = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
+    if steady:
+        log(f"steady state: {steady} more frames of the same run")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first = 1 + args.warmup + args.steps
+        for i in range(first, first + steady):
+            slam.step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["steady_state"] = {"frames": steady, "value": steady / el, "unit": "frames/s", "ms_per_frame": el / steady * 1e3,
+                               "gaussians_at_end": int(slam.gaussians.get_xyz.shape[0]), "keyframes": len(slam.mapper.keyframes),
+                               "note": f"frames {first}..{first + steady - 1} of the run above (same map, same budget, keyframe work included)"}
+    if extras and args.full_seed_steps and frac < 1.0:
+        log("full-seed run (one Gaussian per valid frame-0 pixel)")
+        del slam
+        torch.cuda.empty_cache()
+        slam2 = build(1.0, 2 + args.full_seed_steps + 1, int(0.95 * args.height * args.width))
+        slam2.step(0)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        for i in (1, 2):
+            slam2.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + args.full_seed_steps):
+            slam2.step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["full_seed"] = {"frames": args.full_seed_steps, "value": args.full_seed_steps / el, "unit": "frames/s", "ms_per_frame": el / args.full_seed_steps * 1e3,
+                            "gaussians": int(slam2.gaussians.get_xyz.shape[0]),
+                            "note": "reference-faithful frame-0 seeding (slam/mapper.py:437-474: every valid-depth pixel), same iteration budget"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")
         out["cpu_baseline"] = cpu_baseline(args)
         log("done")
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(out)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ CONFIGS = {
     "C2_tum_150k": (480, 640, 150000, False, 0),
     "C3_utmm_300k_iso": (330, 640, 300000, True, 0),
     "C4_replica_1M": (680, 1200, 1000000, False, 0),
-    "C5_1080p_1M_sh3": (1080, 1920, 1000000, False, 3),
+    "C5_1080p_3M_sh3": (1080, 1920, 3000000, False, 3),
 }
 
 
@@ -68,7 +68,7 @@ def test_full_size_properties(name):
     assert bool((out6[5] * sil + 1e-4 * (1 + out6[5].abs()) >= out6[3] ** 2).all())
 
 
-@pytest.mark.parametrize("name", ["C2_tum_150k", "C3_utmm_300k_iso", "C5_1080p_1M_sh3"])
+@pytest.mark.parametrize("name", ["C2_tum_150k", "C3_utmm_300k_iso", "C5_1080p_3M_sh3"])
 def test_backward_is_linear_in_the_image_gradient(name):
     sc = _scene(name)
     gen = torch.Generator(device=DEV).manual_seed(5)
