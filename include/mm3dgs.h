@@ -144,12 +144,15 @@ typedef struct Mm3dgsSlamGrads {
  * launch less).  Same formula as mm3dgs_adam / torch.optim.Adam; groups in the order xyz, f_dc, opacity, scaling, rotation.
  * When passed to mm3dgs_slam_backward the d_* outputs of Mm3dgsSlamGrads may be NULL. */
 typedef struct Mm3dgsMapAdam {
-  float* param[5]; float* exp_avg[5]; float* exp_avg_sq[5]; float lr[5];
-  float beta1, beta2, eps; int32_t step;
+  float* param[5]; float* exp_avg[5]; float* exp_avg_sq[5];
+  /* hyper-parameters are doubles, exactly the Python floats torch.optim.Adam holds: the library forms 1 - beta, the bias
+   * corrections and lr / (1 - beta1^step) in double and rounds ONCE to float, like torch does (1 - 0.999f in float arithmetic
+   * is off by 1.3e-5 relative) */
+  double lr[5]; double beta1, beta2, eps; int32_t step;
 } Mm3dgsMapAdam;
 
 typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
-  float* pose; float* m; float* v; int32_t* step; float lr_q, lr_t, beta1, beta2, eps;
+  float* pose; float* m; float* v; int32_t* step; double lr_q, lr_t, beta1, beta2, eps;   /* doubles: see Mm3dgsMapAdam */
   /* optional IMU relative-pose residual added to the tracking loss (utils/loss_utils.py:20-40 rel_pose_loss, used at
    * slam/tracker.py:146-155): w_t * |t - t0|^2 + w_q * 2 acos(|normalize(q (x) conj(q0))_w|), (q0, t0) = prior_pose[7]
    * (device; the pose the optimisation started from).  NULL or both weights 0: no residual.  At q == q0 the angle term's
@@ -211,8 +214,8 @@ int mm3dgs_loss(const Mm3dgsLossConfig* cfg, const float* out6, const float* gt_
 
 /* Fused Adam over up to 8 parameter groups in one launch (slam/gaussian_model.py:143-195; torch.optim.Adam formula).
  * step = 1-based step count used for the bias corrections. */
-typedef struct Mm3dgsAdamGroup { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; float lr; } Mm3dgsAdamGroup;
-int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float beta1, float beta2, float eps, void* stream);
+typedef struct Mm3dgsAdamGroup { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; double lr; } Mm3dgsAdamGroup;
+int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double beta1, double beta2, double eps, void* stream);
 
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of

@@ -35,8 +35,8 @@ class Mm3dgsSlamGrads(C.Structure):
 
 
 class Mm3dgsMapAdam(C.Structure):
-    _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_float * 5),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32)]
+    _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_double * 5),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32)]
 
 
 class Mm3dgsMapView(C.Structure):
@@ -44,8 +44,8 @@ class Mm3dgsMapView(C.Structure):
 
 
 class Mm3dgsPoseAdam(C.Structure):
-    _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_float),
-                ("lr_t", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+    _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_double),
+                ("lr_t", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("prior_pose", C.c_void_p), ("prior_w_t", C.c_float), ("prior_w_q", C.c_float)]
 
 
@@ -57,7 +57,7 @@ class Mm3dgsLossConfig(C.Structure):
 
 class Mm3dgsAdamGroup(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_uint64), ("lr", C.c_float)]
+                ("n", C.c_uint64), ("lr", C.c_double)]
 
 
 _P = C.c_void_p
@@ -83,7 +83,7 @@ _SIGS = {
                                   C.POINTER(Mm3dgsMapAdam), _P]),
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_loss": (C.c_int, [C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, _P]),
-    "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
+    "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _P]),
     "mm3dgs_profile_enable": (None, [C.c_int]),
     "mm3dgs_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "mm3dgs_last_error": (C.c_char_p, []),

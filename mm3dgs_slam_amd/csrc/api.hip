@@ -260,7 +260,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   if (pose_adam && pose_adam->pose) {
     if (!pose_adam->m || !pose_adam->v || !pose_adam->step) return fail(-2, "pose Adam state missing");
     pa.pose = pose_adam->pose; pa.m = pose_adam->m; pa.v = pose_adam->v; pa.step = pose_adam->step;
-    pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = pose_adam->eps;
+    pa.lr_q = pose_adam->lr_q; pa.lr_t = pose_adam->lr_t; pa.beta1 = pose_adam->beta1; pa.beta2 = pose_adam->beta2; pa.eps = (float)pose_adam->eps;
     if (pose_adam->prior_pose && (pose_adam->prior_w_t != 0.f || pose_adam->prior_w_q != 0.f)) {
       pa.prior = pose_adam->prior_pose; pa.prior_w_t = pose_adam->prior_w_t; pa.prior_w_q = pose_adam->prior_w_q;
     }
@@ -271,11 +271,12 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     if (map_adam->step < 1) return fail(-1, "map Adam step must be >= 1");
     for (int i = 0; i < 5; i++) {
       if (!map_adam->param[i] || !map_adam->exp_avg[i] || !map_adam->exp_avg_sq[i]) return fail(-2, "map Adam group %d has a NULL pointer", i);
-      ma.p[i] = map_adam->param[i]; ma.m[i] = map_adam->exp_avg[i]; ma.v[i] = map_adam->exp_avg_sq[i]; ma.lr[i] = map_adam->lr[i];
+      ma.p[i] = map_adam->param[i]; ma.m[i] = map_adam->exp_avg[i]; ma.v[i] = map_adam->exp_avg_sq[i];
+      ma.step_size[i] = (float)(map_adam->lr[i] / (1.0 - pow(map_adam->beta1, (double)map_adam->step)));
     }
-    ma.beta1 = map_adam->beta1; ma.beta2 = map_adam->beta2; ma.eps = map_adam->eps;
-    ma.bc1 = 1.f - powf(ma.beta1, (float)map_adam->step);
-    ma.bc2s = sqrtf(1.f - powf(ma.beta2, (float)map_adam->step));
+    ma.omb1 = (float)(1.0 - map_adam->beta1); ma.beta2 = (float)map_adam->beta2; ma.omb2 = (float)(1.0 - map_adam->beta2);
+    ma.eps = (float)map_adam->eps;
+    ma.bc2s = (float)sqrt(1.0 - pow(map_adam->beta2, (double)map_adam->step));
     ma.on = 1;
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
@@ -391,17 +392,17 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   return 0;
 }
 
-int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, float beta1, float beta2, float eps, void* stream) {
+int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double beta1, double beta2, double eps, void* stream) {
   if (!groups || n_groups < 0 || n_groups > 8) return fail(-1, "bad group table");
   if (step < 1) return fail(-1, "step must be >= 1");
   AdamArgs a;
-  a.ngroups = n_groups; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-  a.bc1 = 1.f - powf(beta1, (float)step);
-  a.bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  a.ngroups = n_groups; a.omb1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  a.bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
   for (int i = 0; i < n_groups; i++) {
     if (groups[i].n && (!groups[i].param || !groups[i].grad || !groups[i].exp_avg || !groups[i].exp_avg_sq)) return fail(-1, "NULL in group %d", i);
     a.grp[i].p = groups[i].param; a.grp[i].g = groups[i].grad; a.grp[i].m = groups[i].exp_avg; a.grp[i].v = groups[i].exp_avg_sq;
-    a.grp[i].n = groups[i].n; a.grp[i].lr = groups[i].lr;
+    a.grp[i].n = groups[i].n; a.grp[i].step_size = (float)(groups[i].lr / bc1);
   }
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MM3DGS_PROF_ADAM, s);

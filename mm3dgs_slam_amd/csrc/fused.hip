@@ -362,10 +362,10 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
           const int q = AG_OFF[gq] + c;
           const size_t off = (size_t)idx * AG_N[gq] + c;
           const float gr = gr14[q];
-          const float mi = am[q] + (gr - am[q]) * (1.f - ma.beta1);
-          const float vi = av[q] * ma.beta2 + gr * gr * (1.f - ma.beta2);
+          const float mi = am[q] + (gr - am[q]) * ma.omb1;                 // exp_avg.lerp_(grad, 1 - beta1)
+          const float vi = av[q] * ma.beta2 + gr * gr * ma.omb2;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
           ma.m[gq][off] = mi; ma.v[gq][off] = vi;
-          ma.p[gq][off] = ap[q] - (ma.lr[gq] / ma.bc1) * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+          ma.p[gq][off] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
         }
     }
   }
@@ -513,16 +513,18 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     if (ad.pose) {
       const int t = step0 + 1;
       *ad.step = t;
-      const float bc1 = 1.f - powf(ad.beta1, (float)t), bc2 = 1.f - powf(ad.beta2, (float)t);
-      const float bc2s = sqrtf(bc2);
+      // scalars in double, rounded once to float (torch.optim.Adam does this arithmetic on Python floats)
+      const double bc1 = 1.0 - pow(ad.beta1, (double)t);
+      const float bc2s = (float)sqrt(1.0 - pow(ad.beta2, (double)t));
+      const float omb1 = (float)(1.0 - ad.beta1), b2 = (float)ad.beta2, omb2 = (float)(1.0 - ad.beta2);
+      const float ss_q = (float)(ad.lr_q / bc1), ss_t = (float)(ad.lr_t / bc1);
       for (int i = 0; i < 7; i++) {
-        const float lr = i < 4 ? ad.lr_q : ad.lr_t;
         const float gi = grad[i];
-        const float mi = am[i] + (gi - am[i]) * (1.f - ad.beta1);      // lerp, as torch does
-        const float vi = av[i] * ad.beta2 + gi * gi * (1.f - ad.beta2);
+        const float mi = am[i] + (gi - am[i]) * omb1;      // lerp, as torch does
+        const float vi = av[i] * b2 + gi * gi * omb2;
         ad.m[i] = mi; ad.v[i] = vi;
         const float denom = sqrtf(vi) / bc2s + ad.eps;
-        ad.pose[i] = pcur[i] - (lr / bc1) * (mi / denom);
+        ad.pose[i] = pcur[i] - (i < 4 ? ss_q : ss_t) * (mi / denom);
       }
     }
   }
@@ -558,7 +560,7 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(AdamArgs a) {
   const unsigned long long stride = (unsigned long long)gridDim.x * 256;
   for (int gi = 0; gi < a.ngroups; gi++) {
     const AdamGroup G = a.grp[gi];
-    const float step = G.lr / a.bc1;
+    const float step = G.step_size;
     const bool vec = ((G.n & 3ull) == 0) && ((((uintptr_t)G.p | (uintptr_t)G.g | (uintptr_t)G.m | (uintptr_t)G.v) & 15) == 0);
     if (vec) {
       const unsigned long long n4 = G.n >> 2;
@@ -568,8 +570,8 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(AdamArgs a) {
         float* pp = (float*)&pr; const float* gg = (const float*)&gr; float* mm = (float*)&mi; float* vv = (float*)&vi;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          mm[c] = mm[c] + (gg[c] - mm[c]) * (1.f - a.beta1);
-          vv[c] = vv[c] * a.beta2 + gg[c] * gg[c] * (1.f - a.beta2);
+          mm[c] = mm[c] + (gg[c] - mm[c]) * a.omb1;
+          vv[c] = vv[c] * a.beta2 + gg[c] * gg[c] * a.omb2;
           pp[c] -= step * (mm[c] / (sqrtf(vv[c]) / a.bc2s + a.eps));
         }
         p4[i] = pr; m4[i] = mi; v4[i] = vi;
@@ -577,8 +579,8 @@ __global__ void __launch_bounds__(256) fused_adam_kernel(AdamArgs a) {
     } else {
       for (unsigned long long i = tid; i < G.n; i += stride) {
         const float gr = G.g[i];
-        const float mi = G.m[i] + (gr - G.m[i]) * (1.f - a.beta1);
-        const float vi = G.v[i] * a.beta2 + gr * gr * (1.f - a.beta2);
+        const float mi = G.m[i] + (gr - G.m[i]) * a.omb1;
+        const float vi = G.v[i] * a.beta2 + gr * gr * a.omb2;
         G.m[i] = mi; G.v[i] = vi;
         G.p[i] -= step * (mi / (sqrtf(vi) / a.bc2s + a.eps));
       }

@@ -10,10 +10,12 @@ struct SlamGrads {
   float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation;
   float* max_radii2D; float* grad_accum; float* denom;
 };
-struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float lr[5]; float beta1, beta2, eps, bc1, bc2s; int on; };
-struct PoseAdam { float* pose; float* m; float* v; int* step; float lr_q, lr_t, beta1, beta2, eps; const float* prior; float prior_w_t, prior_w_q; };
-struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float lr; };
-struct AdamArgs { AdamGroup grp[8]; int ngroups; float beta1, beta2, eps, bc1, bc2s; };
+// Adam scalars as torch.optim.Adam applies them: formed in double on the host, rounded once to float.
+//   omb1 = 1 - beta1 (lerp weight), beta2, omb2 = 1 - beta2, step_size = lr / (1 - beta1^t) per group, bc2s = sqrt(1 - beta2^t)
+struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; };
+struct PoseAdam { float* pose; float* m; float* v; int* step; double lr_q, lr_t, beta1, beta2; float eps; const float* prior; float prior_w_t, prior_w_q; };
+struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float step_size; };
+struct AdamArgs { AdamGroup grp[8]; int ngroups; float omb1, beta2, omb2, eps, bc2s; };
 struct LossCfg {
   int H, W;
   float w_l1, w_ssim, w_pearson;

@@ -312,13 +312,15 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           float bx[16], by[16], bz[16];
           sh_basis_grad(deg, ux, uy, uz, bx, by, bz);
           const float* sh = shs + (size_t)idx * M * 3;
-          float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+          // in double: the tangential projection below is a small difference of large terms, and its sum over the map is the
+          // camera-position gradient (held to 1e-5; the float version sat at 1.2e-5 on the degree-2 case)
+          double ddx = 0.0, ddy = 0.0, ddz = 0.0;
           for (int k = 1; k < nb; k++) {
-            float w = sh[k * 3] * gc0 + sh[k * 3 + 1] * gc1 + sh[k * 3 + 2] * gc2;
+            const double w = (double)sh[k * 3] * gc0 + (double)sh[k * 3 + 1] * gc1 + (double)sh[k * 3 + 2] * gc2;
             ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
           }
-          float dot = ux * ddx + uy * ddy + uz * ddz;
-          float mx = (ddx - ux * dot) * inv, my = (ddy - uy * dot) * inv, mz = (ddz - uz * dot) * inv;
+          const double dot = ux * ddx + uy * ddy + uz * ddz;
+          float mx = (float)((ddx - ux * dot) * inv), my = (float)((ddy - uy * dot) * inv), mz = (float)((ddz - uz * dot) * inv);
           dmean[0] += mx; dmean[1] += my; dmean[2] += mz;
           if (want_cam) { cg[24] = -mx; cg[25] = -my; cg[26] = -mz; }
         }

@@ -493,17 +493,20 @@ def test_binning_overflow_is_sticky_and_the_loops_recover():
     eng.forward(pose, g, need_grads=True)
     assert eng.check_capacity()
     n_true = int(eng.ratio * eng.P + 0.5)
-    # shrink the binning buffer below the need: flagged; then a tiny scene that fits: flag must still be there
-    big_cap = eng.n_cap
-    eng.n_cap = max(n_true // 3, 1)
+    true_ratio = eng.ratio
+    # a capacity model that claims ~0 pairs per Gaussian -> tiny binning buffer -> overflow (flagged); then a view that fits:
+    # the flag, the maximum N and the maximum list length must still be there
+    eng.MIN_PAIRS = 64
+    eng.ratio, eng.n_cap = 0.01, 0
     eng.forward(pose, g, need_grads=True)
-    eng.n_cap = big_cap
-    far = pose.clone(); far[6] += 500.0                     # camera far away: almost nothing on screen, no overflow
+    assert eng.n_cap < n_true
+    far = pose.clone(); far[6] -= 1000.0                    # the whole map behind the camera: nothing rendered, no overflow
     eng.forward(far, g, need_grads=True)
     torch.cuda.synchronize()
     hdr = eng.img_state[:16].view(torch.int32).cpu()
     assert int(hdr[1]) == 1 and int(hdr[3]) >= n_true - 1 and int(hdr[0]) < n_true       # sticky overflow / max N; last N small
     assert not eng.check_capacity()
+    assert eng.ratio >= true_ratio * 0.999                   # capacity model learned the true need from the overflowing call
     assert eng.check_capacity()                              # cleared by the read
     # whole loops: same result with a deliberately starved engine as with a healthy one
     results = []
@@ -515,6 +518,7 @@ def test_binning_overflow_is_sticky_and_the_loops_recover():
         slam.step(0)
         e = _engine(slam.renderer)
         if starve:
+            e.MIN_PAIRS = 64
             e.ratio = 0.02                                   # capacity model claims ~0 pairs per Gaussian -> tiny buffers
             e.n_cap = 0
         random.seed(5)
