@@ -235,7 +235,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
                               const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl,
-                              float* prior_loss4 = nullptr) {
+                              float* prior_loss4 = nullptr, int dl_planes = 6) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
@@ -281,7 +281,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl); }
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4); }
   return check_launch("slam_backward");
 }
@@ -310,6 +310,7 @@ int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_co
                 float* loss4, void* stream) {
   if (!c || !out6 || !gt_color || !work || !dL) return fail(-1, "NULL argument");
   if (c->H <= 0 || c->W <= 0) return fail(-1, "bad image size");
+  if ((double)c->H * c->W * 36.0 >= 4294967296.0) return fail(-1, "image too large for the loss kernels' 32-bit offsets");
   if (c->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
   LossCfg lc = loss_cfg_dev(c);
   hipStream_t s = (hipStream_t)stream;
@@ -377,15 +378,47 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   memset(&ad, 0, sizeof(ad));
   if (map_adam) ad = *map_adam;
   Mm3dgsSlamInputs si = *in;
+  if (n_iter > 0 && (!loss_cfg || !loss_work || !dL_dout)) return fail(-1, "NULL argument");
+  // SSIM losses on the fused-sort path (the shipped mapping loss): the forward compositor's epilogue writes the per-tile L1 /
+  // Pearson rows, the SSIM kernel's extra workgroup reduces them, and the gradient image has four planes: two launches per
+  // iteration for the loss instead of three (no finishing launch), the loss values only once, at the end of the run
+  const int no_rows = env_flag("MM3DGS_NO_FORWARD_ROWS", 0);   // read per call: tests compare both paths in one process
+  const bool rows = n_iter > 0 && !no_rows && loss_cfg->w_ssim != 0.f && slam_fused_sort(fwd_flags) && loss_cfg->H == cam->image_height &&
+                    loss_cfg->W == cam->image_width;
+  TrackLoss tl = {};
+  LossCfg lc = {};
+  char* w = (char*)loss_work;
+  double* sums = (double*)w;
+  float* dmaps = (float*)(w + 256);
+  double* partial = n_iter > 0 ? (double*)(w + 256 + align_up((size_t)9 * loss_cfg->H * loss_cfg->W * 4, 256)) : nullptr;
+  if (rows) {
+    lc = loss_cfg_dev(loss_cfg);
+    tl.cfg = lc; tl.out = out_color; tl.sums = sums; tl.partial = partial; tl.loss4 = nullptr; tl.defer_scale = 0;
+  }
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
+    if (loss_cfg->w_pearson != 0.f && !views[it].ref_depth_or_null) return fail(-2, "view %d: Pearson term needs a reference depth", it);
     si.pose = views[it].pose;
-    int rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
-    if (rc) return rc;
-    rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
-    if (rc) return rc;
-    rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
-                              nullptr, nullptr, map_adam ? &ad : nullptr, stream);
+    int rc;
+    if (rows) {
+      tl.gt = views[it].gt_color; tl.ref = views[it].ref_depth_or_null;
+      rc = slam_forward_impl(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, &tl);
+      if (rc) return rc;
+      { ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
+        launch_loss_after_forward_rows(lc, out_color, tl.gt, tl.ref, dmaps, sums, partial, dL_dout, (hipStream_t)stream); }
+      if (loss4 && it == n_iter - 1) launch_loss_finish(lc, sums, partial, (hipStream_t)stream, loss4);
+      rc = check_launch("loss");
+      if (rc) return rc;
+      rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
+                              nullptr, map_adam ? &ad : nullptr, stream, nullptr, nullptr, 4);
+    } else {
+      rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
+      if (rc) return rc;
+      rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
+      if (rc) return rc;
+      rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
+                                nullptr, nullptr, map_adam ? &ad : nullptr, stream);
+    }
     if (rc) return rc;
     ad.step++;
   }

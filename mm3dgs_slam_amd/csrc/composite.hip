@@ -362,7 +362,7 @@ struct SepReduce {
 template <int C, int MODE>
 __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
-                     float* __restrict__ dsub, int has_tl, TrackLoss tl) {
+                     float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
@@ -413,7 +413,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   }
 #pragma unroll
   for (int ch = 0; ch < C; ch++) {
-    if (!dl_done) dL[ch] = inside ? dL_dout[ch * HW + pix] : 0.f;
+    if (!dl_done) dL[ch] = (inside && ch < dl_planes) ? dL_dout[ch * HW + pix] : 0.f;
     if (ch < 3) bg_dot += cam.bg[ch] * dL[ch];
   }
   const float Tf_bg = T_final * bg_dot;
@@ -570,18 +570,18 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
-  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none);
+  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none, C);
 }
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s, const TrackLoss* tl) {
+                               float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
   if (tracking)
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
   else
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none, dl_planes);
 }
 
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,

@@ -40,17 +40,21 @@ struct TrackLoss {
 };
 // the loss partial rows the pose finishing kernel sums when the normalisation is deferred (see TrackLoss::defer_scale)
 struct PoseLossScale { const double* rows; int nrows; float w_l1; float* loss4; };
-void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s);
+void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s, float* loss4 = nullptr);
 
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
                                 const PoseLossScale* pls = nullptr, float* loss4 = nullptr);
+// dl_planes: 6, or 4 when the caller guarantees that the silhouette / depth^2 planes of dL are zero AND need not be read
+// (the mapping loop's loss kernel does not even write them)
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s, const TrackLoss* tl = nullptr);
+                               float* dsub, hipStream_t s, const TrackLoss* tl = nullptr, int dl_planes = 6);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
                                 const TrackLoss* tl = nullptr);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s);
+void launch_loss_after_forward_rows(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums,
+                                    double* partial, float* dL, hipStream_t s);

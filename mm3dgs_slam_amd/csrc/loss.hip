@@ -4,9 +4,18 @@
 //             (1-l) * mean |image - gt| + l * (1 - SSIM_11x11,sigma1.5(image, gt)) [+ w * (1 - Pearson(depth, ref))]
 // replacing ~60 small torch kernels, 10 MIOpen convolutions and the boolean-mask gathers (host syncs) per iteration.
 //
-// Two launches: (1) per 16x16 tile, separable Gaussian moments in LDS -> SSIM value and its partial-derivative maps,
-// plus every scalar reduction (L1 sum/count, SSIM sum, Pearson moments) accumulated in double; (2) per tile, the
-// adjoint convolution of the derivative maps + L1 sign + Pearson gradient -> dL/dout, and the loss scalars.
+// Kernels (16x16-pixel tile per 256-lane workgroup; the whole 1200-workgroup grid of a 640x480 image is resident at once):
+//   ssim_maps_kernel   separable 11x11 Gaussian moments of one colour channel at a time -> SSIM value and its three
+//                      partial-derivative maps.  Both passes work on register strips: the horizontal pass reads 14 raw values
+//                      per image with four ds_read_b128 and produces 4 outputs x 5 moments (220 FMA per 8 LDS reads; the first
+//                      version issued one ds_read_b32 per FMA operand and ran at 6 % of the HBM roofline), the vertical pass
+//                      produces 2 outputs per lane from 12 rows.  <ROWS>: also the per-pixel sums (L1, Pearson moments) of the
+//                      tile; otherwise those rows were written by the forward compositor's epilogue (mm3dgs_slam_map) and one
+//                      extra workgroup of this launch reduces them to the scalars the gradient kernel needs -- no separate
+//                      finishing launch in the mapping loop.
+//   loss_rows_kernel   the per-pixel sums alone (losses without an SSIM term outside the folded tracking path).
+//   loss_finish_kernel one workgroup: fixed-order double-precision sum of the tile rows, Pearson scalars, the four loss values.
+//   loss_grad_kernel   adjoint convolution of the derivative maps (same strip scheme) + L1 sign + Pearson gradient -> dL/dout.
 // Channel layout of `out`: 0..2 RGB, 3 depth (alpha-weighted z), 4 silhouette, 5 depth^2.
 #include "mm3dgs_common.h"
 #include "fused_api.h"
@@ -15,112 +24,56 @@
 #define LT 16
 #define HALO 5
 #define LW (LT + 2 * HALO)  // 26
-#define LWP 27              // LDS row stride (odd: rows start on different banks; 48 would be conflict-free but costs a workgroup of occupancy)
-#define NSUM 16
+#define SW 28               // LDS row stride of the 26-wide staging rows (16-byte aligned rows for ds_read_b128)
+#define HW_ 24              // LDS row stride of the 16-wide horizontal-pass outputs: 2-row strips of the vertical pass land on
+                            // disjoint bank halves (2 * 24 mod 32 = 16), rows stay 16-byte aligned for the b128 stores
 
-__global__ void __launch_bounds__(256)
-loss_reduce_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
-                   float* __restrict__ dmaps, double* __restrict__ partial) {
-  // One colour channel at a time through 14 KB of LDS: the whole grid (1200 workgroups at 640x480) is then resident at
-  // once (>= 5 workgroups per CU); staging all three channels (42 KB) left room for 3 per CU -> two rounds, the second
-  // nearly empty (24 us instead of ~12).  The next channel's halo loads are in flight while this one is convolved.
-  __shared__ float sI[LW][LWP], sG[LW][LWP];
-  __shared__ float hM1[LW][LT], hM2[LW][LT], hE11[LW][LT], hE22[LW][LT], hE12[LW][LT];
-  __shared__ double red[4][12];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-  const int px = x0 + tx, py = y0 + ty;
-  const bool inside = px < cfg.W && py < cfg.H;
-  const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
-  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  double acc[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+// Global accesses of the two image kernels go through buffer resources (SGPR descriptor + 32-bit VGPR byte offset): with flat
+// 64-bit addresses the address pairs of the halo prefetch and of the map stores pushed ssim_maps_kernel past the 96 registers
+// that 5 waves per SIMD allow (it spilled ~40 registers).
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+__device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ float bld(Rsrc r, uint32_t elem) { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4u, 0, 0)); }
+__device__ __forceinline__ void bst(Rsrc r, uint32_t elem, float v) { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, elem * 4u, 0, 0); }
 
-  const float sil = inside ? out[4 * HW + pix] : 0.f;
-  if (cfg.w_ssim != 0.f) {
-    // the (row, column) of a lane's three halo elements are computed once and reused for every channel
-    constexpr int NEL = (LW * LW + 255) / 256;   // 3
-    int off[NEL], lds[NEL];
+struct HaloIdx { int off[3], lds[3]; };   // a lane's three elements of the 26x26 halo region: global offset (-1: outside the image), LDS index (-1: none)
+
+__device__ __forceinline__ HaloIdx halo_index(const LossCfg& cfg, int x0, int y0) {
+  HaloIdx h;
 #pragma unroll
-    for (int e = 0; e < NEL; e++) {
-      const int i = threadIdx.x + e * 256;
-      const int ly = i / LW, lx = i - ly * LW;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      const bool in = i < LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-      off[e] = in ? gy * cfg.W + gx : -1;
-      lds[e] = i < LW * LW ? ly * LWP + lx : -1;
-    }
-    float va[NEL], vb[NEL];
-#pragma unroll
-    for (int e = 0; e < NEL; e++) {
-      va[e] = off[e] >= 0 ? out[off[e]] : 0.f;
-      vb[e] = off[e] >= 0 ? gt[off[e]] : 0.f;
-    }
-    for (int ch = 0; ch < 3; ch++) {
-#pragma unroll
-      for (int e = 0; e < NEL; e++)
-        if (lds[e] >= 0) { (&sI[0][0])[lds[e]] = va[e]; (&sG[0][0])[lds[e]] = vb[e]; }
-      __syncthreads();   // also orders the previous channel's vertical pass before this channel's h* writes
-      if (ch < 2) {
-#pragma unroll
-        for (int e = 0; e < NEL; e++) {
-          va[e] = off[e] >= 0 ? out[(size_t)(ch + 1) * HW + off[e]] : 0.f;
-          vb[e] = off[e] >= 0 ? gt[(size_t)(ch + 1) * HW + off[e]] : 0.f;
-        }
-      }
-      // horizontal pass: 26 rows x 16 columns = 416 outputs, lane t takes outputs t and t + 256 (shift/mask only)
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const int o = threadIdx.x + e * 256;
-        if (o < LW * LT) {
-          const int ly = o >> 4, lx = o & 15;
-          const float* ri = &sI[ly][lx];
-          const float* rg = &sG[ly][lx];
-          float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-          for (int k = 0; k < 11; k++) {
-            const float a = ri[k], b = rg[k], w = cfg.window[k];
-            const float wa = w * a, wb = w * b;
-            m1 += wa; m2 += wb; e11 = fmaf(wa, a, e11); e22 = fmaf(wb, b, e22); e12 = fmaf(wa, b, e12);
-          }
-          hM1[ly][lx] = m1; hM2[ly][lx] = m2; hE11[ly][lx] = e11; hE22[ly][lx] = e22; hE12[ly][lx] = e12;
-        }
-      }
-      __syncthreads();
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = cfg.window[k];
-        m1 += w * hM1[ty + k][tx]; m2 += w * hM2[ty + k][tx]; e11 += w * hE11[ty + k][tx];
-        e22 += w * hE22[ty + k][tx]; e12 += w * hE12[ty + k][tx];
-      }
-      if (inside) {
-        const float s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
-        const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
-        const float inv = 1.f / (B1 * B2);
-        const float f = A1 * A2 * inv;
-        acc[2] += (double)f;
-        const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 / B1;
-        const float df_ds1 = -f / B2;
-        const float df_ds12 = 2.f * A1 * inv;
-        dmaps[(size_t)(ch * 3 + 0) * HW + pix] = df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12;  // d/d mu1 (total)
-        dmaps[(size_t)(ch * 3 + 1) * HW + pix] = df_ds1;                                     // d/d E[x^2]
-        dmaps[(size_t)(ch * 3 + 2) * HW + pix] = df_ds12;                                    // d/d E[xy]
-      }
-    }
+  for (int e = 0; e < 3; e++) {
+    const int i = threadIdx.x + e * 256;
+    const int ly = i / LW, lx = i - ly * LW;
+    const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
+    const bool in = i < LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
+    h.off[e] = in ? gy * cfg.W + gx : -1;
+    h.lds[e] = i < LW * LW ? ly * SW + lx : -1;
   }
-  if (inside) {
-    const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
-    loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);   // acc[2] (SSIM) untouched
+  return h;
+}
+
+// fixed-order reduction of the tile rows by one 256-lane workgroup: lane = 16 * rowgroup + column.  cols_mask selects the
+// columns to sum (a column that another workgroup of the same launch is still writing must not be read).
+__device__ __forceinline__ void reduce_rows_256(const double* __restrict__ partial, int nrows, unsigned cols_mask, double (*part)[16], double* tot) {
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (col < 12 && ((cols_mask >> col) & 1u)) {
+    int r = grp;
+    for (; r + 48 < nrows; r += 64) {
+      a0 += partial[(size_t)r * 12 + col]; a1 += partial[(size_t)(r + 16) * 12 + col];
+      a2 += partial[(size_t)(r + 32) * 12 + col]; a3 += partial[(size_t)(r + 48) * 12 + col];
+    }
+    for (; r < nrows; r += 16) a0 += partial[(size_t)r * 12 + col];
   }
-  block_sums<12>(acc, red, cfg.w_pearson != 0.f);
-  // one row of partial sums per workgroup (plain stores): 14k double atomics on two cache lines cost ~90 us
-  if (threadIdx.x == 0) {
-    double* row = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 12;
+  part[grp][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; k++) row[k] = acc[k];
+    for (int q = 0; q < 16; q++) t += part[q][threadIdx.x];
+    tot[threadIdx.x] = t;
   }
+  __syncthreads();
 }
 
 __device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, double st, double stt, double sxt, double& rho,
@@ -131,12 +84,220 @@ __device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, d
   rho = cxt / sqrt(cxx * ctt);
 }
 
+// lane 0: the Pearson scalars every pixel of the gradient pass needs (sums[16..23]) from the finished moments tot[3..11]
+__device__ __forceinline__ void pearson_scalars(const double* tot, int pearson_on, int pearson_invert, double* __restrict__ sums) {
+  double valid = 0.0, use2 = 0.0, rho = 0.0, k1 = 0.0, k2 = 0.0, mx = 0.0, mt = 0.0, loss_p = 0.0;
+  const double n = tot[3];
+  if (pearson_on && n > 1.0) {
+    double rho1, cxx, ctt1, rho2 = -2.0, ctt2 = 1.0, cxx2;
+    pearson_terms(n, tot[4], tot[5], tot[6], tot[7], tot[8], rho1, cxx, ctt1);
+    bool u2 = false;
+    if (pearson_invert) {
+      pearson_terms(n, tot[4], tot[5], tot[9], tot[10], tot[11], rho2, cxx2, ctt2);
+      u2 = (1.0 - rho2) < (1.0 - rho1);
+    }
+    rho = u2 ? rho2 : rho1;
+    const double ctt = u2 ? ctt2 : ctt1;
+    valid = 1.0; use2 = u2 ? 1.0 : 0.0;
+    k1 = 1.0 / sqrt(cxx * ctt); k2 = rho / cxx;
+    mx = tot[4] / n; mt = (u2 ? tot[9] : tot[6]) / n;
+    loss_p = 1.0 - rho;
+  }
+  sums[16] = valid; sums[17] = use2; sums[18] = rho; sums[19] = k1; sums[20] = k2; sums[21] = mx; sums[22] = mt; sums[23] = loss_p;
+}
+
+// ---- SSIM moments and derivative maps ---------------------------------------------------------------------------------------
+template <bool ROWS>
+__global__ void __launch_bounds__(256, 5)   // >= 5 waves per SIMD: the whole 1200-workgroup grid of a 640x480 image in one round
+ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
+                 float* __restrict__ dmaps, double* __restrict__ partial, double* __restrict__ sums, int tiles_x, int T) {
+  __shared__ __align__(16) float sI[LW][SW], sG[LW][SW];
+  __shared__ __align__(16) float hS[5][LW][HW_];
+  __shared__ double red[4][12];
+  if ((int)blockIdx.x >= T) {
+    // the extra workgroup of the mapping loop: the forward compositor's epilogue wrote the L1 / Pearson rows of this render;
+    // reduce them (every column but the SSIM sums the other workgroups are writing right now) and derive the Pearson scalars
+    double (*part)[16] = (double (*)[16])&hS[0][0][0];
+    __shared__ double tot[16];
+    reduce_rows_256(partial, T, 0xffbu, part, tot);
+    if (threadIdx.x < 12 && threadIdx.x != 2) sums[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x == 0) pearson_scalars(tot, cfg.w_pearson != 0.f ? 1 : 0, cfg.pearson_invert, sums);
+    return;
+  }
+  const int tile = blockIdx.x;
+  const int x0 = (tile % tiles_x) * LT, y0 = (tile / tiles_x) * LT;
+  const uint32_t HW = (uint32_t)cfg.H * (uint32_t)cfg.W;   // 32-bit element offsets (9 H W < 2^31 is checked by the API): 64-bit address temporaries spilled
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  const int tid = threadIdx.x;
+  const HaloIdx hx = halo_index(cfg, x0, y0);
+  const Rsrc r_out = make_rsrc(out, HW * 24u), r_gt = make_rsrc(gt, HW * 12u), r_dm = make_rsrc(dmaps, HW * 36u);
+  float va[3], vb[3];
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    va[e] = hx.off[e] >= 0 ? bld(r_out, (uint32_t)hx.off[e]) : 0.f;
+    vb[e] = hx.off[e] >= 0 ? bld(r_gt, (uint32_t)hx.off[e]) : 0.f;
+  }
+  // per-pixel sums of this lane's pixel (ROWS): lane = 16 * row + column of the tile
+  const int tx = tid & 15, ty = tid >> 4;
+  const int px = x0 + tx, py = y0 + ty;
+  const bool inside = px < cfg.W && py < cfg.H;
+  const uint32_t pix = (uint32_t)py * (uint32_t)cfg.W + (uint32_t)px;
+  float l1 = 0.f;
+  float ssim_sum = 0.f;      // <= 6 addends per lane
+  // vertical-pass item: 2 outputs (rows vy, vy + 1) of column vx
+  const int vx = tid & 15, vy = (tid >> 4) * 2;
+#pragma unroll 1   // (unrolled x3 the kernel needed 120+ registers)
+  for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+      if (hx.lds[e] >= 0) { (&sI[0][0])[hx.lds[e]] = va[e]; (&sG[0][0])[hx.lds[e]] = vb[e]; }
+    __syncthreads();   // staging complete; also: every lane has finished the previous channel's vertical pass (hS is free)
+    if (ch < 2) {
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        va[e] = hx.off[e] >= 0 ? bld(r_out, (uint32_t)(ch + 1) * HW + (uint32_t)hx.off[e]) : 0.f;
+        vb[e] = hx.off[e] >= 0 ? bld(r_gt, (uint32_t)(ch + 1) * HW + (uint32_t)hx.off[e]) : 0.f;
+      }
+    }
+    if (ROWS) l1 += fabsf(sI[ty + HALO][tx + HALO] - sG[ty + HALO][tx + HALO]);
+    // horizontal pass: 26 rows x 4 strips of 4 outputs; 14 inputs per image as four 16-byte reads
+    if (tid < LW * 4) {
+      const int row = tid >> 2, s = tid & 3;
+      float a[16], b[16];
+      const float4* ra = (const float4*)&sI[row][4 * s];
+      const float4* rb = (const float4*)&sG[row][4 * s];
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const float4 qa = ra[v], qb = rb[v];
+        a[4 * v] = qa.x; a[4 * v + 1] = qa.y; a[4 * v + 2] = qa.z; a[4 * v + 3] = qa.w;
+        b[4 * v] = qb.x; b[4 * v + 1] = qb.y; b[4 * v + 2] = qb.z; b[4 * v + 3] = qb.w;
+      }
+      // three groups (a-moments, b-moments, cross moment) so that only one 14-value product array is live at a time: the kernel
+      // must stay under 96 registers for 5 waves per SIMD (1200 workgroups resident at once)
+      auto moments2 = [&](const float (&x)[16], const float (&xx)[14], float (*dst_m)[HW_], float (*dst_e)[HW_]) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+          for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; m[o] = fmaf(w, x[o + k], m[o]); e[o] = fmaf(w, xx[o + k], e[o]); }
+        *(float4*)&dst_m[row][4 * s] = make_float4(m[0], m[1], m[2], m[3]);
+        *(float4*)&dst_e[row][4 * s] = make_float4(e[0], e[1], e[2], e[3]);
+      };
+      {
+        float pp[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) pp[i] = a[i] * a[i];
+        moments2(a, pp, hS[0], hS[2]);
+#pragma unroll
+        for (int i = 0; i < 14; i++) pp[i] = b[i] * b[i];
+        moments2(b, pp, hS[1], hS[3]);
+#pragma unroll
+        for (int i = 0; i < 14; i++) pp[i] = a[i] * b[i];
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+          for (int k = 0; k < 11; k++) e[o] = fmaf(cfg.window[k], pp[o + k], e[o]);
+        *(float4*)&hS[4][row][4 * s] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+    __syncthreads();
+    // vertical pass: 16 columns x 8 strips of 2 outputs, 12 rows of each moment per lane
+    if (tid < 128) {
+      float st[5][2];
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        float r[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) r[i] = hS[q][vy + i][vx];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; s0 = fmaf(w, r[k], s0); s1 = fmaf(w, r[k + 1], s1); }
+        st[q][0] = s0; st[q][1] = s1;
+        // one moment's 12 reads in flight at a time: with all 60 hoisted the kernel needs 120 registers (96 allow 5 waves per SIMD)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int o = 0; o < 2; o++) {
+        const int gx = x0 + vx, gy = y0 + vy + o;
+        if (gx < cfg.W && gy < cfg.H) {
+          const float m1 = st[0][o], m2 = st[1][o];
+          const float s1 = st[2][o] - m1 * m1, s2 = st[3][o] - m2 * m2, s12 = st[4][o] - m1 * m2;
+          const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
+          // v_rcp_f32 (1 ulp) instead of three IEEE divisions: their scale / fixup sequences held ~40 registers live
+          const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
+          const float inv = rB1 * rB2;
+          const float f = A1 * A2 * inv;
+          ssim_sum += f;
+          const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 * rB1;
+          const float df_ds1 = -f * rB2;
+          const float df_ds12 = 2.f * A1 * inv;
+          const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
+          bst(r_dm, (uint32_t)(ch * 3 + 0) * HW + p, df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12);  // d/d mu1 (total)
+          bst(r_dm, (uint32_t)(ch * 3 + 1) * HW + p, df_ds1);                                     // d/d E[x^2]
+          bst(r_dm, (uint32_t)(ch * 3 + 2) * HW + p, df_ds12);                                    // d/d E[xy]
+        }
+      }
+    }
+  }
+  if constexpr (ROWS) {
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = 0.0;
+    if (inside) {
+      // (the L1 sum was taken from the staged channels; loss_px_sums only needs it and the depth / silhouette / reference)
+      const float sil = out[4 * HW + pix];
+      const float rgb[3] = {l1, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+      loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
+    }
+    acc[2] = (double)ssim_sum;
+    block_sums<12>(acc, red, cfg.w_pearson != 0.f);
+    if (tid == 0) {
+      double* row = partial + (size_t)tile * 12;
+#pragma unroll
+      for (int k = 0; k < 12; k++) row[k] = acc[k];
+    }
+  } else {
+    // only the tile's SSIM sum (column 2 of its row; the other columns came from the forward compositor)
+    const float t = wave_sum_to_lane63(ssim_sum);
+    if ((tid & 63) == 63) red[tid >> 6][0] = (double)t;
+    __syncthreads();
+    if (tid == 0) partial[(size_t)tile * 12 + 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  }
+}
+
+// per-pixel sums only (no SSIM term): one row of partial sums per 16x16 tile (plain stores: 14k double atomics on two cache
+// lines cost ~90 us)
+__global__ void __launch_bounds__(256)
+loss_rows_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
+                 double* __restrict__ partial, int tiles_x) {
+  __shared__ double red[4][12];
+  const int tile = blockIdx.x;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int px = (tile % tiles_x) * LT + tx, py = (tile / tiles_x) * LT + ty;
+  const bool inside = px < cfg.W && py < cfg.H;
+  const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  if (inside) {
+    const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
+    loss_px_sums(cfg, rgb, out[4 * HW + pix], cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
+  }
+  block_sums<12>(acc, red, cfg.w_pearson != 0.f);
+  if (threadIdx.x == 0) {
+    double* row = partial + (size_t)tile * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) row[k] = acc[k];
+  }
+}
+
 // one 1024-lane workgroup: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short (the
 // kernel is pure latency), then the groups are added in a fixed order (deterministic).  Lane 0 also derives the Pearson
-// scalars every pixel of loss_grad_kernel needs (sums[16..23]) -- ~200 double-precision operations that each of the
-// 307 k lanes of that kernel used to repeat.
-__global__ void __launch_bounds__(1024) loss_finish_kernel(const double* __restrict__ partial, int nrows, double* __restrict__ sums,
-                                                           int pearson_on, int pearson_invert) {
+// scalars every pixel of loss_grad_kernel needs (sums[16..23]) and, when asked, the four loss values.
+__global__ void __launch_bounds__(1024) loss_finish_kernel(LossCfg cfg, const double* __restrict__ partial, int nrows, double* __restrict__ sums,
+                                                           float* __restrict__ loss4) {
   __shared__ double part[64][16];
   __shared__ double part8[8][16];
   __shared__ double tot[16];
@@ -166,122 +327,136 @@ __global__ void __launch_bounds__(1024) loss_finish_kernel(const double* __restr
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double valid = 0.0, use2 = 0.0, rho = 0.0, k1 = 0.0, k2 = 0.0, mx = 0.0, mt = 0.0, loss_p = 0.0;
-    const double n = tot[3];
-    if (pearson_on && n > 1.0) {
-      double rho1, cxx, ctt1, rho2 = -2.0, ctt2 = 1.0, cxx2;
-      pearson_terms(n, tot[4], tot[5], tot[6], tot[7], tot[8], rho1, cxx, ctt1);
-      bool u2 = false;
-      if (pearson_invert) {
-        pearson_terms(n, tot[4], tot[5], tot[9], tot[10], tot[11], rho2, cxx2, ctt2);
-        u2 = (1.0 - rho2) < (1.0 - rho1);
-      }
-      rho = u2 ? rho2 : rho1;
-      const double ctt = u2 ? ctt2 : ctt1;
-      valid = 1.0; use2 = u2 ? 1.0 : 0.0;
-      k1 = 1.0 / sqrt(cxx * ctt); k2 = rho / cxx;
-      mx = tot[4] / n; mt = (u2 ? tot[9] : tot[6]) / n;
-      loss_p = 1.0 - rho;
-    }
-    sums[16] = valid; sums[17] = use2; sums[18] = rho; sums[19] = k1; sums[20] = k2; sums[21] = mx; sums[22] = mt; sums[23] = loss_p;
+    pearson_scalars(tot, cfg.w_pearson != 0.f ? 1 : 0, cfg.pearson_invert, sums);
+    if (loss4) loss_scalars(cfg, sums, (size_t)cfg.H * cfg.W, loss4);
   }
 }
 
-
-__global__ void __launch_bounds__(256, 5)   // >= 5 waves per SIMD: the whole 1200-workgroup grid resident in one round
+// ---- gradient image ------------------------------------------------------------------------------------------------------------
+// write6: also store zeros to the silhouette / depth^2 planes (no loss term reaches them); the mapping loop's backward compositor
+// does not read those planes and passes 0.
+__global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
-                 const float* __restrict__ dmaps, const double* __restrict__ sums, float* __restrict__ dL, float* __restrict__ loss) {
-  __shared__ float sD[3][LW][LWP];   // one colour channel (three derivative maps) at a time, as in loss_reduce_kernel
-  __shared__ float hD[3][LW][LT];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-  const int px = x0 + tx, py = y0 + ty;
-  const bool inside = px < cfg.W && py < cfg.H;
-  const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
+                 const float* __restrict__ dmaps, const double* __restrict__ sums, float* __restrict__ dL, int tiles_x, int write6) {
+  __shared__ __align__(16) float sD[3][LW][SW];   // one colour channel (three derivative maps) at a time
+  __shared__ __align__(16) float hD[3][LW][HW_];
+  const int tile = blockIdx.x;
+  const int x0 = (tile % tiles_x) * LT, y0 = (tile / tiles_x) * LT;
+  const int tid = threadIdx.x;
+  const uint32_t HW = (uint32_t)cfg.H * (uint32_t)cfg.W;
   const float l1_scale = loss_l1_scale(cfg, sums);
   const float ssim_scale = -cfg.w_ssim / (float)(3.0 * (double)HW);
-  const float sil = inside ? out[4 * HW + pix] : 0.f;
-  const bool smask = sil > cfg.sil_thr;
-  float gch[3] = {0.f, 0.f, 0.f};
+  // output item: 2 pixels (rows vy, vy + 1) of column vx, lanes 0..127; lanes 128..255 only help with staging and the
+  // horizontal pass (the vertical pass is 1/6 of the work)
+  const int vx = tid & 15, vy = ((tid >> 4) & 7) * 2;
+  const bool item = tid < 128;
+  float gch[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   if (cfg.w_ssim != 0.f) {
-    constexpr int NEL = (LW * LW + 255) / 256;   // 3 halo elements per lane and map
-    int off[NEL], lds[NEL];
-#pragma unroll
-    for (int e = 0; e < NEL; e++) {
-      const int i = threadIdx.x + e * 256;
-      const int ly = i / LW, lx = i - ly * LW;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      const bool in = i < LW * LW && gx >= 0 && gx < cfg.W && gy >= 0 && gy < cfg.H;
-      off[e] = in ? gy * cfg.W + gx : -1;
-      lds[e] = i < LW * LW ? ly * LWP + lx : -1;
-    }
-    float v[3][NEL];
+    const HaloIdx hx = halo_index(cfg, x0, y0);
+    const Rsrc r_dm = make_rsrc(dmaps, HW * 36u);
+    float v[3][3];
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
-      for (int e = 0; e < NEL; e++) v[q][e] = off[e] >= 0 ? dmaps[(size_t)q * HW + off[e]] : 0.f;
+      for (int e = 0; e < 3; e++) v[q][e] = hx.off[e] >= 0 ? bld(r_dm, (uint32_t)q * HW + (uint32_t)hx.off[e]) : 0.f;
     for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
       for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int e = 0; e < NEL; e++)
-          if (lds[e] >= 0) (&sD[q][0][0])[lds[e]] = v[q][e];
+        for (int e = 0; e < 3; e++)
+          if (hx.lds[e] >= 0) (&sD[q][0][0])[hx.lds[e]] = v[q][e];
       __syncthreads();   // also orders the previous channel's vertical pass before this channel's hD writes
-      const float oc = inside ? out[(size_t)ch * HW + pix] : 0.f, gc = inside ? gt[(size_t)ch * HW + pix] : 0.f;
       if (ch < 2) {
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
-          for (int e = 0; e < NEL; e++) v[q][e] = off[e] >= 0 ? dmaps[(size_t)((ch + 1) * 3 + q) * HW + off[e]] : 0.f;
+          for (int e = 0; e < 3; e++) v[q][e] = hx.off[e] >= 0 ? bld(r_dm, (uint32_t)((ch + 1) * 3 + q) * HW + (uint32_t)hx.off[e]) : 0.f;
       }
-#pragma unroll 1
-      for (int q = 0; q < 3; q++) {   // not unrolled: 66 LDS reads in flight would cost the fifth wave per SIMD
+      // horizontal pass: 3 maps x 26 rows x 4 strips of 4 outputs = 312 items over 256 lanes
+      for (int it = tid; it < 3 * LW * 4; it += 256) {
+        const int q = it / (LW * 4), rem = it - q * (LW * 4);
+        const int row = rem >> 2, s = rem & 3;
+        float a[16];
+        const float4* ra = (const float4*)&sD[q][row][4 * s];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const int o = threadIdx.x + e * 256;
-          if (o < LW * LT) {
-            const int ly = o >> 4, lx = o & 15;
-            const float* rd = &sD[q][ly][lx];
-            float sacc = 0.f;
+        for (int u = 0; u < 4; u++) { const float4 t = ra[u]; a[4 * u] = t.x; a[4 * u + 1] = t.y; a[4 * u + 2] = t.z; a[4 * u + 3] = t.w; }
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 11; k++) sacc = fmaf(cfg.window[k], rd[k], sacc);
-            hD[q][ly][lx] = sacc;
+        for (int o = 0; o < 4; o++)
+#pragma unroll
+          for (int k = 0; k < 11; k++) r[o] = fmaf(cfg.window[k], a[o + k], r[o]);
+        *(float4*)&hD[q][row][4 * s] = make_float4(r[0], r[1], r[2], r[3]);
+      }
+      __syncthreads();
+      if (item) {
+        float c[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          float rr[12];
+#pragma unroll
+          for (int i = 0; i < 12; i++) rr[i] = hD[q][vy + i][vx];
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; s0 = fmaf(w, rr[k], s0); s1 = fmaf(w, rr[k + 1], s1); }
+          c[q][0] = s0; c[q][1] = s1;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+          const int gx = x0 + vx, gy = y0 + vy + o;
+          if (gx < cfg.W && gy < cfg.H) {
+            const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
+            const float oc = out[(uint32_t)ch * HW + p], gc = gt[(uint32_t)ch * HW + p];
+            const float gval = ssim_scale * (c[0][o] + 2.f * oc * c[1][o] + gc * c[2][o]);
+            if (ch == 0) gch[0][o] = gval; else if (ch == 1) gch[1][o] = gval; else gch[2][o] = gval;
           }
         }
       }
-      __syncthreads();
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = cfg.window[k];
-        c0 += w * hD[0][ty + k][tx]; c1 += w * hD[1][ty + k][tx]; c2 += w * hD[2][ty + k][tx];
-      }
-      const float gval = ssim_scale * (c0 + 2.f * oc * c1 + gc * c2);
-      if (ch == 0) gch[0] = gval; else if (ch == 1) gch[1] = gval; else gch[2] = gval;
     }
   }
-  if (inside) {
+  if (item) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++)
-      dL[ch * HW + pix] = gch[ch] + loss_px_l1_grad(cfg, out[ch * HW + pix], gt[ch * HW + pix], smask, l1_scale);
-    // depth channel: Pearson; silhouette and depth^2 carry no loss
-    dL[3 * HW + pix] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + pix], ref[pix], sums) : 0.f;
-    dL[4 * HW + pix] = 0.f;
-    dL[5 * HW + pix] = 0.f;
+    for (int o = 0; o < 2; o++) {
+      const int gx = x0 + vx, gy = y0 + vy + o;
+      if (gx < cfg.W && gy < cfg.H) {
+        const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
+        const float sil = out[4 * HW + p];
+        const bool smask = sil > cfg.sil_thr;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+          dL[ch * HW + p] = gch[ch][o] + loss_px_l1_grad(cfg, out[ch * HW + p], gt[ch * HW + p], smask, l1_scale);
+        // depth channel: Pearson; silhouette and depth^2 carry no loss
+        dL[3 * HW + p] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + p], ref[p], sums) : 0.f;
+        if (write6) { dL[4 * HW + p] = 0.f; dL[5 * HW + p] = 0.f; }
+      }
+    }
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss) loss_scalars(cfg, sums, HW, loss);
 }
 
-void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s) {
-  const int nrows = ((cfg.W + LT - 1) / LT) * ((cfg.H + LT - 1) / LT);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, nrows, sums, cfg.w_pearson != 0.f ? 1 : 0, cfg.pearson_invert);
+static int loss_tiles_x(const LossCfg& cfg) { return (cfg.W + LT - 1) / LT; }
+static int loss_tiles(const LossCfg& cfg) { return loss_tiles_x(cfg) * ((cfg.H + LT - 1) / LT); }
+
+void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s, float* loss4) {
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, cfg, partial, loss_tiles(cfg), sums, loss4);
 }
 
+// standalone form (mm3dgs_loss): rows (+ SSIM maps) -> finish (+ loss values) -> gradient image with all six planes written
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s) {
-  dim3 grid((cfg.W + LT - 1) / LT, (cfg.H + LT - 1) / LT), block(256);
-  hipLaunchKernelGGL(loss_reduce_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, partial);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)(grid.x * grid.y), sums, cfg.w_pearson != 0.f ? 1 : 0,
-                     cfg.pearson_invert);
-  hipLaunchKernelGGL(loss_grad_kernel, grid, block, 0, s, cfg, out, gt, ref, dmaps, sums, dL, loss);
+  const int T = loss_tiles(cfg), tx = loss_tiles_x(cfg);
+  if (cfg.w_ssim != 0.f)
+    hipLaunchKernelGGL(ssim_maps_kernel<true>, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, partial, sums, tx, T);
+  else
+    hipLaunchKernelGGL(loss_rows_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, partial, tx);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, cfg, partial, T, sums, loss);
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 1);
+}
+
+// mapping-loop form (mm3dgs_slam_map): the forward compositor's epilogue already wrote the L1 / Pearson rows of this render.
+// Two launches, no finishing launch; dL gets its first four planes only (the backward compositor is told not to read the rest).
+// The loss values are produced on demand by launch_loss_finish (every row column is complete after the first launch here).
+void launch_loss_after_forward_rows(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums,
+                                    double* partial, float* dL, hipStream_t s) {
+  const int T = loss_tiles(cfg), tx = loss_tiles_x(cfg);
+  hipLaunchKernelGGL(ssim_maps_kernel<false>, dim3(T + 1), dim3(256), 0, s, cfg, out, gt, ref, dmaps, partial, sums, tx, T);
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 0);
 }
