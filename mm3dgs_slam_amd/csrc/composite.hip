@@ -485,7 +485,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         n_red++;
         const float a_eff = valid ? alpha : 0.f;
         const float G_eff = valid ? G : 0.f;
-        const float r = __builtin_amdgcn_rcpf(1.f - a_eff);
+        // generic mode: correctly rounded division -- T is rebuilt by ~50 successive divisions per pixel and the 1-ulp v_rcp_f32
+        // showed up as 5e-6 of noise on every gradient (camera gradients are held to 1e-5); the SLAM modes keep v_rcp_f32
+        const float r = MODE == 0 ? 1.f / (1.f - a_eff) : __builtin_amdgcn_rcpf(1.f - a_eff);
         Tr *= r;  // transmittance in front of this splat
         const float w = a_eff * Tr;
         float col[C];
