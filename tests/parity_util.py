@@ -131,4 +131,12 @@ def compare(case, verbose=False, **hip_kw):
         m["d_" + k] = rel_l2(gh, go)
     if verbose:
         print({k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in m.items()})
+    m["case"] = case
     return m
+
+
+def f32_floor(case):
+    """Error of the float32 evaluation of the oracle itself against its float64 evaluation, per gradient."""
+    _, _, _, g64 = run_oracle(case, torch.float64)
+    _, _, _, g32 = run_oracle(case, torch.float32)
+    return {"d_" + k: rel_l2(g32[k], g64[k]) for k in g64 if g64[k] is not None and g32[k] is not None}
