@@ -173,7 +173,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
         const float g3[3] = {tl->gt[pix], tl->gt[HW + pix], tl->gt[2 * HW + pix]};
         loss_px_sums(tl->cfg, rgb, fin[4], fin[3], g3, tl->cfg.w_pearson != 0.f ? tl->ref[pix] : 0.f, ls);
       }
-      block_sums<12>(ls, red, tl->cfg.w_pearson != 0.f);
+      block_sums<12>(ls, red, pearson_double_cols(tl->cfg));
       if (threadIdx.x == 0) {
         double* rowp = tl->partial + (size_t)tile * 12;
 #pragma unroll

@@ -24,9 +24,10 @@
 #define LT 16
 #define HALO 5
 #define LW (LT + 2 * HALO)  // 26
-#define SW 28               // LDS row stride of the 26-wide staging rows (16-byte aligned rows for ds_read_b128)
-#define HW_ 24              // LDS row stride of the 16-wide horizontal-pass outputs: 2-row strips of the vertical pass land on
-                            // disjoint bank halves (2 * 24 mod 32 = 16), rows stay 16-byte aligned for the b128 stores
+#define SW 48               // LDS row stride of the 26-wide staging rows: the four rows a 32-lane group of the horizontal pass reads
+                            // (8 two-output strips each, ds_read_b64) start 48 banks apart = on the four quarters of the 64 banks
+#define HW_ 16              // LDS row stride of the 16-wide horizontal-pass outputs (dense): the two rows a 32-lane group of the
+                            // vertical pass reads land on the two halves of the 32 banks
 
 // Global accesses of the two image kernels go through buffer resources (SGPR descriptor + 32-bit VGPR byte offset): with flat
 // 64-bit addresses the address pairs of the halo prefetch and of the map stores pushed ssim_maps_kernel past the 96 registers
@@ -143,9 +144,7 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   const bool inside = px < cfg.W && py < cfg.H;
   const uint32_t pix = (uint32_t)py * (uint32_t)cfg.W + (uint32_t)px;
   float l1 = 0.f;
-  float ssim_sum = 0.f;      // <= 6 addends per lane
-  // vertical-pass item: 2 outputs (rows vy, vy + 1) of column vx
-  const int vx = tid & 15, vy = (tid >> 4) * 2;
+  float ssim_sum = 0.f;      // 3 addends per lane
 #pragma unroll 1   // (unrolled x3 the kernel needed 120+ registers)
   for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
@@ -160,84 +159,63 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
       }
     }
     if (ROWS) l1 += fabsf(sI[ty + HALO][tx + HALO] - sG[ty + HALO][tx + HALO]);
-    // horizontal pass: 26 rows x 4 strips of 4 outputs; 14 inputs per image as four 16-byte reads
-    if (tid < LW * 4) {
-      const int row = tid >> 2, s = tid & 3;
-      float a[16], b[16];
-      const float4* ra = (const float4*)&sI[row][4 * s];
-      const float4* rb = (const float4*)&sG[row][4 * s];
+    // horizontal pass: 26 rows x 8 strips of 2 outputs (208 of the 256 lanes); 12 inputs per image as six 8-byte reads
+    if (tid < LW * 8) {
+      const int row = tid >> 3, s = tid & 7;
+      float a[12], b[12];
+      const float2* ra = (const float2*)&sI[row][2 * s];
+      const float2* rb = (const float2*)&sG[row][2 * s];
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const float4 qa = ra[v], qb = rb[v];
-        a[4 * v] = qa.x; a[4 * v + 1] = qa.y; a[4 * v + 2] = qa.z; a[4 * v + 3] = qa.w;
-        b[4 * v] = qb.x; b[4 * v + 1] = qb.y; b[4 * v + 2] = qb.z; b[4 * v + 3] = qb.w;
+      for (int v = 0; v < 6; v++) {
+        const float2 qa = ra[v], qb = rb[v];
+        a[2 * v] = qa.x; a[2 * v + 1] = qa.y; b[2 * v] = qb.x; b[2 * v + 1] = qb.y;
       }
-      // three groups (a-moments, b-moments, cross moment) so that only one 14-value product array is live at a time: the kernel
-      // must stay under 96 registers for 5 waves per SIMD (1200 workgroups resident at once)
-      auto moments2 = [&](const float (&x)[16], const float (&xx)[14], float (*dst_m)[HW_], float (*dst_e)[HW_]) {
-        float m[4] = {0.f, 0.f, 0.f, 0.f}, e[4] = {0.f, 0.f, 0.f, 0.f};
+      float m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f}, e11[2] = {0.f, 0.f}, e22[2] = {0.f, 0.f}, e12[2] = {0.f, 0.f};
 #pragma unroll
-        for (int o = 0; o < 4; o++)
+      for (int i = 0; i < 12; i++) {
+        const float aa = a[i] * a[i], bb = b[i] * b[i], ab = a[i] * b[i];
 #pragma unroll
-          for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; m[o] = fmaf(w, x[o + k], m[o]); e[o] = fmaf(w, xx[o + k], e[o]); }
-        *(float4*)&dst_m[row][4 * s] = make_float4(m[0], m[1], m[2], m[3]);
-        *(float4*)&dst_e[row][4 * s] = make_float4(e[0], e[1], e[2], e[3]);
-      };
-      {
-        float pp[14];
-#pragma unroll
-        for (int i = 0; i < 14; i++) pp[i] = a[i] * a[i];
-        moments2(a, pp, hS[0], hS[2]);
-#pragma unroll
-        for (int i = 0; i < 14; i++) pp[i] = b[i] * b[i];
-        moments2(b, pp, hS[1], hS[3]);
-#pragma unroll
-        for (int i = 0; i < 14; i++) pp[i] = a[i] * b[i];
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-          for (int k = 0; k < 11; k++) e[o] = fmaf(cfg.window[k], pp[o + k], e[o]);
-        *(float4*)&hS[4][row][4 * s] = make_float4(e[0], e[1], e[2], e[3]);
+        for (int o = 0; o < 2; o++) {
+          const int k = i - o;
+          if (k >= 0 && k < 11) {
+            const float w = cfg.window[k];
+            m1[o] = fmaf(w, a[i], m1[o]); m2[o] = fmaf(w, b[i], m2[o]);
+            e11[o] = fmaf(w, aa, e11[o]); e22[o] = fmaf(w, bb, e22[o]); e12[o] = fmaf(w, ab, e12[o]);
+          }
+        }
       }
+      *(float2*)&hS[0][row][2 * s] = make_float2(m1[0], m1[1]);
+      *(float2*)&hS[1][row][2 * s] = make_float2(m2[0], m2[1]);
+      *(float2*)&hS[2][row][2 * s] = make_float2(e11[0], e11[1]);
+      *(float2*)&hS[3][row][2 * s] = make_float2(e22[0], e22[1]);
+      *(float2*)&hS[4][row][2 * s] = make_float2(e12[0], e12[1]);
     }
     __syncthreads();
-    // vertical pass: 16 columns x 8 strips of 2 outputs, 12 rows of each moment per lane
-    if (tid < 128) {
-      float st[5][2];
+    // vertical pass: one output per lane (all 256), 11 rows of each moment
+    {
+      float st[5];
 #pragma unroll
       for (int q = 0; q < 5; q++) {
-        float r[12];
+        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 12; i++) r[i] = hS[q][vy + i][vx];
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; s0 = fmaf(w, r[k], s0); s1 = fmaf(w, r[k + 1], s1); }
-        st[q][0] = s0; st[q][1] = s1;
-        // one moment's 12 reads in flight at a time: with all 60 hoisted the kernel needs 120 registers (96 allow 5 waves per SIMD)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 11; k++) acc = fmaf(cfg.window[k], hS[q][ty + k][tx], acc);
+        st[q] = acc;
       }
-#pragma unroll
-      for (int o = 0; o < 2; o++) {
-        const int gx = x0 + vx, gy = y0 + vy + o;
-        if (gx < cfg.W && gy < cfg.H) {
-          const float m1 = st[0][o], m2 = st[1][o];
-          const float s1 = st[2][o] - m1 * m1, s2 = st[3][o] - m2 * m2, s12 = st[4][o] - m1 * m2;
-          const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
-          // v_rcp_f32 (1 ulp) instead of three IEEE divisions: their scale / fixup sequences held ~40 registers live
-          const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
-          const float inv = rB1 * rB2;
-          const float f = A1 * A2 * inv;
-          ssim_sum += f;
-          const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 * rB1;
-          const float df_ds1 = -f * rB2;
-          const float df_ds12 = 2.f * A1 * inv;
-          const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
-          bst(r_dm, (uint32_t)(ch * 3 + 0) * HW + p, df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12);  // d/d mu1 (total)
-          bst(r_dm, (uint32_t)(ch * 3 + 1) * HW + p, df_ds1);                                     // d/d E[x^2]
-          bst(r_dm, (uint32_t)(ch * 3 + 2) * HW + p, df_ds12);                                    // d/d E[xy]
-        }
+      if (inside) {
+        const float m1 = st[0], m2 = st[1];
+        const float s1 = st[2] - m1 * m1, s2 = st[3] - m2 * m2, s12 = st[4] - m1 * m2;
+        const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
+        // v_rcp_f32 (1 ulp) instead of three IEEE divisions (their scale / fixup sequences held ~40 registers live)
+        const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
+        const float inv = rB1 * rB2;
+        const float f = A1 * A2 * inv;
+        ssim_sum += f;
+        const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 * rB1;
+        const float df_ds1 = -f * rB2;
+        const float df_ds12 = 2.f * A1 * inv;
+        bst(r_dm, (uint32_t)(ch * 3 + 0) * HW + pix, df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12);  // d/d mu1 (total)
+        bst(r_dm, (uint32_t)(ch * 3 + 1) * HW + pix, df_ds1);                                     // d/d E[x^2]
+        bst(r_dm, (uint32_t)(ch * 3 + 2) * HW + pix, df_ds12);                                    // d/d E[xy]
       }
     }
   }
@@ -252,7 +230,7 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
       loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
     }
     acc[2] = (double)ssim_sum;
-    block_sums<12>(acc, red, cfg.w_pearson != 0.f);
+    block_sums<12>(acc, red, pearson_double_cols(cfg));
     if (tid == 0) {
       double* row = partial + (size_t)tile * 12;
 #pragma unroll
@@ -285,7 +263,7 @@ loss_rows_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
     const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
     loss_px_sums(cfg, rgb, out[4 * HW + pix], cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
   }
-  block_sums<12>(acc, red, cfg.w_pearson != 0.f);
+  block_sums<12>(acc, red, pearson_double_cols(cfg));
   if (threadIdx.x == 0) {
     double* row = partial + (size_t)tile * 12;
 #pragma unroll
@@ -346,11 +324,18 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   const uint32_t HW = (uint32_t)cfg.H * (uint32_t)cfg.W;
   const float l1_scale = loss_l1_scale(cfg, sums);
   const float ssim_scale = -cfg.w_ssim / (float)(3.0 * (double)HW);
-  // output item: 2 pixels (rows vy, vy + 1) of column vx, lanes 0..127; lanes 128..255 only help with staging and the
-  // horizontal pass (the vertical pass is 1/6 of the work)
-  const int vx = tid & 15, vy = ((tid >> 4) & 7) * 2;
-  const bool item = tid < 128;
-  float gch[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  const int tx = tid & 15, ty = tid >> 4;      // this lane's output pixel
+  const int px = x0 + tx, py = y0 + ty;
+  const bool inside = px < cfg.W && py < cfg.H;
+  const uint32_t pix = (uint32_t)py * (uint32_t)cfg.W + (uint32_t)px;
+  const Rsrc r_out = make_rsrc(out, HW * 24u), r_gt = make_rsrc(gt, HW * 12u);
+  float oc[3] = {0.f, 0.f, 0.f}, gc[3] = {0.f, 0.f, 0.f}, sil = 0.f;
+  if (inside) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) { oc[ch] = bld(r_out, (uint32_t)ch * HW + pix); gc[ch] = bld(r_gt, (uint32_t)ch * HW + pix); }
+    sil = bld(r_out, 4u * HW + pix);
+  }
+  float gch[3] = {0.f, 0.f, 0.f};
   if (cfg.w_ssim != 0.f) {
     const HaloIdx hx = halo_index(cfg, x0, y0);
     const Rsrc r_dm = make_rsrc(dmaps, HW * 36u);
@@ -359,6 +344,7 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
     for (int q = 0; q < 3; q++)
 #pragma unroll
       for (int e = 0; e < 3; e++) v[q][e] = hx.off[e] >= 0 ? bld(r_dm, (uint32_t)q * HW + (uint32_t)hx.off[e]) : 0.f;
+#pragma unroll 1
     for (int ch = 0; ch < 3; ch++) {
 #pragma unroll
       for (int q = 0; q < 3; q++)
@@ -372,63 +358,41 @@ loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
 #pragma unroll
           for (int e = 0; e < 3; e++) v[q][e] = hx.off[e] >= 0 ? bld(r_dm, (uint32_t)((ch + 1) * 3 + q) * HW + (uint32_t)hx.off[e]) : 0.f;
       }
-      // horizontal pass: 3 maps x 26 rows x 4 strips of 4 outputs = 312 items over 256 lanes
-      for (int it = tid; it < 3 * LW * 4; it += 256) {
-        const int q = it / (LW * 4), rem = it - q * (LW * 4);
-        const int row = rem >> 2, s = rem & 3;
-        float a[16];
-        const float4* ra = (const float4*)&sD[q][row][4 * s];
+      // horizontal pass: 3 maps x 26 rows x 8 strips of 2 outputs = 624 items over the 256 lanes
+      for (int it = tid; it < 3 * LW * 8; it += 256) {
+        const int q = it / (LW * 8), rem = it - q * (LW * 8);
+        const int row = rem >> 3, s = rem & 7;
+        const float2* ra = (const float2*)&sD[q][row][2 * s];
+        float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const float4 t = ra[u]; a[4 * u] = t.x; a[4 * u + 1] = t.y; a[4 * u + 2] = t.z; a[4 * u + 3] = t.w; }
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-#pragma unroll
-          for (int k = 0; k < 11; k++) r[o] = fmaf(cfg.window[k], a[o + k], r[o]);
-        *(float4*)&hD[q][row][4 * s] = make_float4(r[0], r[1], r[2], r[3]);
+        for (int u = 0; u < 6; u++) {
+          const float2 t = ra[u];
+          if (2 * u < 11) r0 = fmaf(cfg.window[2 * u], t.x, r0);
+          if (2 * u - 1 >= 0) r1 = fmaf(cfg.window[2 * u - 1], t.x, r1);
+          if (2 * u + 1 < 11) r0 = fmaf(cfg.window[2 * u + 1], t.y, r0);
+          r1 = fmaf(cfg.window[2 * u], t.y, r1);
+        }
+        *(float2*)&hD[q][row][2 * s] = make_float2(r0, r1);
       }
       __syncthreads();
-      if (item) {
-        float c[3][2];
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          float rr[12];
-#pragma unroll
-          for (int i = 0; i < 12; i++) rr[i] = hD[q][vy + i][vx];
-          float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-          for (int k = 0; k < 11; k++) { const float w = cfg.window[k]; s0 = fmaf(w, rr[k], s0); s1 = fmaf(w, rr[k + 1], s1); }
-          c[q][0] = s0; c[q][1] = s1;
-        }
-#pragma unroll
-        for (int o = 0; o < 2; o++) {
-          const int gx = x0 + vx, gy = y0 + vy + o;
-          if (gx < cfg.W && gy < cfg.H) {
-            const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
-            const float oc = out[(uint32_t)ch * HW + p], gc = gt[(uint32_t)ch * HW + p];
-            const float gval = ssim_scale * (c[0][o] + 2.f * oc * c[1][o] + gc * c[2][o]);
-            if (ch == 0) gch[0][o] = gval; else if (ch == 1) gch[1][o] = gval; else gch[2][o] = gval;
-          }
-        }
+      for (int k = 0; k < 11; k++) {
+        const float w = cfg.window[k];
+        c0 = fmaf(w, hD[0][ty + k][tx], c0); c1 = fmaf(w, hD[1][ty + k][tx], c1); c2 = fmaf(w, hD[2][ty + k][tx], c2);
       }
+      const float o_ = ch == 0 ? oc[0] : (ch == 1 ? oc[1] : oc[2]), g_ = ch == 0 ? gc[0] : (ch == 1 ? gc[1] : gc[2]);
+      const float gval = ssim_scale * (c0 + 2.f * o_ * c1 + g_ * c2);
+      if (ch == 0) gch[0] = gval; else if (ch == 1) gch[1] = gval; else gch[2] = gval;
     }
   }
-  if (item) {
+  if (inside) {
+    const bool smask = sil > cfg.sil_thr;
 #pragma unroll
-    for (int o = 0; o < 2; o++) {
-      const int gx = x0 + vx, gy = y0 + vy + o;
-      if (gx < cfg.W && gy < cfg.H) {
-        const uint32_t p = (uint32_t)gy * (uint32_t)cfg.W + (uint32_t)gx;
-        const float sil = out[4 * HW + p];
-        const bool smask = sil > cfg.sil_thr;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-          dL[ch * HW + p] = gch[ch][o] + loss_px_l1_grad(cfg, out[ch * HW + p], gt[ch * HW + p], smask, l1_scale);
-        // depth channel: Pearson; silhouette and depth^2 carry no loss
-        dL[3 * HW + p] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + p], ref[p], sums) : 0.f;
-        if (write6) { dL[4 * HW + p] = 0.f; dL[5 * HW + p] = 0.f; }
-      }
-    }
+    for (int ch = 0; ch < 3; ch++) dL[ch * HW + pix] = gch[ch] + loss_px_l1_grad(cfg, oc[ch], gc[ch], smask, l1_scale);
+    // depth channel: Pearson; silhouette and depth^2 carry no loss
+    dL[3 * HW + pix] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + pix], ref[pix], sums) : 0.f;
+    if (write6) { dL[4 * HW + pix] = 0.f; dL[5 * HW + pix] = 0.f; }
   }
 }
 

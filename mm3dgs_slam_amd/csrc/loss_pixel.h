@@ -6,19 +6,24 @@
 #include "mm3dgs_common.h"
 #include "fused_api.h"
 
-// sum of NR per-lane values over the 256-lane workgroup (valid in lane 0 only).  Entries < NF (sums of non-negative terms:
-// L1 sum / count, SSIM sum) take a float DPP reduction inside each wave (<= 64 addends); entries >= NF (the Pearson moments
-// n, x, xx, t, tt, xt: the covariances are later formed as stt - st^2 / n, where mean^2 / variance reaches 1e5 on the
-// 1 / (ref + 200) branch, so a 1e-7 relative rounding of the sums would become 1e-2 on the correlation) stay in double.
-template <int NR, int NF = 3>
-__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR], bool tail_on = true) {
+// sum of the twelve per-lane loss values over the 256-lane workgroup (valid in lane 0 only).  Columns 0..3 (L1 sum / count, SSIM
+// sum, Pearson pixel count: sums of non-negative terms, <= 64 addends per wave) take a float DPP reduction; the Pearson moments
+// x, xx, t, tt, xt (columns 4..11; the covariances are later formed as stt - st^2 / n, where mean^2 / variance reaches 1e5 on the
+// 1 / (ref + 200) branch, so a 1e-7 relative rounding of the sums would become 1e-2 on the correlation) stay in double -- only
+// the columns the configuration uses (workgroup-uniform mask): none without a Pearson term, 4..8 for the mapping loss, 4..11 with
+// the two-target tracking form.
+__device__ __forceinline__ unsigned pearson_double_cols(const LossCfg& cfg) {
+  return cfg.w_pearson == 0.f ? 0u : (cfg.pearson_invert ? 0xff0u : 0x1f0u);
+}
+template <int NR>
+__device__ __forceinline__ void block_sums(double (&v)[NR], double (*sh)[NR], unsigned dmask) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NR; k++) {
-    if (k < NF) {
+    if (k < 4) {
       const float t = wave_sum_to_lane63((float)v[k]);
       if (lane == 63) sh[wv][k] = (double)t;
-    } else if (tail_on) {       // workgroup-uniform: the Pearson term is off in most tracking configurations (all zeros then)
+    } else if ((dmask >> k) & 1u) {
       const double t = wave_sum_to_lane63_f64(v[k]);
       if (lane == 63) sh[wv][k] = t;
     } else if (lane == 63) {
