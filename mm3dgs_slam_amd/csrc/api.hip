@@ -281,8 +281,12 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s); launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4); }
+  // MM3DGS_BWD2 (default 1): the 2-pixels-per-lane / MFMA-reduction backward compositor; 0 selects the first-generation kernel
+  const int bwd2 = env_flag("MM3DGS_BWD2", 1);   // read per call: tests compare both in one process
+  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s);
+    if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes);
+    else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, bwd2); }
   return check_launch("slam_backward");
 }
 

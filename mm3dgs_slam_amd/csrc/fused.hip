@@ -189,7 +189,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
 template <bool TRACK>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma, int yshift) {
   const int idx = blockIdx.x * FB + threadIdx.x;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
@@ -217,7 +217,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = btile + toff;
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? 8 : SPLAT_F, FB>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2);
+    gather_records<TRACK ? 2 : 3, TRACK ? 8 : SPLAT_F, FB>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -532,17 +532,17 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4) {
+                                const PoseLossScale* pls, float* loss4, int yshift) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
   if (P > 0) {
     if (out.d_xyz || ma.on)
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, partial, out, ma);
+                         bw.dsub, partial, out, ma, yshift);
     else
       hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, partial, out, ma);
+                         bw.dsub, partial, out, ma, yshift);
   }
   if (want_pose)
   {

@@ -560,3 +560,32 @@ def test_mapping_loss_via_forward_rows_matches_the_standalone_loss_kernels(pears
 def eng_grads(eng, g):
     eng._ensure(int(g._xyz.shape[0]), True)
     return eng.grads
+
+
+@pytest.mark.parametrize("mode", ["map", "track"])
+def test_second_generation_backward_compositor_matches_the_first(mode, monkeypatch):
+    """composite_bwd2_kernel (2 pixels per lane, MFMA block reduction, y-moments about the block centre shifted in the gather)
+    against composite_bwd_kernel (DPP butterflies): same decisions, same per-pixel arithmetic, different summation trees."""
+    from mm3dgs_slam_amd.fused import FusedEngine
+    for P, H, W, scale_up in ((20000, 200, 272, 0.0), (300, 128, 160, 3.0)):     # SLAM-sized splats / huge splats (flat work list)
+        cfg, g, R, pose, color, depth = _setup(P=P, H=H, W=W, seed=13)
+        with torch.no_grad():
+            g._scaling += scale_up
+        res = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("MM3DGS_BWD2", flag)
+            eng = FusedEngine(R)
+            si = eng.forward(pose, g, need_grads=True)
+            eng.dL.copy_(torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(21)))
+            if mode == "map":
+                eng.backward(si, grads=eng.grads, dpose=eng.dpose)
+                res.append(({k: v.clone() for k, v in eng.grads.items()}, eng.dpose.clone()))
+            else:
+                eng.backward(si, dpose=eng.dpose)
+                res.append(({}, eng.dpose.clone()))
+            assert eng.check_capacity()
+        (ga, pa), (gb, pb) = res
+        assert torch.isfinite(pb).all()
+        assert pu.rel_l2(pb, pa) < 2e-5, (mode, P, pa, pb)
+        for k in ga:
+            assert pu.rel_l2(gb[k], ga[k]) < (2e-4 if k == "rotation" else 2e-5), (mode, P, k)
