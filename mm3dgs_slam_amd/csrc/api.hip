@@ -281,8 +281,11 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
-  // MM3DGS_BWD2 (default 1): the 2-pixels-per-lane / MFMA-reduction backward compositor; 0 selects the first-generation kernel
-  const int bwd2 = env_flag("MM3DGS_BWD2", 1);   // read per call: tests compare both in one process
+  // MM3DGS_BWD2=1 selects the 2-pixels-per-lane / MFMA-reduction backward compositor (composite_bwd2.hip).  Default off: it
+  // executes 29 % fewer VALU instructions but, with half the waves per SIMD (2.3 instead of 4.7), cannot keep the VALU busy
+  // (58 % active; 61 us against 49 us at SLAM size -- profiles/r02_bwd2_experiment.md).  Kept: it is bit-checked against the
+  // first-generation kernel (tests/test_gpu_fused.py) and wins where a view has enough pixels per SIMD.
+  const int bwd2 = env_flag("MM3DGS_BWD2", 0);   // read per call: tests compare both in one process
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
