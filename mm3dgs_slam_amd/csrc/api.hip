@@ -193,6 +193,7 @@ static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in
   return 0;
 }
 
+static int bwd2_requested() { return env_flag("MM3DGS_BWD2", 0); }
 static bool slam_fused_sort(int flags) {
   static const int no_fused_sort = env_flag("MM3DGS_NO_FUSED_SORT", 0);
   return (flags & MM3DGS_FWD_SHORT_LISTS) && !no_fused_sort;
@@ -280,12 +281,13 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     ma.on = 1;
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
-  if (tl && !tracking) return fail(-1, "internal: folded loss is a tracking-mode feature");
+  if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
+  if (tl && !tracking && bwd2_requested()) return fail(-1, "internal: the folded mapping loss runs in the first-generation backward compositor");
   // MM3DGS_BWD2=1 selects the 2-pixels-per-lane / MFMA-reduction backward compositor (composite_bwd2.hip).  Default off: it
   // executes 29 % fewer VALU instructions but, with half the waves per SIMD (2.3 instead of 4.7), cannot keep the VALU busy
   // (58 % active; 61 us against 49 us at SLAM size -- profiles/r02_bwd2_experiment.md).  Kept: it is bit-checked against the
   // first-generation kernel (tests/test_gpu_fused.py) and wins where a view has enough pixels per SIMD.
-  const int bwd2 = env_flag("MM3DGS_BWD2", 0);   // read per call: tests compare both in one process
+  const int bwd2 = bwd2_requested();   // read per call: tests compare both in one process
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
@@ -411,13 +413,17 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       tl.gt = views[it].gt_color; tl.ref = views[it].ref_depth_or_null;
       rc = slam_forward_impl(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, &tl);
       if (rc) return rc;
+      // the gradient-image pass itself runs in the backward compositor's prologue (tl.dmaps set) unless the second-generation
+      // compositor or MM3DGS_NO_FOLDED_LOSS asks for the separate launch
+      const bool fold_grad = !bwd2_requested() && !env_flag("MM3DGS_NO_FOLDED_LOSS", 0);
       { ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
-        launch_loss_after_forward_rows(lc, out_color, tl.gt, tl.ref, dmaps, sums, partial, dL_dout, (hipStream_t)stream); }
+        launch_loss_after_forward_rows(lc, out_color, tl.gt, tl.ref, dmaps, sums, partial, fold_grad ? nullptr : dL_dout, (hipStream_t)stream); }
       if (loss4 && it == n_iter - 1) launch_loss_finish(lc, sums, partial, (hipStream_t)stream, loss4);
       rc = check_launch("loss");
       if (rc) return rc;
+      tl.dmaps = fold_grad ? dmaps : nullptr;
       rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
-                              nullptr, map_adam ? &ad : nullptr, stream, nullptr, nullptr, 4);
+                              nullptr, map_adam ? &ad : nullptr, stream, fold_grad ? &tl : nullptr, nullptr, 4);
     } else {
       rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
       if (rc) return rc;

@@ -23,6 +23,7 @@
 #include "sort_tile.h"
 #include "fused_api.h"
 #include "loss_pixel.h"
+#include "loss_tile.h"
 
 #include "composite_common.h"
 
@@ -356,7 +357,10 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;   // record stride in floats: tracking records (7 floats) are packed at 32 B
   // [buffer][wave][field A|B|C|pair index][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address
   // register per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
-  __shared__ float4 stg[2][4][4][64];
+  // (the staging buffers share their 32 KB with the scratch of the folded mapping-loss gradient pass, which runs first)
+  __shared__ __align__(16) unsigned char smem_raw[sizeof(float4) * 2 * 4 * 4 * 64];
+  static_assert(sizeof(smem_raw) >= sizeof(LossGradSmem) + 4 * 256 * sizeof(float), "LDS union too small for the loss pass");
+  float4 (*stg)[4][4][64] = (float4 (*)[4][4][64])smem_raw;
   constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -379,6 +383,26 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         if (tl.cfg.w_pearson != 0.f) dL[3] = loss_px_pearson_grad(tl.cfg, sil, tl.out[3 * HW + pix], tl.ref[pix], tl.sums);
       }
       if (!tl.defer_scale && tile == 0 && threadIdx.x == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
+      dl_done = true;
+    }
+  }
+  if constexpr (MODE == 1) {
+    if (has_tl) {
+      // mapping loss folded in: the gradient-image pass of loss.hip (adjoint SSIM convolution + L1 sign + Pearson gradient) for
+      // this tile, in this workgroup, into registers -- one launch and the dL round trip through HBM less per iteration.  The
+      // pass works in raster order (lane = 16 * y + x of the tile); the compositor's lanes pick their pixel up through LDS.
+      LossGradSmem& lsm = *(LossGradSmem*)smem_raw;
+      float* exch = (float*)(smem_raw + sizeof(LossGradSmem));
+      float g4[4];
+      bool in_raster;
+      loss_grad_tile(tl.cfg, tl.out, tl.gt, tl.ref, tl.dmaps, tl.sums, tile, cam.gx, lsm, g4, in_raster);
+#pragma unroll
+      for (int ch = 0; ch < 4; ch++) exch[ch * 256 + tid] = g4[ch];
+      __syncthreads();
+      const int lx = (wv & 1) * 8 + (row & 1) * 4 + (q & 3), ly = (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) dL[ch] = ch < 4 ? exch[ch * 256 + ly * 16 + lx] : 0.f;
+      __syncthreads();      // the staging buffers reuse this memory
       dl_done = true;
     }
   }
@@ -554,7 +578,7 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
   if (tracking)
     hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
   else
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none, dl_planes);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
 }
 
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,

@@ -32,6 +32,7 @@ struct TrackLoss {
   const float* gt;      // [3,H,W]
   const float* ref;     // [H,W] or NULL (Pearson off)
   const float* out;     // [6,H,W] the rendered bundle (backward prologue)
+  const float* dmaps;   // [9,H,W] SSIM derivative maps (mapping loss folded into the backward compositor's prologue) or NULL
   double* partial;      // [tiles][12]
   const double* sums;   // finished sums (loss_finish_kernel)
   float* loss4;         // {total, l1, 1-ssim, 1-rho} or NULL

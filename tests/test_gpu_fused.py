@@ -531,30 +531,36 @@ def test_binning_overflow_is_sticky_and_the_loops_recover():
 
 @pytest.mark.parametrize("pearson", [False, True])
 def test_mapping_loss_via_forward_rows_matches_the_standalone_loss_kernels(pearson, monkeypatch):
-    """mm3dgs_slam_map takes the L1 / Pearson tile sums from the forward compositor's epilogue, reduces them in the SSIM kernel's
-    extra workgroup and writes a 4-plane gradient image (2 launches); MM3DGS_NO_FORWARD_ROWS=1 runs the standalone
-    3-launch form of mm3dgs_loss instead.  Same per-pixel arithmetic, different reduction trees: gradients and loss agree."""
+    """Three forms of the mapping loss inside mm3dgs_slam_map, same per-pixel arithmetic, different launch structure:
+    A  MM3DGS_NO_FORWARD_ROWS=1: the standalone mm3dgs_loss (tile sums + SSIM maps, finish, gradient image with 6 planes);
+    B  tile sums from the forward compositor's epilogue, reduced by the SSIM kernel's extra workgroup, gradient image with 4 planes
+       (MM3DGS_NO_FOLDED_LOSS=1 keeps the gradient pass a launch of its own);
+    C  (default) as B with the gradient pass inside the backward compositor's prologue -- no gradient image at all."""
     from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
     cfg, g, R, pose, color, depth = _setup(P=15000, H=200, W=272, seed=11)
     lc = _loss_cfg(200, 272, 0.8, 0.2, 0.05 if pearson else 0.0, 0, 2 if pearson else 0, 0, 0.5)
     ref = depth.contiguous() if pearson else None
-    res = []
-    for no_rows in ("1", "0"):
+    res = {}
+    for name, no_rows, no_fold in (("A", "1", "0"), ("B", "0", "1"), ("C", "0", "0")):
         monkeypatch.setenv("MM3DGS_NO_FORWARD_ROWS", no_rows)
+        monkeypatch.setenv("MM3DGS_NO_FOLDED_LOSS", no_fold)
         eng = FusedEngine(R)
         eng.max_tile_len = 100          # "short lists": the fused sort + composite kernel (carries the epilogue)
-        eng.dL.fill_(float("nan"))      # planes 4, 5 are not written by the 2-launch form and must not be read
+        eng.dL.fill_(float("nan"))      # planes the form does not write must not be read
         eng.map_loop([(pose.contiguous(), color.contiguous(), ref)], g, lc, None, None, grads=eng_grads(eng, g))
         torch.cuda.synchronize()
         assert eng.check_capacity()
-        res.append(({k: v.clone() for k, v in eng.grads.items()}, eng.loss.clone(), eng.dL[:4].clone()))
-    (ga, la, da), (gb, lb, db) = res
-    assert torch.isfinite(db).all()
-    assert pu.rel_l2(db, da) < 1e-6
-    assert (la - lb).abs().max() < 1e-6 * max(1.0, float(la.abs().max())), (la, lb)
-    for k in ga:
-        assert torch.isfinite(gb[k]).all()
-        assert pu.rel_l2(gb[k], ga[k]) < 1e-5, k
+        res[name] = ({k: v.clone() for k, v in eng.grads.items()}, eng.loss.clone(), eng.dL.clone())
+    ga, la, da = res["A"]
+    assert torch.isfinite(da).all() and torch.isfinite(res["B"][2][:4]).all() and torch.isnan(res["B"][2][4:]).all()
+    assert torch.isnan(res["C"][2]).all()                    # form C never touches the gradient image
+    assert pu.rel_l2(res["B"][2][:4], da[:4]) < 1e-6
+    for name in ("B", "C"):
+        gb, lb, _ = res[name]
+        assert (la - lb).abs().max() < 1e-6 * max(1.0, float(la.abs().max())), (name, la, lb)
+        for k in ga:
+            assert torch.isfinite(gb[k]).all(), (name, k)
+            assert pu.rel_l2(gb[k], ga[k]) < 1e-5, (name, k)
 
 
 def eng_grads(eng, g):
