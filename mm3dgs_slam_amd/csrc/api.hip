@@ -285,8 +285,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   if (tl && !tracking && bwd2_requested()) return fail(-1, "internal: the folded mapping loss runs in the first-generation backward compositor");
   // MM3DGS_BWD2=1 selects the 2-pixels-per-lane / MFMA-reduction backward compositor (composite_bwd2.hip).  Default off: it
   // executes 29 % fewer VALU instructions but, with half the waves per SIMD (2.3 instead of 4.7), cannot keep the VALU busy
-  // (58 % active; 61 us against 49 us at SLAM size -- profiles/r02_bwd2_experiment.md).  Kept: it is bit-checked against the
-  // first-generation kernel (tests/test_gpu_fused.py) and wins where a view has enough pixels per SIMD.
+  // (58 % active; 61 us against 49 us at SLAM size, and no better at 1200x680 -- profiles/r02_bwd2_experiment.md).  Kept as a
+  // checked alternative (tests/test_gpu_fused.py compares it with the first-generation kernel).
   const int bwd2 = bwd2_requested();   // read per call: tests compare both in one process
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes);
