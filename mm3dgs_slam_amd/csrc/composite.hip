@@ -522,7 +522,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
-      if (my_slot >= 0 && row_on) my_rec[(size_t)ti * RECF] = tot;
+      if (my_slot >= 0 && row_on && !(cam.exp & 1)) my_rec[(size_t)ti * RECF] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies

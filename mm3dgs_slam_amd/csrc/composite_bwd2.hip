@@ -27,6 +27,7 @@
 #include "composite_common.h"
 #include "fused_api.h"
 #include "loss_pixel.h"
+#include "loss_tile.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -249,12 +250,239 @@ composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   else run_chunks(std::false_type{});
 }
 
+// ---- third generation: ONE pixel per lane (the first generation's 4800 waves at 640x480: 4.7 per SIMD cover the in-order
+// stalls that 2.3 could not), the matrix-core block reduction of the second.  A wave = an 8x8 sub-tile = four blocks; lane =
+// (k, b, x): k = lane / 16 the pixel row inside the block, b = (lane % 16) / 4 the block, x = lane % 4 the pixel column.  The MFMA
+// sums over k; the four columns x of a block sit in one quad and are joined with two quad_perm adds per result register.
+template <int MODE>
+__global__ void __launch_bounds__(256, 5)   // 5 waves per SIMD: the 4800 waves of a 640x480 view resident at once
+composite_bwd3_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
+                      float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
+  constexpr int C = 6;
+  constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;
+  constexpr int NG = MODE == 2 ? 2 : 3;                 // float4 groups of a record that carry data
+  constexpr int ROW_CZ = MODE == 2 ? 3 : 6, ROW_MY = MODE == 2 ? 4 : 7, ROW_MXY = MODE == 2 ? 5 : 8, ROW_MYY = MODE == 2 ? 6 : 9;
+  constexpr uint32_t CH = 16;                           // list entries staged per block and chunk
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = lane >> 4, j = lane & 15, bq = j >> 2, x = j & 3;
+  const int L = 4 * wv + bq;                            // block list: 4 * (8x8 sub-tile) + block inside it (sort_tile.h)
+  const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (bq & 1) * 4 + x;
+  const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (bq >> 1) * 4 + k;
+  const bool inside = px < cam.W && py < cam.H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
+  const uint32_t len = end - start;
+  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;
+  const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
+
+  // [wave][buffer][field A|B|C][block * 16 + entry] (+ the record index): lane-contiguous staging writes, block-uniform reads.
+  // The folded mapping-loss gradient pass (loss_tile.h) uses the same memory first.
+  __shared__ __align__(16) unsigned char smem_raw[sizeof(float4) * 4 * 2 * 3 * 64 + sizeof(uint32_t) * 4 * 2 * 64];
+  static_assert(sizeof(smem_raw) >= sizeof(LossGradSmem) + 4 * 256 * sizeof(float), "LDS union too small for the loss pass");
+  float4 (*stg)[2][3][64] = (float4 (*)[2][3][64])smem_raw;
+  uint32_t (*srec)[2][64] = (uint32_t (*)[2][64])(smem_raw + sizeof(float4) * 4 * 2 * 3 * 64);
+  __shared__ uint32_t s_todo[4][4];
+  __shared__ unsigned long long s_list[4][4];
+
+  const size_t HW = (size_t)cam.H * cam.W;
+  const size_t pix = (size_t)py * cam.W + px;
+  const float Tf = inside ? iv.final_T[pix] : 0.f;
+  const uint32_t lastc = inside ? iv.n_contrib[pix] : 0u;
+  float dL[C];
+  bool dl_done = false;
+  if constexpr (MODE == 2) {
+    if (has_tl) {
+      // tracking loss folded in: dL/d(image) of this pixel from the finished sums (what loss_grad_kernel would have written)
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) dL[ch] = 0.f;
+      if (inside) {
+        const float sil = tl.out[4 * HW + pix];
+        const bool smask = sil > tl.cfg.sil_thr;
+        const float l1s = tl.defer_scale ? tl.cfg.w_l1 / 3.f : loss_l1_scale(tl.cfg, tl.sums);   // deferred: 1/n applied to the pose gradient
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dL[ch] = loss_px_l1_grad(tl.cfg, tl.out[ch * HW + pix], tl.gt[ch * HW + pix], smask, l1s);
+        if (tl.cfg.w_pearson != 0.f) dL[3] = loss_px_pearson_grad(tl.cfg, sil, tl.out[3 * HW + pix], tl.ref[pix], tl.sums);
+      }
+      if (!tl.defer_scale && tile == 0 && tid == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
+      dl_done = true;
+    }
+  }
+  if constexpr (MODE == 1) {
+    if (has_tl) {
+      // mapping loss folded in (see composite_bwd_kernel): the gradient-image pass of this tile, in raster order, then each
+      // lane picks its own pixel up through LDS
+      LossGradSmem& lsm = *(LossGradSmem*)smem_raw;
+      float* exch = (float*)(smem_raw + sizeof(LossGradSmem));
+      float g4[4];
+      bool in_raster;
+      loss_grad_tile(tl.cfg, tl.out, tl.gt, tl.ref, tl.dmaps, tl.sums, tile, cam.gx, lsm, g4, in_raster);
+#pragma unroll
+      for (int ch = 0; ch < 4; ch++) exch[ch * 256 + tid] = g4[ch];
+      __syncthreads();
+      const int lx = (wv & 1) * 8 + (bq & 1) * 4 + x, ly = (wv >> 1) * 8 + (bq >> 1) * 4 + k;
+#pragma unroll
+      for (int ch = 0; ch < C; ch++) dL[ch] = ch < 4 ? exch[ch * 256 + ly * 16 + lx] : 0.f;
+      __syncthreads();      // the staging buffers reuse this memory
+      dl_done = true;
+    }
+  }
+  float bg_dot = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < C; ch++) {
+    if (!dl_done) dL[ch] = (inside && ch < dl_planes) ? dL_dout[ch * HW + pix] : 0.f;
+    if (ch < 3) bg_dot += cam.bg[ch] * dL[ch];
+  }
+  const float Tf_bg = Tf * bg_dot;
+  float Tr = Tf;
+  float behind = 0.f;                // (colour accumulated behind the current list position) . dL
+
+  // nothing behind the deepest contributor of any pixel of the block matters: todo = max over the block's 16 pixels
+  // (the quad's 4 columns, then the 4 rows 16 / 32 lanes over)
+  uint32_t todo = lastc;
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 1, 64));
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 2, 64));
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 16, 64));
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 32, 64));
+  todo = min(todo, count);
+  uint32_t maxtodo = todo;
+  maxtodo = max(maxtodo, (uint32_t)__shfl_xor((int)maxtodo, 4, 64));
+  maxtodo = max(maxtodo, (uint32_t)__shfl_xor((int)maxtodo, 8, 64));
+  maxtodo = __builtin_amdgcn_readfirstlane(maxtodo);
+  if (k == 0 && x == 0) {
+    s_todo[wv][bq] = todo;
+    s_list[wv][bq] = (unsigned long long)NLIST * start + (unsigned long long)L * len;
+  }
+  // entries behind `todo` receive no gradient: their records are zero (16 lanes per block)
+  {
+    const uint32_t q16 = (uint32_t)(k * 4 + x);
+    for (uint32_t e = todo + q16; e < count; e += 16) {
+      float4* r = (float4*)(dsub + (size_t)list[e].y * RECF);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int f = 0; f < NG; f++) r[f] = z;
+    }
+  }
+  __syncthreads();                   // s_todo / s_list visible (every wave takes the same path up to here)
+  if (maxtodo == 0) return;          // wave-uniform
+
+  // selector / weight matrices of the MFMAs: lane (i = lane % 16, kk = lane / 16) supplies A[i][kk]
+  const float yt = (float)k - 1.5f;  // this lane group's row offset from the block centre
+  const int ai = lane & 15;
+  const float aU0 = ai == 0 ? 1.f : (ai == ROW_MY ? yt : (ai == ROW_MYY ? yt * yt : 0.f));
+  const float aU1 = ai == 1 ? 1.f : (ai == ROW_MXY ? yt : 0.f);
+  const float aU2 = ai == 2 ? 1.f : 0.f;
+  const float aCZ = ai == ROW_CZ ? 1.f : 0.f;
+  const float aP0 = ai == 3 ? 1.f : 0.f, aP1 = ai == 4 ? 1.f : 0.f, aP2 = ai == 5 ? 1.f : 0.f;   // mapping only
+
+  // staging: lane (sb = lane / 16, sq = lane % 16) loads entry sq of block sb's chunk
+  const int sb = lane >> 4, sq = lane & 15;
+  const uint32_t stodo = s_todo[wv][sb];
+  const uint2* __restrict__ slist = b.sublist + s_list[wv][sb];
+  auto entry_at = [&](uint32_t pos_from_back) -> uint2 {           // traversal position -> list entry (back to front)
+    return pos_from_back < stodo ? slist[stodo - 1u - pos_from_back] : make_uint2(0u, 0u);
+  };
+  {
+    const uint2 e0 = entry_at((uint32_t)sq);
+    const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)sq < stodo);
+    stg[wv][0][0][lane] = r0.A; stg[wv][0][1][lane] = r0.B; stg[wv][0][2][lane] = r0.C; srec[wv][0][lane] = e0.y;
+  }
+  uint2 en0 = entry_at(CH + (uint32_t)sq);
+  int cur = 0;
+
+  const bool z45_wave = __ballot(dL[4] != 0.f || dL[5] != 0.f) == 0ull;
+  auto run_chunks = [&](auto z45_tag) {
+    constexpr bool Z45 = decltype(z45_tag)::value;
+    for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
+      const SplatRec rn0 = load_rec<C>(g.splat, en0.x, base + CH + (uint32_t)sq < stodo);
+      const uint2 enn0 = entry_at(base + 2 * CH + (uint32_t)sq);
+      const float4 (*wS)[64] = stg[wv][cur];
+      const uint32_t* wR = srec[wv][cur];
+      const int r16 = bq * 16;
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
+      auto step = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t rec, const int s) {
+        const bool blk_on = base + (uint32_t)s < todo;                 // this block still has an entry at this step
+        const uint32_t pos = todo - 1u - (base + (uint32_t)s);          // 0-based index in the block's list (garbage when !blk_on)
+        const float dx = A.x - pxf, dy = A.y - pyf;
+        const float power = splat_power(dx, dy, A.z, A.w, B.x);
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, B.y * G);
+        const bool valid = blk_on && (pos < lastc) && !(power > 0.f) && !(alpha < ALPHA_MIN);
+        const float a_eff = valid ? alpha : 0.f;
+        const float G_eff = valid ? G : 0.f;
+        const float r = __builtin_amdgcn_rcpf(1.f - a_eff);
+        Tr *= r;                                                        // transmittance in front of this splat
+        const float w = a_eff * Tr;
+        float qd = B.z * dL[0];
+        qd = fmaf(B.w, dL[1], qd); qd = fmaf(Cc.x, dL[2], qd); qd = fmaf(Cc.y, dL[3], qd);
+        if (!Z45) { qd = fmaf(Cc.z, dL[4], qd); qd = fmaf(Cc.w, dL[5], qd); }
+        const float diff = qd - behind;
+        behind = fmaf(a_eff, diff, behind);
+        const float dLa = diff * Tr - Tf_bg * r;
+        const float u = B.y * dLa * G_eff;                             // dL/dG * G: its moments give d/dxy and d/dconic
+        const float udx = u * dx;
+        f32x4 D = {0.f, 0.f, 0.f, 0.f};
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(aU0, u, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(aU1, udx, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(aU2, udx * dx, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(aCZ, w * (Z45 ? dL[3] : fmaf(2.f * Cc.y, dL[5], dL[3])), D, 0, 0, 0);
+        if (MODE == 1) {
+          D = __builtin_amdgcn_mfma_f32_16x16x4f32(aP0, w * dL[0], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_16x16x4f32(aP1, w * dL[1], D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f32_16x16x4f32(aP2, w * dL[2], D, 0, 0, 0);
+        }
+        // lane (gq = lane / 16, column (block, x)) holds record floats 4 gq .. 4 gq + 3 of its pixel column: join the quad
+        float4 R;
+        float* Rp = (float*)&R;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float v = D[c];
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+          v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+          Rp[c] = v;
+        }
+        // the block's lanes are the only writers of the (block, splat) record: NG lanes store 16 bytes each
+        if (blk_on && x == 0 && k < NG) *(float4*)(dsub + (size_t)rec * RECF + 4 * k) = R;
+      };
+      // two register sets used alternately: the next step's LDS reads are in flight while the current one is evaluated
+      float4 A0 = wS[0][r16], B0 = wS[1][r16], C0 = wS[2][r16];
+      uint32_t t0 = wR[r16];
+      for (int s = 0; s < cnt; s += 2) {
+        const int s1 = s + 1 < cnt ? s + 1 : s;
+        const float4 A1 = wS[0][r16 + s1], B1 = wS[1][r16 + s1], C1 = wS[2][r16 + s1];
+        const uint32_t t1 = wR[r16 + s1];
+        step(A0, B0, C0, t0, s);
+        if (s + 1 < cnt) {
+          const int s2 = s + 2 < cnt ? s + 2 : s1;
+          A0 = wS[0][r16 + s2]; B0 = wS[1][r16 + s2]; C0 = wS[2][r16 + s2];
+          t0 = wR[r16 + s2];
+          step(A1, B1, C1, t1, s1);
+        }
+      }
+      stg[wv][cur ^ 1][0][lane] = rn0.A; stg[wv][cur ^ 1][1][lane] = rn0.B; stg[wv][cur ^ 1][2][lane] = rn0.C; srec[wv][cur ^ 1][lane] = en0.y;
+      en0 = enn0;
+    }
+  };
+  if (z45_wave) run_chunks(std::true_type{});
+  else run_chunks(std::false_type{});
+}
+
 void launch_composite_bwd2_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
+                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes, int gen) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
+  if (gen == 3) {
+    if (tracking)
+      hipLaunchKernelGGL((composite_bwd3_kernel<2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+    else
+      hipLaunchKernelGGL((composite_bwd3_kernel<1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+    return;
+  }
   if (tracking)
     hipLaunchKernelGGL((composite_bwd2_kernel<2>), dim3(grid), dim3(128), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
   else

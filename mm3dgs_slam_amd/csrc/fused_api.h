@@ -49,7 +49,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
                                 const PoseLossScale* pls = nullptr, float* loss4 = nullptr, int yshift = 0);
 // second-generation backward compositor (composite_bwd2.hip): 2 pixels per lane, MFMA block reduction; its records need yshift = 1
 void launch_composite_bwd2_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes);
+                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes, int gen = 2);
 // dl_planes: 6, or 4 when the caller guarantees that the silhouette / depth^2 planes of dL are zero AND need not be read
 // (the mapping loop's loss kernel does not even write them)
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,

@@ -166,6 +166,7 @@ struct CamDev {
   int sh_degree;
   int tilemap;  // 0: tile = workgroup id; 1: contiguous tile span per XCD
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
+  int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
   int fused_scan;   // 1: no scan_tiles launch, every scatter workgroup scans the tile counters itself (persistent state)
   const float* bg;
@@ -188,6 +189,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.sh_degree = c->sh_degree;
   d.tilemap = env_flag("MM3DGS_TILEMAP", 0);
   d.stats = env_flag("MM3DGS_STATS", 0);
+  d.exp = env_flag("MM3DGS_EXP", 0);
   d.sort_single = 0;
   d.fused_scan = 0;
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;

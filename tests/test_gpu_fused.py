@@ -568,8 +568,9 @@ def eng_grads(eng, g):
     return eng.grads
 
 
+@pytest.mark.parametrize("gen", ["2", "3"])
 @pytest.mark.parametrize("mode", ["map", "track"])
-def test_second_generation_backward_compositor_matches_the_first(mode, monkeypatch):
+def test_second_generation_backward_compositor_matches_the_first(mode, gen, monkeypatch):
     """composite_bwd2_kernel (2 pixels per lane, MFMA block reduction, y-moments about the block centre shifted in the gather)
     against composite_bwd_kernel (DPP butterflies): same decisions, same per-pixel arithmetic, different summation trees."""
     from mm3dgs_slam_amd.fused import FusedEngine
@@ -578,7 +579,7 @@ def test_second_generation_backward_compositor_matches_the_first(mode, monkeypat
         with torch.no_grad():
             g._scaling += scale_up
         res = []
-        for flag in ("0", "1"):
+        for flag in ("0", gen):      # MM3DGS_BWD2: 0 first generation, 2 / 3 the MFMA-reduction kernels (2 px / 1 px per lane)
             monkeypatch.setenv("MM3DGS_BWD2", flag)
             eng = FusedEngine(R)
             si = eng.forward(pose, g, need_grads=True)
