@@ -217,6 +217,31 @@ int mm3dgs_loss(const Mm3dgsLossConfig* cfg, const float* out6, const float* gt_
 typedef struct Mm3dgsAdamGroup { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; double lr; } Mm3dgsAdamGroup;
 int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double beta1, double beta2, double eps, void* stream);
 
+/* =====================================================================================================
+ * Map surgery on the device: pruning predicate, order-preserving compaction of the
+ * per-Gaussian SoA state, seeding of new Gaussians.  Replaces the torch nonzero / index_select / cat machinery of
+ * slam/gaussian_model.py:380-451 (prune_points, _prune_optimizer) and slam/mapper.py:409-493,644-668 (get_pointcloud +
+ * initialisation of the new rows).  All asynchronous; the counts land in device words the caller reads when it chooses to.
+ * ===================================================================================================== */
+/* keep[i] = 0 where  sigmoid(opacity[i]) < min_opacity  ||  max_k exp(log_scales[i,k]) > max_scale  ||
+ * (max_radii2D != NULL && max_radii2D[i] > max_screen_size)   (slam/gaussian_model.py:574-588), else 1;
+ * *n_pruned_accum += number of zeros written (a sticky counter: never reset by the library). */
+int mm3dgs_prune_mask(int P, const float* opacity_logits, const float* log_scales, const float* max_radii2D_or_null, float min_opacity,
+                      float max_scale, float max_screen_size, uint8_t* keep, uint32_t* n_pruned_accum, void* stream);
+/* Ranks of the kept elements of keep[0..n) in order: `work` (mm3dgs_compact_work_bytes(n)) receives the plan, *n_keep the total. */
+size_t mm3dgs_compact_work_bytes(size_t n);
+int mm3dgs_compact_plan(size_t n, const uint8_t* keep, void* work, uint32_t* n_keep, void* stream);
+/* dst[rank(i)][0..width) = src[i][0..width) for every kept i, for up to 32 arrays in one launch (rows are `width` floats). */
+typedef struct Mm3dgsCompactArray { const float* src; float* dst; int32_t width; } Mm3dgsCompactArray;
+int mm3dgs_compact_rows(size_t n, const uint8_t* keep, const void* work, const Mm3dgsCompactArray* arrays, int n_arrays, void* stream);
+/* One new Gaussian per kept pixel (raster order) of an RGB-D frame, written to rows row0 + rank of the output arrays:
+ * xyz = back-projection through `pose` (world->camera 7-vector), log-scale log(z / ((fx+fy)/2)) on all three axes, opacity logit 0,
+ * identity quaternion, f_dc = (rgb - 0.5) / C0, f_rest = 0 (n_rest coefficients), rgb = colour.  Plan from mm3dgs_compact_plan(H*W). */
+typedef struct Mm3dgsSeedOutputs { float* xyz; float* f_dc; float* f_rest; float* opacity; float* scaling; float* rotation; float* rgb; } Mm3dgsSeedOutputs;
+int mm3dgs_seed_gaussians(int H, int W, const float* color /*[3,H,W]*/, const float* depth /*[H,W]*/, const uint8_t* keep, const void* work,
+                          const float* pose, float fx, float fy, float cx, float cy, uint32_t row0, const Mm3dgsSeedOutputs* out, int n_rest,
+                          void* stream);
+
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
  * (timed) launches and their summed duration since the previous read, and resets the counters. */

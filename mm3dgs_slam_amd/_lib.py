@@ -60,8 +60,23 @@ class Mm3dgsAdamGroup(C.Structure):
                 ("n", C.c_uint64), ("lr", C.c_double)]
 
 
+class Mm3dgsCompactArray(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", C.c_int32)]
+
+
+class Mm3dgsSeedOutputs(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("f_dc", C.c_void_p), ("f_rest", C.c_void_p), ("opacity", C.c_void_p), ("scaling", C.c_void_p),
+                ("rotation", C.c_void_p), ("rgb", C.c_void_p)]
+
+
 _P = C.c_void_p
 _SIGS = {
+    "mm3dgs_prune_mask": (C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
+    "mm3dgs_compact_work_bytes": (C.c_size_t, [C.c_size_t]),
+    "mm3dgs_compact_plan": (C.c_int, [C.c_size_t, _P, _P, _P, _P]),
+    "mm3dgs_compact_rows": (C.c_int, [C.c_size_t, _P, _P, C.POINTER(Mm3dgsCompactArray), C.c_int, _P]),
+    "mm3dgs_seed_gaussians": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_uint32,
+                                        C.POINTER(Mm3dgsSeedOutputs), C.c_int, _P]),
     "mm3dgs_geom_bytes": (C.c_size_t, [C.c_int]),
     "mm3dgs_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_binning_bytes": (C.c_size_t, [C.c_size_t]),

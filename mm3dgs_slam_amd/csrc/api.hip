@@ -456,6 +456,48 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double be
   return check_launch("adam");
 }
 
+// ---- map surgery (compact.hip) -----------------------------------------------------------------------------------------
+int mm3dgs_prune_mask(int P, const float* opacity, const float* log_scales, const float* max_radii2D, float min_opacity, float max_scale,
+                      float max_screen_size, uint8_t* keep, uint32_t* n_pruned_accum, void* stream) {
+  if (P < 0) return fail(-1, "P < 0");
+  if (P > 0 && (!opacity || !log_scales || !keep || !n_pruned_accum)) return fail(-1, "NULL argument");
+  launch_prune_mask(P, opacity, log_scales, max_radii2D, min_opacity, max_scale, max_screen_size, max_radii2D ? 1 : 0, keep, n_pruned_accum,
+                    (hipStream_t)stream);
+  return check_launch("prune_mask");
+}
+size_t mm3dgs_compact_work_bytes(size_t n) { return align_up(((n + 255) / 256 + 1) * 4, 256); }
+int mm3dgs_compact_plan(size_t n, const uint8_t* keep, void* work, uint32_t* n_keep, void* stream) {
+  if (n > 0x7fffffffull) return fail(-1, "n too large");
+  if (!work || !n_keep || (n > 0 && !keep)) return fail(-1, "NULL argument");
+  launch_compact_plan((int)n, keep, (uint32_t*)work, n_keep, (hipStream_t)stream);
+  return check_launch("compact_plan");
+}
+int mm3dgs_compact_rows(size_t n, const uint8_t* keep, const void* work, const Mm3dgsCompactArray* arrays, int n_arrays, void* stream) {
+  if (n > 0x7fffffffull) return fail(-1, "n too large");
+  if (n_arrays < 0 || n_arrays > 32) return fail(-1, "at most 32 arrays per call");
+  if (n > 0 && (!keep || !work || (n_arrays > 0 && !arrays))) return fail(-1, "NULL argument");
+  CompactTable t;
+  t.n_arrays = 0;
+  for (int a = 0; a < n_arrays; a++) {
+    if (arrays[a].width < 0) return fail(-1, "array %d: negative width", a);
+    if (arrays[a].width == 0) continue;     // empty rows (e.g. f_rest at SH degree 0)
+    if (!arrays[a].src || !arrays[a].dst) return fail(-1, "array %d: NULL pointer", a);
+    t.src[t.n_arrays] = arrays[a].src; t.dst[t.n_arrays] = arrays[a].dst; t.width[t.n_arrays] = arrays[a].width; t.n_arrays++;
+  }
+  launch_compact_rows((int)n, keep, (const uint32_t*)work, t, (hipStream_t)stream);
+  return check_launch("compact_rows");
+}
+int mm3dgs_seed_gaussians(int H, int W, const float* color, const float* depth, const uint8_t* keep, const void* work, const float* pose, float fx,
+                          float fy, float cx, float cy, uint32_t row0, const Mm3dgsSeedOutputs* out, int n_rest, void* stream) {
+  if (H <= 0 || W <= 0 || (double)H * W > 2147483647.0) return fail(-1, "bad image size");
+  if (!color || !depth || !keep || !work || !pose || !out) return fail(-1, "NULL argument");
+  if (!out->xyz || !out->f_dc || !out->opacity || !out->scaling || !out->rotation || !out->rgb || (n_rest > 0 && !out->f_rest))
+    return fail(-1, "NULL output array");
+  SeedOut o = {out->xyz, out->f_dc, out->f_rest, out->opacity, out->scaling, out->rotation, out->rgb, n_rest > 0 ? n_rest : 0};
+  launch_seed_gaussians(H, W, color, depth, keep, (const uint32_t*)work, pose, fx, fy, cx, cy, row0, o, (hipStream_t)stream);
+  return check_launch("seed_gaussians");
+}
+
 int mm3dgs_mark_visible(const Mm3dgsCamera* cam, int P, const float* means3D, uint8_t* visible, void* stream) {
   if (!cam || !cam->viewmatrix || (P > 0 && (!means3D || !visible))) return fail(-1, "NULL buffer");
   launch_mark_visible(cam_dev(cam), P, means3D, visible, (hipStream_t)stream);

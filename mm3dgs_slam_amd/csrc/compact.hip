@@ -1,0 +1,156 @@
+// Map surgery on the device (8f row 2): the pruning predicate, order-preserving stream compaction of the
+// SoA state (parameters + Adam moments + densification statistics) and the seeding of new Gaussians from an RGB-D frame.
+//
+// Reference: slam/gaussian_model.py:380-451 (prune_points / _prune_optimizer: every per-Gaussian tensor keeps the rows with
+// mask == false, in order), :574-588 (prune: sigmoid(opacity) < min_opacity, max exp(scaling) > 0.1 extent, max_radii2D > size
+// threshold), slam/mapper.py:409-493,600-688 (one Gaussian per selected pixel in raster order: back-projected position,
+// log-scale log(z / ((fx + fy) / 2)) on all axes, opacity logit 0, identity quaternion, f_dc = (rgb - 0.5) / C0).
+//
+// Compaction = three small launches over `n` flagged elements (Gaussians or pixels): per-256 counts, one workgroup scanning the
+// counts, scatter by rank.  Order preserving and deterministic (no atomics decide a position).
+#include "mm3dgs_common.h"
+#include "fused_api.h"
+
+#define CB 256
+
+// keep[i] = !pruned; *n_pruned += number of pruned elements (sticky device counter: the host may read it much later)
+__global__ void __launch_bounds__(CB)
+prune_mask_kernel(int P, const float* __restrict__ opacity, const float* __restrict__ scaling, const float* __restrict__ max_radii2D,
+                  float min_opacity, float max_scale, float max_screen_size, int use_screen, uint8_t* __restrict__ keep,
+                  uint32_t* __restrict__ n_pruned) {
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool pr = false;
+  if (i < P) {
+    const float o = 1.f / (1.f + expf(-opacity[i]));      // (accurate exp: the decisions must match torch.sigmoid / torch.exp)
+    const float s = fmaxf(fmaxf(scaling[(size_t)i * 3], scaling[(size_t)i * 3 + 1]), scaling[(size_t)i * 3 + 2]);
+    pr = (o < min_opacity) || (expf(s) > max_scale) || (use_screen && max_radii2D[i] > max_screen_size);
+    keep[i] = pr ? 0 : 1;
+  }
+  const unsigned long long m = __ballot(pr);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_pruned, (uint32_t)__popcll(m));
+}
+
+__global__ void __launch_bounds__(CB) compact_count_kernel(int n, const uint8_t* __restrict__ keep, uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t wsum[CB / 64];
+  const int i = blockIdx.x * CB + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && keep[i] != 0);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one workgroup: block_counts[0..nb) -> exclusive prefix in place, total to *n_keep
+__global__ void __launch_bounds__(1024) compact_scan_kernel(int nb, uint32_t* __restrict__ block_counts, uint32_t* __restrict__ n_keep) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nb ? block_counts[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wtot[wv] = x;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wv; w++) pre += wtot[w];
+    if (i < nb) block_counts[i] = pre + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + x;
+    __syncthreads();
+  }
+  if (tid == 0) *n_keep = carry;
+}
+
+// rank[i] = position of element i among the kept ones (only meaningful where keep[i])
+__device__ __forceinline__ uint32_t compact_rank(int i, int n, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ block_pre,
+                                                 bool& kept, uint32_t* wsum) {
+  kept = i < n && keep[i] != 0;
+  const unsigned long long m = __ballot(kept);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t pre = block_pre[blockIdx.x];
+  for (int w = 0; w < wv; w++) pre += wsum[w];
+  return pre + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(CB)
+compact_rows_kernel(int n, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ block_pre, CompactTable t) {
+  __shared__ uint32_t wsum[CB / 64];
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool kept;
+  const uint32_t r = compact_rank(i, n, keep, block_pre, kept, wsum);
+  if (!kept) return;
+  for (int a = 0; a < t.n_arrays; a++) {
+    const int w = t.width[a];
+    const float* s = t.src[a] + (size_t)i * w;
+    float* d = t.dst[a] + (size_t)r * w;
+    for (int c = 0; c < w; c++) d[c] = s[c];
+  }
+}
+
+// pixel i (raster order) with keep[i] seeds Gaussian row0 + rank(i)
+__global__ void __launch_bounds__(CB)
+seed_gaussians_kernel(int H, int W, const float* __restrict__ color, const float* __restrict__ depth, const uint8_t* __restrict__ keep,
+                      const uint32_t* __restrict__ block_pre, const float* __restrict__ pose, float fx, float fy, float cx, float cy, uint32_t row0,
+                      SeedOut o) {
+  __shared__ uint32_t wsum[CB / 64];
+  const int n = H * W;
+  const int i = blockIdx.x * CB + threadIdx.x;
+  bool kept;
+  const uint32_t r = row0 + compact_rank(i, n, keep, block_pre, kept, wsum);
+  if (!kept) return;
+  // camera-to-world of the world-to-camera pose (qw,qx,qy,qz,tx,ty,tz): x_w = R^T (x_c - t)
+  float qw = pose[0], qx = pose[1], qy = pose[2], qz = pose[3];
+  const float qn = 1.f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+  qw *= qn; qx *= qn; qy *= qn; qz *= qn;
+  const float R[3][3] = {{1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qw * qz), 2.f * (qx * qz + qw * qy)},
+                         {2.f * (qx * qy + qw * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qw * qx)},
+                         {2.f * (qx * qz - qw * qy), 2.f * (qy * qz + qw * qx), 1.f - 2.f * (qx * qx + qy * qy)}};
+  const int u = i % W, v = i / W;
+  const float z = depth[i];
+  const float c[3] = {((float)u - cx) / fx * z - pose[4], ((float)v - cy) / fy * z - pose[5], z - pose[6]};
+#pragma unroll
+  for (int a = 0; a < 3; a++) o.xyz[(size_t)r * 3 + a] = R[0][a] * c[0] + R[1][a] * c[1] + R[2][a] * c[2];
+  const float ls = logf(z / ((fx + fy) * 0.5f));     // log sqrt((z / f)^2)
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float rgb = color[(size_t)a * n + i];
+    o.rgb[(size_t)r * 3 + a] = rgb;
+    o.f_dc[(size_t)r * 3 + a] = (rgb - 0.5f) / 0.28209479177387814f;
+    o.scaling[(size_t)r * 3 + a] = ls;
+  }
+  for (int a = 0; a < o.n_rest * 3; a++) o.f_rest[(size_t)r * o.n_rest * 3 + a] = 0.f;
+  o.opacity[r] = 0.f;
+  o.rotation[(size_t)r * 4] = 1.f; o.rotation[(size_t)r * 4 + 1] = 0.f; o.rotation[(size_t)r * 4 + 2] = 0.f; o.rotation[(size_t)r * 4 + 3] = 0.f;
+}
+
+// ---- launchers (called from api.hip) ------------------------------------------------------------------------------------------
+void launch_prune_mask(int P, const float* opacity, const float* scaling, const float* max_radii2D, float min_opacity, float max_scale,
+                       float max_screen_size, int use_screen, uint8_t* keep, uint32_t* n_pruned, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(prune_mask_kernel, dim3((P + CB - 1) / CB), dim3(CB), 0, s, P, opacity, scaling, max_radii2D, min_opacity, max_scale,
+                     max_screen_size, use_screen, keep, n_pruned);
+}
+void launch_compact_plan(int n, const uint8_t* keep, uint32_t* block_pre, uint32_t* n_keep, hipStream_t s) {
+  const int nb = (n + CB - 1) / CB;
+  if (n > 0) hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(CB), 0, s, n, keep, block_pre);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, n > 0 ? nb : 0, block_pre, n_keep);
+}
+void launch_compact_rows(int n, const uint8_t* keep, const uint32_t* block_pre, const CompactTable& t, hipStream_t s) {
+  if (n <= 0 || t.n_arrays <= 0) return;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((n + CB - 1) / CB), dim3(CB), 0, s, n, keep, block_pre, t);
+}
+void launch_seed_gaussians(int H, int W, const float* color, const float* depth, const uint8_t* keep, const uint32_t* block_pre,
+                           const float* pose, float fx, float fy, float cx, float cy, uint32_t row0, const SeedOut& o, hipStream_t s) {
+  const int n = H * W;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(seed_gaussians_kernel, dim3((n + CB - 1) / CB), dim3(CB), 0, s, H, W, color, depth, keep, block_pre, pose, fx, fy, cx, cy,
+                     row0, o);
+}

@@ -62,3 +62,14 @@ void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const fl
                  float* dL, float* loss, hipStream_t s);
 void launch_loss_after_forward_rows(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums,
                                     double* partial, float* dL, hipStream_t s);
+
+// ---- map surgery (compact.hip) ----
+struct CompactTable { const float* src[32]; float* dst[32]; int width[32]; int n_arrays; };
+struct SeedOut { float* xyz; float* f_dc; float* f_rest; float* opacity; float* scaling; float* rotation; float* rgb; int n_rest; };
+void launch_prune_mask(int P, const float* opacity, const float* scaling, const float* max_radii2D, float min_opacity, float max_scale,
+                       float max_screen_size, int use_screen, uint8_t* keep, uint32_t* n_pruned, hipStream_t s);
+void launch_compact_plan(int n, const uint8_t* keep, uint32_t* block_pre, uint32_t* n_keep, hipStream_t s);
+void launch_compact_rows(int n, const uint8_t* keep, const uint32_t* block_pre, const CompactTable& t, hipStream_t s);
+void launch_seed_gaussians(int H, int W, const float* color, const float* depth, const uint8_t* keep, const uint32_t* block_pre,
+                           const float* pose, float fx, float fy, float cx, float cy, uint32_t row0, const SeedOut& o, hipStream_t s);
+

@@ -157,10 +157,13 @@ class FusedEngine:
         covers every iteration and every view of it.  Updates the capacity model from the LARGEST pair count seen, clears the
         sticky words, and returns False if any forward overflowed (its tile lists were clamped, so the loop's results are
         invalid: the caller restores its state and re-runs with the capacity this call has already raised)."""
-        h = self.img_state[:16].view(torch.int32).cpu()
+        h = self.img_state[:32].view(torch.int32).cpu()
         overflow, n_max = int(h[1]), int(h[3])
         self.max_tile_len = int(h[2])
+        self.pruned_count = int(h[7])      # speculative pruning steps of the mapping loop add here (FusedMapper)
         self.img_state[4:16].zero_()
+        if self.pruned_count:
+            self.img_state[28:32].zero_()
         self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
         self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
         return not overflow
@@ -250,6 +253,32 @@ class FusedMapper(Mapper):
                 return eng.out[3], eng.out[4]
         raise RuntimeError("mm3dgs: render kept overflowing its binning capacity")
 
+    def initialize_new_gaussians(self, idx, camera_pose, gt_color, gt_depth=None, est_depth=None):
+        """New-keyframe seeding (slam/mapper.py:409-493,600-688) with the non-presence test on one native render and the new rows
+        written by the seeding kernel (csrc/compact.hip) instead of meshgrid / boolean-mask gathers / RGB2SH / cat."""
+        if not FusedEngine.eligible(self.cfg, self.gaussians) or not self.gaussians._native():
+            return super().initialize_new_gaussians(idx, camera_pose, gt_color, gt_depth, est_depth)
+        depth = gt_depth if self.cfg["use_gt_depth"] else est_depth
+        dev = depth.device
+        with torch.no_grad():
+            if idx == 0 and "iteration" not in self.cfg:
+                non_presence = torch.ones(depth.numel(), dtype=torch.bool, device=dev)
+            else:
+                rdepth, sil = self._render_depth_sil(camera_pose)
+                err = (depth - rdepth).abs() * (depth > 0)
+                non_presence = ((sil < 0.5) | (err > 10 * err.median())).reshape(-1)
+            non_presence = non_presence & (depth > 0).reshape(-1)
+            frac = float(self.cfg["mapping"].get("seed_fraction", 1.0))
+            if frac < 1.0:     # workload knob (not in the reference): seed only a fixed pseudo-random subset of the pixels
+                gen = torch.Generator(device="cpu").manual_seed(1234 + idx)
+                non_presence = non_presence & (torch.rand(non_presence.numel(), generator=gen) < frac).to(dev)
+            fx, fy, cx, cy = self._intr()
+            P0 = int(self.gaussians.get_xyz.shape[0])
+            n = self.gaussians.seed_device(gt_color, depth, non_presence.reshape(depth.shape), camera_pose, fx, fy, cx, cy)
+            new_mask = torch.zeros(P0 + n, dtype=torch.bool, device=dev)
+            new_mask[P0:] = True
+        return new_mask, non_presence.reshape(depth.shape)
+
     def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]
@@ -300,14 +329,22 @@ class FusedMapper(Mapper):
         # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
         # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
         # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
+        # Pruning is speculative in the same way: a pruning step only evaluates the predicate on the device and COUNTS (the map of
+        # a running SLAM session almost never has anything to prune, and the reference's prune needs a host round trip for the
+        # new size); if the count read back at the end is not zero, the loop is re-run with exact pruning steps.
         snap, rng_state = g.snapshot(), _random.getstate()
-        for attempt in range(4):
-            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
+        exact_prune = False
+        for attempt in range(5):
+            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, exact_prune)
             ok = eng.check_capacity()
+            redo_exact = eng.pruned_count > 0 and not exact_prune
+            ok = ok and not redo_exact
             if self.window is not None and self.window.world > 1:
                 ok = not self.window.any_flag(not ok, device=eng.dev)
+                redo_exact = self.window.any_flag(redo_exact, device=eng.dev)
             if ok:
                 break
+            exact_prune = exact_prune or redo_exact
             g.restore(snap)
             _random.setstate(rng_state)
             stack = None
@@ -315,7 +352,7 @@ class FusedMapper(Mapper):
             raise RuntimeError("mm3dgs: mapping loop kept overflowing its binning capacity")
         self.mapping_iter_count += num_iter
 
-    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
+    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, exact_prune=False):
         with torch.no_grad():
             iteration = 0
             while iteration < num_iter:
@@ -367,7 +404,10 @@ class FusedMapper(Mapper):
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
                     eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads)
                 if prune_now:
-                    g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    if exact_prune:
+                        g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    else:       # speculative: predicate + count on the device, no host round trip (see optimize_map)
+                        g.prune_mask_device(m["min_opacity"], self.camera_extent, m["size_threshold"], counter_ptr=eng.img_state.data_ptr() + 28)
                 iteration += 1
 
     def _inline_adam(self, n=1):

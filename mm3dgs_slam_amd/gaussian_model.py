@@ -161,6 +161,124 @@ class GaussianModel:
         self._assign(out)
         self.xyz_gradient_accum, self.denom, self.max_radii2D = (t.clone() for t in snap["stats"])
 
+    # ---- device-side surgery (csrc/compact.hip through the C ABI; CUDA tensors only) ---------------------------------------
+    def _native(self):
+        return str(self.cfg["device"]).startswith("cuda")
+
+    def prune_mask_device(self, min_opacity, extent, max_screen_size=None, counter_ptr=None):
+        """The pruning predicate of ``prune`` evaluated by one kernel: returns the uint8 keep mask; the number of pruned
+        Gaussians is ADDED to the device word at ``counter_ptr`` (no host synchronisation)."""
+        import ctypes as C
+        from . import _lib
+        from .rasterizer import _stream
+        lib = _lib.load()
+        P = int(self._xyz.shape[0])
+        keep = torch.empty(P, dtype=torch.uint8, device=self._xyz.device)
+        if counter_ptr is None:
+            self._prune_counter = torch.zeros(1, dtype=torch.int32, device=self._xyz.device)
+            counter_ptr = self._prune_counter.data_ptr()
+        radii = self.max_radii2D if max_screen_size is not None else None
+        _lib.check(lib.mm3dgs_prune_mask(P, C.c_void_p(self._opacity.data_ptr()), C.c_void_p(self._scaling.data_ptr()),
+                                         C.c_void_p(radii.data_ptr()) if radii is not None else None, float(min_opacity), float(0.1 * extent),
+                                         float(max_screen_size if max_screen_size is not None else 0.0), C.c_void_p(keep.data_ptr()),
+                                         C.c_void_p(counter_ptr), _stream()))
+        return keep
+
+    def compact_device(self, keep):
+        """``prune_points(~keep)`` with the order-preserving compaction kernels: one plan (counts + scan), ONE 4-byte read-back
+        for the new size, one scatter launch over every parameter, Adam moment and statistic (instead of a nonzero and ~24
+        index_select launches).  Nothing to prune leaves every tensor in place, like ``prune_points``."""
+        import ctypes as C
+        from . import _lib
+        from .rasterizer import _stream
+        lib = _lib.load()
+        P = int(keep.shape[0])
+        dev = keep.device
+        work = torch.empty(lib.mm3dgs_compact_work_bytes(P), dtype=torch.uint8, device=dev)
+        n_keep = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mm3dgs_compact_plan(P, C.c_void_p(keep.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(n_keep.data_ptr()), _stream()))
+        n = int(n_keep.item())
+        if n == P:
+            for group in self.optimizer.param_groups:
+                group["params"][0].grad = None
+            return
+        pairs = []                      # (old tensor, new tensor)
+
+        def moved(t):
+            new = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            pairs.append((t.detach(), new))
+            return new
+        out = {}
+        self.generation += 1
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            new = nn.Parameter(moved(old).requires_grad_(True))
+            if state is not None and "exp_avg" in state:
+                state["exp_avg"], state["exp_avg_sq"] = moved(state["exp_avg"]), moved(state["exp_avg_sq"])
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            out[group["name"]] = new
+        self._assign(out)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = moved(self.xyz_gradient_accum), moved(self.denom), moved(self.max_radii2D)
+        table = (_lib.Mm3dgsCompactArray * 32)()
+        k = 0
+        for old, new in pairs:
+            w = int(old[0].numel()) if old.shape[0] > 0 else 0
+            if w == 0:
+                continue
+            table[k].src, table[k].dst, table[k].width = old.data_ptr(), new.data_ptr(), w
+            k += 1
+        _lib.check(lib.mm3dgs_compact_rows(P, C.c_void_p(keep.data_ptr()), C.c_void_p(work.data_ptr()), table, k, _stream()))
+        self._surgery_keepalive = (pairs, keep, work)      # the launch is asynchronous
+
+    def seed_device(self, color, depth, mask, pose, fx, fy, cx, cy):
+        """``densification_postfix`` with the rows of the new Gaussians written by the seeding kernel: one Gaussian per pixel of
+        ``mask`` (bool [H,W], raster order), initialised as slam/mapper.py:437-474,644-668 do.  Returns the number added."""
+        import ctypes as C
+        from . import _lib
+        from .rasterizer import _stream
+        lib = _lib.load()
+        dev = depth.device
+        H, W = depth.shape
+        keep = mask.reshape(-1).to(torch.uint8).contiguous()
+        work = torch.empty(lib.mm3dgs_compact_work_bytes(H * W), dtype=torch.uint8, device=dev)
+        n_new = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.mm3dgs_compact_plan(H * W, C.c_void_p(keep.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(n_new.data_ptr()), _stream()))
+        n = int(n_new.item())           # (a keyframe event: the new size must be known to allocate)
+        P = int(self._xyz.shape[0])
+
+        def grown(t, zero_tail):
+            new = (torch.zeros if zero_tail else torch.empty)((P + n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            if P:
+                new[:P].copy_(t.detach())
+            return new
+        out = {}
+        self.generation += 1
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            new = nn.Parameter(grown(old, False).requires_grad_(True))
+            if state is not None and "exp_avg" in state:
+                state["exp_avg"], state["exp_avg_sq"] = grown(state["exp_avg"], True), grown(state["exp_avg_sq"], True)
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            out[group["name"]] = new
+        self._assign(out)
+        so = _lib.Mm3dgsSeedOutputs()
+        so.xyz, so.f_dc, so.f_rest = self._xyz.data_ptr(), self._features_dc.data_ptr(), self._features_rest.data_ptr()
+        so.opacity, so.scaling, so.rotation, so.rgb = self._opacity.data_ptr(), self._scaling.data_ptr(), self._rotation.data_ptr(), self._rgb.data_ptr()
+        color, depth, pose = color.contiguous().float(), depth.contiguous().float(), pose.detach().contiguous().float()
+        if n:
+            _lib.check(lib.mm3dgs_seed_gaussians(H, W, C.c_void_p(color.data_ptr()), C.c_void_p(depth.data_ptr()), C.c_void_p(keep.data_ptr()),
+                                                 C.c_void_p(work.data_ptr()), C.c_void_p(pose.data_ptr()), float(fx), float(fy), float(cx), float(cy),
+                                                 P, C.byref(so), int(self._features_rest.shape[1]), _stream()))
+        self.xyz_gradient_accum = torch.zeros((P + n, 1), device=dev)
+        self.denom = torch.zeros((P + n, 1), device=dev)
+        self.max_radii2D = torch.zeros((P + n,), device=dev)
+        self._surgery_keepalive = (keep, work, color, depth, pose)
+        return n
+
     def prune_points(self, mask):
         # ONE nonzero (one host sync) shared by the ~24 tensors instead of a boolean-mask gather (= nonzero + sync) per
         # tensor; nothing to prune (the common case in SLAM: two pruning steps per frame) leaves every tensor, parameter
@@ -189,6 +307,11 @@ class GaussianModel:
         self.max_radii2D = torch.zeros((n,), device=dev)
 
     def prune(self, min_opacity, extent, max_screen_size=None):
+        if self._native():
+            # predicate, plan and compaction on the device (three small launches + a 4-byte read-back of the new size)
+            keep = self.prune_mask_device(min_opacity, extent, max_screen_size)
+            self.compact_device(keep)
+            return keep == 0
         mask = (self.get_opacity < min_opacity).squeeze(-1)
         big = self.get_scaling.max(dim=1).values > 0.1 * extent
         if max_screen_size is not None:

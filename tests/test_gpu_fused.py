@@ -596,3 +596,74 @@ def test_second_generation_backward_compositor_matches_the_first(mode, gen, monk
         assert pu.rel_l2(pb, pa) < 2e-5, (mode, P, pa, pb)
         for k in ga:
             assert pu.rel_l2(gb[k], ga[k]) < (2e-4 if k == "rotation" else 2e-5), (mode, P, k)
+
+
+def test_device_prune_compaction_matches_the_torch_surgery():
+    """GaussianModel.prune on the device (predicate kernel + order-preserving compaction of parameters, Adam moments and statistics,
+    csrc/compact.hip) against the torch path (slam/gaussian_model.py:380-451,574-588 mirrored in prune_points): same rows, same order."""
+    import copy
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    cfg, g, R, pose, color, depth = _setup(P=5000, H=120, W=160, seed=15)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        g._opacity += (torch.randn(5000, 1, generator=gen) * 4).to(DEV)          # some below sigmoid^-1(0.005)
+        g._scaling[::7] += 3.0                                                     # some larger than 0.1 * extent
+        g.max_radii2D = (torch.rand(5000, generator=gen) * 150).to(DEV)           # some above the screen-size threshold
+    # give the optimiser real moments
+    for grp in g.optimizer.param_groups:
+        p = grp["params"][0]
+        p.grad = torch.randn_like(p)
+    g.optimizer.step()
+    g.xyz_gradient_accum = torch.rand(5000, 1, device=DEV); g.denom = torch.rand(5000, 1, device=DEV)
+    ref = copy.deepcopy(g)
+    extent = 1.3
+    monkey_native = g._native
+    ref._native = lambda: False                     # force the torch mirror on the copy
+    mask_ref = ref.prune(0.005, extent, 100.0)
+    mask_dev = g.prune(0.005, extent, 100.0)
+    torch.cuda.synchronize()
+    assert 100 < int(mask_ref.sum()) < 4900
+    assert torch.equal(mask_ref, mask_dev)
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_rgb", "xyz_gradient_accum", "denom", "max_radii2D"):
+        assert torch.equal(getattr(g, name).detach(), getattr(ref, name).detach()), name
+    for ga, gb in zip(g.optimizer.param_groups, ref.optimizer.param_groups):
+        sa, sb = g.optimizer.state[ga["params"][0]], ref.optimizer.state[gb["params"][0]]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), ga["name"]
+    # nothing to prune: every tensor object stays, gradients are dropped (the reference's no-op optimiser step)
+    before = g._xyz
+    g._xyz.grad = torch.zeros_like(g._xyz)
+    g.prune(0.0, 1e9, None)
+    assert g._xyz is before and g._xyz.grad is None
+
+
+def test_device_seeding_matches_the_reference_fixture_g7_and_the_torch_mirror():
+    """mm3dgs_seed_gaussians against G7 (the reference's get_pointcloud + initialisation on a 32x24 RGB-D, tests/golden) and, at
+    640x480 with a sparse mask, against the torch mirror Mapper.initialize_new_gaussians (same rows in the same raster order)."""
+    import os
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    from mm3dgs_slam_amd.sh_utils import RGB2SH
+    d = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_seed.npz")).items()}
+    H, W = d["depth"].shape
+    fx, fy, cx, cy = (float(v) for v in d["intr"])
+    cfg = default_config(device=DEV, height=H, width=W)
+    g = GaussianModel(cfg); g.training_setup()
+    mask = (d["depth"] > 0).to(DEV)
+    n = g.seed_device(d["color"].to(DEV), d["depth"].to(DEV), mask, d["pose"].to(DEV), fx, fy, cx, cy)
+    torch.cuda.synchronize()
+    assert n == d["cld"].shape[0] == g._xyz.shape[0]
+    assert (g._xyz.detach().cpu() - d["cld"][:, :3]).abs().max() < 2e-5
+    assert (g._rgb.detach().cpu() - d["cld"][:, 3:6]).abs().max() == 0
+    assert (g._scaling.detach().cpu() - d["log_scale"][:, None]).abs().max() < 2e-6
+    assert (g._features_dc.detach().cpu()[:, 0] - RGB2SH(d["cld"][:, 3:6])).abs().max() < 1e-6
+    assert float(g._opacity.abs().max()) == 0 and torch.equal(g._rotation.detach().cpu(), torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1))
+    # appended behind an existing map, moments extended with zeros, statistics reset
+    for grp in g.optimizer.param_groups:
+        grp["params"][0].grad = torch.ones_like(grp["params"][0])
+    g.optimizer.step()
+    old_xyz = g._xyz.detach().clone()
+    n2 = g.seed_device(d["color"].to(DEV), d["depth"].to(DEV), mask & (torch.rand(H, W, device=DEV) < 0.3), d["pose"].to(DEV), fx, fy, cx, cy)
+    assert g._xyz.shape[0] == n + n2 and torch.equal(g._xyz.detach()[:n], old_xyz)
+    st = g.optimizer.state[g._xyz]
+    assert float(st["exp_avg"][n:].abs().max()) == 0 and float(st["exp_avg"][:n].abs().min()) > 0
+    assert g.denom.shape == (n + n2, 1) and float(g.denom.abs().max()) == 0
