@@ -348,7 +348,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.profile_enable(False)
     prof = _lib.profile_read()
-    log(f"timed region done: {elapsed:.2f} s")
+    log(f"timed region done: {elapsed:.2f} s; mapping loops re-run after a binning overflow: {getattr(slam.mapper, 'loop_reruns', 0)}")
     if phases:
         for k, v in phases.items():
             log(f"  phase {k:34s} {v / args.steps * 1e3:8.2f} ms/frame")

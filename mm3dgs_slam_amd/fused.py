@@ -157,13 +157,10 @@ class FusedEngine:
         covers every iteration and every view of it.  Updates the capacity model from the LARGEST pair count seen, clears the
         sticky words, and returns False if any forward overflowed (its tile lists were clamped, so the loop's results are
         invalid: the caller restores its state and re-runs with the capacity this call has already raised)."""
-        h = self.img_state[:32].view(torch.int32).cpu()
+        h = self.img_state[:16].view(torch.int32).cpu()
         overflow, n_max = int(h[1]), int(h[3])
         self.max_tile_len = int(h[2])
-        self.pruned_count = int(h[7])      # speculative pruning steps of the mapping loop add here (FusedMapper)
         self.img_state[4:16].zero_()
-        if self.pruned_count:
-            self.img_state[28:32].zero_()
         self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
         self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
         return not overflow
@@ -329,22 +326,17 @@ class FusedMapper(Mapper):
         # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
         # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
         # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
-        # Pruning is speculative in the same way: a pruning step only evaluates the predicate on the device and COUNTS (the map of
-        # a running SLAM session almost never has anything to prune, and the reference's prune needs a host round trip for the
-        # new size); if the count read back at the end is not zero, the loop is re-run with exact pruning steps.
+        # (Pruning steps are NOT speculated on: measured on the benchmark sequence, 28 % of the frames prune something, and a
+        # re-run of the whole loop costs far more than the 4-byte read-back of the new size that an exact step needs.)
         snap, rng_state = g.snapshot(), _random.getstate()
-        exact_prune = False
-        for attempt in range(5):
-            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, exact_prune)
+        for attempt in range(4):
+            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
             ok = eng.check_capacity()
-            redo_exact = eng.pruned_count > 0 and not exact_prune
-            ok = ok and not redo_exact
             if self.window is not None and self.window.world > 1:
                 ok = not self.window.any_flag(not ok, device=eng.dev)
-                redo_exact = self.window.any_flag(redo_exact, device=eng.dev)
             if ok:
                 break
-            exact_prune = exact_prune or redo_exact
+            self.loop_reruns = getattr(self, "loop_reruns", 0) + 1
             g.restore(snap)
             _random.setstate(rng_state)
             stack = None
@@ -352,7 +344,7 @@ class FusedMapper(Mapper):
             raise RuntimeError("mm3dgs: mapping loop kept overflowing its binning capacity")
         self.mapping_iter_count += num_iter
 
-    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, exact_prune=False):
+    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
         with torch.no_grad():
             iteration = 0
             while iteration < num_iter:
@@ -404,10 +396,9 @@ class FusedMapper(Mapper):
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
                     eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads)
                 if prune_now:
-                    if exact_prune:
-                        g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
-                    else:       # speculative: predicate + count on the device, no host round trip (see optimize_map)
-                        g.prune_mask_device(m["min_opacity"], self.camera_extent, m["size_threshold"], counter_ptr=eng.img_state.data_ptr() + 28)
+                    # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
+                    # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py)
+                    g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
                 iteration += 1
 
     def _inline_adam(self, n=1):
