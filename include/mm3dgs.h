@@ -149,6 +149,10 @@ typedef struct Mm3dgsMapAdam {
    * corrections and lr / (1 - beta1^step) in double and rounds ONCE to float, like torch does (1 - 0.999f in float arithmetic
    * is off by 1.3e-5 relative) */
   double lr[5]; double beta1, beta2, eps; int32_t step;
+  /* optional: uint8 [P]; the gradient of a Gaussian with opt_mask == 0 is set to zero before the step (bundle adjustment optimises
+   * the Gaussians seen by >= 2 window keyframes plus the new ones, slam/mapper.py:931-936; a zero gradient still decays the moments,
+   * as `p.grad[~mask] = 0` followed by optimizer.step() does).  NULL: every Gaussian. */
+  const uint8_t* opt_mask;
 } Mm3dgsMapAdam;
 
 typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
@@ -174,6 +178,12 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
                          float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam,
                          void* stream);
 
+/* Visibility of the map from one pose with the projection stage alone (no binning, no compositing): radii[P] as the forward pass
+ * would report them, and seen_count[i] += (radii[i] > 0) when seen_count != NULL -- what get_covisible_gaussians needs
+ * (slam/mapper.py:690-716: Gaussians visible in >= 2 window keyframes).  geom_state: scratch of mm3dgs_geom_bytes(P). */
+int mm3dgs_slam_visibility(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, int32_t* radii, uint32_t* seen_count_or_null,
+                           void* geom_state, void* stream);
+
 /* n_iter tracking iterations enqueued back to back from C (slam/tracker.py:94-177 with the "vigs" loss): each is
  * forward -> loss -> backward with the pose Adam step on the device; the pose buffer is updated in place. */
 int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color,
@@ -189,7 +199,12 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
  * its d_* pointers, when set, receive the parameter gradients of the LAST iteration (map_adam may then be NULL: a window
  * rank that all-reduces gradients before a common Adam step runs n_iter = 1 this way).  `in->pose` is ignored.  No host
  * synchronisation; `views` is read on the host during the call. */
-typedef struct Mm3dgsMapView { const float* pose; const float* gt_color; const float* ref_depth_or_null; } Mm3dgsMapView;
+typedef struct Mm3dgsMapView {
+  const float* pose; const float* gt_color; const float* ref_depth_or_null;
+  /* bundle adjustment (mapping.do_BA, slam/mapper.py:718-795,931-942): when set, the pose gradient of this view is reduced and
+   * the Adam step of ITS pose is taken on the device (pose_adam->pose must be `pose`; per-keyframe moments and step counter). */
+  const Mm3dgsPoseAdam* pose_adam_or_null;
+} Mm3dgsMapView;
 int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in,
                     float* out_color, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
                     size_t N_capacity, int fwd_flags, const struct Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout,

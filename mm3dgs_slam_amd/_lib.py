@@ -36,17 +36,17 @@ class Mm3dgsSlamGrads(C.Structure):
 
 class Mm3dgsMapAdam(C.Structure):
     _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_double * 5),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32)]
-
-
-class Mm3dgsMapView(C.Structure):
-    _fields_ = [("pose", C.c_void_p), ("gt_color", C.c_void_p), ("ref_depth_or_null", C.c_void_p)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32), ("opt_mask", C.c_void_p)]
 
 
 class Mm3dgsPoseAdam(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_double),
                 ("lr_t", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("prior_pose", C.c_void_p), ("prior_w_t", C.c_float), ("prior_w_q", C.c_float)]
+
+
+class Mm3dgsMapView(C.Structure):
+    _fields_ = [("pose", C.c_void_p), ("gt_color", C.c_void_p), ("ref_depth_or_null", C.c_void_p), ("pose_adam_or_null", C.c_void_p)]
 
 
 class Mm3dgsLossConfig(C.Structure):
@@ -91,6 +91,7 @@ _SIGS = {
                                       C.c_int, _P]),
     "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
                                        C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), C.POINTER(Mm3dgsMapAdam), _P]),
+    "mm3dgs_slam_visibility": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P]),
     "mm3dgs_slam_track": (C.c_int, [C.c_int, C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                     C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, C.POINTER(Mm3dgsPoseAdam), _P]),
     "mm3dgs_slam_map": (C.c_int, [C.c_int, C.POINTER(Mm3dgsMapView), C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P,

@@ -227,6 +227,18 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   return check_launch("slam_forward");
 }
 
+int mm3dgs_slam_visibility(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, int32_t* radii, uint32_t* seen_count, void* geom_state,
+                           void* stream) {
+  int rc = check_slam(cam, P, in);
+  if (rc) return rc;
+  if (!geom_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
+  CamDev cd = cam_dev(cam);
+  GeomView g = geom_view(geom_state, P > 0 ? P : 1);
+  ImageView iv = {};
+  launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, (hipStream_t)stream, seen_count, true);
+  return check_launch("slam_visibility");
+}
+
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                         void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream) {
   return slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, flags, stream, nullptr);
@@ -278,6 +290,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     ma.omb1 = (float)(1.0 - map_adam->beta1); ma.beta2 = (float)map_adam->beta2; ma.omb2 = (float)(1.0 - map_adam->beta2);
     ma.eps = (float)map_adam->eps;
     ma.bc2s = (float)sqrt(1.0 - pow(map_adam->beta2, (double)map_adam->step));
+    ma.opt_mask = map_adam->opt_mask;
     ma.on = 1;
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
@@ -423,14 +436,14 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       if (rc) return rc;
       tl.dmaps = fold_grad ? dmaps : nullptr;
       rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
-                              nullptr, map_adam ? &ad : nullptr, stream, fold_grad ? &tl : nullptr, nullptr, 4);
+                              views[it].pose_adam_or_null, map_adam ? &ad : nullptr, stream, fold_grad ? &tl : nullptr, nullptr, 4);
     } else {
       rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
       if (rc) return rc;
       rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
       if (rc) return rc;
       rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
-                                nullptr, nullptr, map_adam ? &ad : nullptr, stream);
+                                nullptr, views[it].pose_adam_or_null, map_adam ? &ad : nullptr, stream);
     }
     if (rc) return rc;
     ad.step++;

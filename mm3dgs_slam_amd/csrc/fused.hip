@@ -60,7 +60,8 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
 }
 
 __global__ void __launch_bounds__(FB)
-slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles) {
+slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles,
+                           int vis_only, uint32_t* __restrict__ seen) {
   extern __shared__ uint32_t hist[];
   const int T = cam.gx * cam.gy;
   for (int t = threadIdx.x; t < lds_tiles; t += FB) hist[t] = 0;
@@ -133,6 +134,10 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
     g.rect[(size_t)idx * 2] = r0;
     g.rect[(size_t)idx * 2 + 1] = r1;
   }
+  if (vis_only) {      // mm3dgs_slam_visibility: the projection stage alone (workgroup-uniform): no tile counting, no scans
+    if (live && seen && rad > 0) seen[idx] += 1u;
+    return;
+  }
   {
     const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;
     const int w = maxx - minx, area = w * (maxy - miny);
@@ -176,12 +181,13 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
   }
 }
 
-void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s) {
+void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s,
+                                uint32_t* seen, bool visibility_only) {
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
-  const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
+  const int lds_tiles = (T <= MAX_LDS_TILES && !visibility_only) ? T : 0;
   hipLaunchKernelGGL(slam_preprocess_fwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
-                     iv, lds_tiles);
+                     iv, lds_tiles, visibility_only ? 1 : 0, seen);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -353,8 +359,9 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     }
     if (ma.on) {
       // the map's Adam step for this Gaussian (every Gaussian, visible or not: zero gradients still decay the moments)
-      const float gr14[14] = {dxyz[0], dxyz[1], dxyz[2], dfd[0], dfd[1], dfd[2], dlogit, dls[0], dls[1], dls[2],
-                              dqr[0], dqr[1], dqr[2], dqr[3]};
+      const float keepg = (ma.opt_mask && ma.opt_mask[idx] == 0) ? 0.f : 1.f;     // bundle adjustment: masked-out Gaussians get a zero gradient
+      const float gr14[14] = {keepg * dxyz[0], keepg * dxyz[1], keepg * dxyz[2], keepg * dfd[0], keepg * dfd[1], keepg * dfd[2], keepg * dlogit,
+                              keepg * dls[0], keepg * dls[1], keepg * dls[2], keepg * dqr[0], keepg * dqr[1], keepg * dqr[2], keepg * dqr[3]};
 #pragma unroll
       for (int gq = 0; gq < 5; gq++)
 #pragma unroll

@@ -12,7 +12,7 @@ struct SlamGrads {
 };
 // Adam scalars as torch.optim.Adam applies them: formed in double on the host, rounded once to float.
 //   omb1 = 1 - beta1 (lerp weight), beta2, omb2 = 1 - beta2, step_size = lr / (1 - beta1^t) per group, bc2s = sqrt(1 - beta2^t)
-struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; };
+struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; const uint8_t* opt_mask; };
 struct PoseAdam { float* pose; float* m; float* v; int* step; double lr_q, lr_t, beta1, beta2; float eps; const float* prior; float prior_w_t, prior_w_q; };
 struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float step_size; };
 struct AdamArgs { AdamGroup grp[8]; int ngroups; float omb1, beta2, omb2, eps, bc2s; };
@@ -43,7 +43,8 @@ struct TrackLoss {
 struct PoseLossScale { const double* rows; int nrows; float w_l1; float* loss4; };
 void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s, float* loss4 = nullptr);
 
-void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
+void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s,
+                                uint32_t* seen_only = nullptr, bool visibility_only = false);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
                                 const PoseLossScale* pls = nullptr, float* loss4 = nullptr, int yshift = 0);

@@ -134,8 +134,11 @@ class FusedEngine:
         self._ensure(P, True)
         si = self.inputs(views[0][0], g)
         arr = (_lib.Mm3dgsMapView * len(views))()
-        for i, (pose, gt_color, ref) in enumerate(views):
+        for i, view in enumerate(views):
+            pose, gt_color, ref = view[:3]
             arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
+            if len(view) > 3 and view[3] is not None:        # bundle adjustment: this view's pose takes an Adam step on the device
+                arr[i].pose_adam_or_null = C.addressof(view[3])
         sg = None
         if stats is not None or grads is not None:
             sg = _lib.Mm3dgsSlamGrads()
@@ -150,6 +153,14 @@ class FusedEngine:
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
                                             _p(self.dL), _p(self.loss), _p(self.scratch), C.byref(sg) if sg is not None else None,
                                             C.byref(map_adam) if map_adam is not None else None, _stream()))
+
+    def visibility(self, pose, g, seen):
+        """seen[i] += 1 for every Gaussian the projection stage would hand to the rasterizer from `pose` (radii > 0): the
+        preprocess kernel alone, no binning / compositing (slam/mapper.py:690-716 needs only this)."""
+        P = int(g._xyz.shape[0])
+        self._ensure(P, False)
+        si = self.inputs(pose, g)
+        _lib.check(self.lib.mm3dgs_slam_visibility(C.byref(self.cam), P, C.byref(si), _p(self.radii), _p(seen), _p(self.geom), _stream()))
 
     def check_capacity(self):
         """Synchronises: reads the image-state header.  Its overflow / max_tile_len / max_num_rendered words are STICKY on the
@@ -250,6 +261,23 @@ class FusedMapper(Mapper):
                 return eng.out[3], eng.out[4]
         raise RuntimeError("mm3dgs: render kept overflowing its binning capacity")
 
+    def get_covisible_gaussians(self, keyframe_idx_list, curr_camera_tensor, min_kf=2):
+        """Gaussians visible from >= 2 views of the window (slam/mapper.py:690-716; the reference ignores `min_kf` and uses 2):
+        one projection-only launch per view accumulating a per-Gaussian counter -- no render."""
+        if not FusedEngine.eligible(self.cfg, self.gaussians):
+            return super().get_covisible_gaussians(keyframe_idx_list, curr_camera_tensor, min_kf)
+        eng = _engine(self.renderer)
+        g = self.gaussians
+        with torch.no_grad():
+            seen = torch.zeros(g._xyz.shape[0], dtype=torch.int32, device=eng.dev)
+            keep = []
+            for k in keyframe_idx_list:
+                pose = (curr_camera_tensor if k == -1 else self.keyframes[k].pose).detach().float().contiguous()
+                keep.append(pose)
+                eng.visibility(pose, g, seen)
+            self._vis_keepalive = keep
+            return seen >= 2
+
     def initialize_new_gaussians(self, idx, camera_pose, gt_color, gt_depth=None, est_depth=None):
         """New-keyframe seeding (slam/mapper.py:409-493,600-688) with the non-presence test on one native render and the new rows
         written by the seeding kernel (csrc/compact.hip) instead of meshgrid / boolean-mask gathers / RGB2SH / cat."""
@@ -279,7 +307,9 @@ class FusedMapper(Mapper):
     def optimize_map(self, idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]
-        if (num_iter == 0 or (m["do_BA"] and idx > 0) or not FusedEngine.eligible(self.cfg, self.gaussians)):
+        do_ba = bool(m["do_BA"]) and idx > 0
+        if (num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians)
+                or (do_ba and self.window is not None and self.window.views_per_step > 1)):     # (BA with a sharded window: torch-graph loop)
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
@@ -307,6 +337,8 @@ class FusedMapper(Mapper):
                 view_cache[k] = _view_of(k)
             return view_cache[k]
 
+        ba_state = {}     # view id -> (pose buffer, m, v, step, Mm3dgsPoseAdam): bundle adjustment steps every window pose on the device
+
         def _view_of(k):
             if k == -1:
                 pose, gt_color, gt_depth, est_depth = curr_camera_tensor, curr_gt_color, curr_gt_depth, curr_est_depth
@@ -316,12 +348,31 @@ class FusedMapper(Mapper):
             ref = None
             if w_p:
                 ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
-            return pose.detach().float().contiguous(), gt_color.contiguous(), ref
+            buf = pose.detach().float().contiguous()
+            if not do_ba:
+                return buf, gt_color.contiguous(), ref
+            # pose Adam of slam/mapper.py:742-752: Adam(lr=0, eps=1e-15), groups cam_rot (cam_q_lr) / cam_pos (cam_t_lr); a pose is
+            # only stepped in the iterations that render its view (torch skips parameters without a gradient), hence per-view state
+            buf = buf.clone()
+            mom, var = torch.zeros(7, device=eng.dev), torch.zeros(7, device=eng.dev)
+            step = torch.zeros(1, dtype=torch.int32, device=eng.dev)
+            ad = _lib.Mm3dgsPoseAdam()
+            ad.pose, ad.m, ad.v, ad.step = buf.data_ptr(), mom.data_ptr(), var.data_ptr(), step.data_ptr()
+            ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = float(m["cam_q_lr"]), float(m["cam_t_lr"]), 0.9, 0.999, 1e-15
+            ba_state[k] = (buf, mom, var, step, ad, pose)
+            return buf, gt_color.contiguous(), ref, ad
 
         def prune_at(it):
             return it <= m["densify_until_iter"] and it >= m["densify_from_iter"] and it % m["pruning_interval"] == 0
 
         import random as _random
+        self._opt_mask = None
+        if do_ba:
+            with torch.no_grad():
+                om = self.get_covisible_gaussians(keyframe_idx_list, curr_camera_tensor, 2)
+                if new_gaussians_mask is not None:
+                    om = om | new_gaussians_mask
+                self._opt_mask = om.to(torch.uint8).contiguous()
         multi = self.window is not None and self.window.views_per_step > 1
         # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
         # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
@@ -340,8 +391,19 @@ class FusedMapper(Mapper):
             g.restore(snap)
             _random.setstate(rng_state)
             stack = None
+            view_cache.clear(); ba_state.clear()       # (pose buffers and their Adam state start over)
+            if do_ba:
+                with torch.no_grad():
+                    om = self.get_covisible_gaussians(keyframe_idx_list, curr_camera_tensor, 2)
+                    if new_gaussians_mask is not None:
+                        om = om | new_gaussians_mask
+                    self._opt_mask = om.to(torch.uint8).contiguous()
         else:
             raise RuntimeError("mm3dgs: mapping loop kept overflowing its binning capacity")
+        if do_ba:      # the optimised window poses go back where the reference's in-place Adam leaves them
+            with torch.no_grad():
+                for k, (buf, _m, _v, _s, _ad, pose) in ba_state.items():
+                    pose.data.copy_(buf)
         self.mapping_iter_count += num_iter
 
     def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
@@ -398,7 +460,9 @@ class FusedMapper(Mapper):
                 if prune_now:
                     # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
                     # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py)
-                    g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    pruned = g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
+                        self._opt_mask = self._opt_mask[~pruned].contiguous()
                 iteration += 1
 
     def _inline_adam(self, n=1):
@@ -422,6 +486,8 @@ class FusedMapper(Mapper):
             ma.lr[i] = float(group["lr"])
         b1, b2 = opt.param_groups[0]["betas"]
         ma.beta1, ma.beta2, ma.eps, ma.step = float(b1), float(b2), float(opt.param_groups[0]["eps"]), step_val
+        if getattr(self, "_opt_mask", None) is not None:
+            ma.opt_mask = self._opt_mask.data_ptr()
         return ma
 
     def _adam_step(self, eng):

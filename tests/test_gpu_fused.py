@@ -667,3 +667,48 @@ def test_device_seeding_matches_the_reference_fixture_g7_and_the_torch_mirror():
     st = g.optimizer.state[g._xyz]
     assert float(st["exp_avg"][n:].abs().max()) == 0 and float(st["exp_avg"][:n].abs().min()) > 0
     assert g.denom.shape == (n + n2, 1) and float(g.denom.abs().max()) == 0
+
+
+def test_covisible_gaussians_from_the_projection_stage_alone():
+    """FusedMapper.get_covisible_gaussians (mm3dgs_slam_visibility: projection only) == the reference's way (a full render per view,
+    visibility_filter summed, >= 2; slam/mapper.py:690-716)."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import FusedMapper
+    from mm3dgs_slam_amd.mapper import KeyFrame, Mapper
+    cfg, g, R, pose, color, depth = _setup(P=20000, H=120, W=160, seed=17)
+    poses = [pose, pose + torch.tensor([0, 0.02, -0.01, 0.0, 0.4, 0.0, 0.1], device=DEV), pose + torch.tensor([0, -0.03, 0.02, 0.01, -0.5, 0.1, -0.2], device=DEV)]
+    fm, tm = FusedMapper(cfg, g, R, [None] * 4), Mapper(cfg, g, R, [None] * 4)
+    for mp in (fm, tm):
+        mp.keyframes = [KeyFrame(i, color, p, depth) for i, p in enumerate(poses)]
+    cur = pose + torch.tensor([0, 0.01, 0.01, -0.02, 0.2, -0.3, 0.05], device=DEV)
+    a = fm.get_covisible_gaussians([0, 1, 2, -1], cur)
+    b = tm.get_covisible_gaussians([0, 1, 2, -1], cur)
+    assert a.dtype == torch.bool and a.shape == b.shape
+    assert 1000 < int(b.sum()) < 20000
+    assert int((a != b).sum()) <= 2          # (two float32 projection pipelines: a borderline radius may differ)
+
+
+def test_native_bundle_adjustment_follows_the_torch_graph_loop():
+    """mapping.do_BA natively (per-view pose Adam on the device inside mm3dgs_slam_map, gradient masking by covisibility inside the
+    in-kernel map Adam) against the torch-graph Mapper.optimize_map with do_BA (slam/mapper.py:718-795,931-942)."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    results = {}
+    for native in (False, True):
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 10}, mapping={"iters": 12, "do_BA": True, "kf_every": 1,
+                                                                                                 "min_covisibility": 2.0})
+        seq = SyntheticSequence(cfg, 4, 8000, seed=4)
+        slam = SLAM(cfg, seq, native_loops=native)
+        random.seed(1)
+        for i in range(4):
+            slam.step(i)
+        assert len(slam.mapper.keyframes) >= 3
+        results[native] = (torch.stack(slam.estimate_pose_list[:4]).cpu(), torch.stack([kf.pose for kf in slam.mapper.keyframes]).detach().cpu(),
+                           slam.gaussians._xyz.detach().cpu())
+    a, b = results[False], results[True]
+    assert a[2].shape == b[2].shape
+    assert (a[0] - b[0]).abs().max() < 4e-3 and (a[1] - b[1]).abs().max() < 4e-3, (a[1], b[1])
+    assert pu.rel_l2(b[2], a[2]) < 2e-3
+    # BA really moved the keyframe poses away from the tracked ones
+    assert (b[1][:-1] - b[0][:b[1].shape[0] - 1]).abs().max() > 1e-5
