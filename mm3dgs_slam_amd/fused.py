@@ -349,7 +349,11 @@ class FusedMapper(Mapper):
             if w_p:
                 ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
             buf = pose.detach().float().contiguous()
-            if not do_ba:
+            # Reference quirk kept by default: slam/mapper.py:752-760 puts `keyframes[k].pose[:4].requires_grad_()` views into the pose
+            # optimiser, but the loop renders from FRESH views `keyframe.pose[:4]` (:817-819) that do not require grad -- so the
+            # reference's bundle adjustment only ever refines the CURRENT frame's pose.  mapping.ba_optimize_keyframes: true gives
+            # the intended behaviour (every window pose stepped when its view is rendered).
+            if not do_ba or (k != -1 and not m.get("ba_optimize_keyframes", False)):
                 return buf, gt_color.contiguous(), ref
             # pose Adam of slam/mapper.py:742-752: Adam(lr=0, eps=1e-15), groups cam_rot (cam_q_lr) / cam_pos (cam_t_lr); a pose is
             # only stepped in the iterations that render its view (torch skips parameters without a gradient), hence per-view state
