@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
                     "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=50000)
-    ap.add_argument("--workload", default="slam", choices=["slam", "c5"],
-                    help="slam = BASELINE.json configs[1] (the headline line); c5 = configs[4]: synthetic 1920x1080, 3 M Gaussians, SH degree 3, "
-                         "rasterizer forward+backward sweep (a step = one render + backward of one view)")
+    ap.add_argument("--workload", default="slam", choices=["slam", "c3", "c5"],
+                    help="slam = BASELINE.json configs[1] (the headline line); c3 = configs[2]: UT-MM-shaped 640x330 RGB-D + IMU (configs/UTMM.yml "
+                         "settings, IMU dead-reckoning for the pose prediction + the IMU relative-pose residual in the tracking loss), full track+map; "
+                         "c5 = configs[4]: synthetic 1920x1080, 3 M Gaussians, SH degree 3, rasterizer forward+backward sweep (a step = one render + "
+                         "backward of one view)")
     ap.add_argument("--steady-frames", type=int, default=100,
                     help="slam, 1 GPU: after the timed region keep running this many more frames and report them as `steady_state` (0 = skip)")
     ap.add_argument("--full-seed-steps", type=int, default=10,
@@ -316,9 +318,19 @@ def main():
     extras = world == 1 and rank == 0
     steady = args.steady_frames if extras else 0
 
+    c3 = args.workload == "c3"
+    if c3:
+        args.height, args.width = 330, 640
+        frac = args.seed_fraction or 1.0      # 640x330 has ~200 k valid pixels: the reference's one-Gaussian-per-pixel seeding, not thinned
+
     def build(frac_, n_frames, n_target):
-        cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
-                             mapping={"iters": args.map_iters, "seed_fraction": frac_})
+        if c3:
+            from mm3dgs_slam_amd.config import utmm_config
+            cfg = utmm_config(device=dev, tracking={"iters": args.track_iters, "use_imu_loss": True, "imu_T_weight": 1.0, "imu_q_weight": 0.1},
+                              mapping={"iters": args.map_iters, "seed_fraction": frac_})
+        else:
+            cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
+                                 mapping={"iters": args.map_iters, "seed_fraction": frac_})
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         seq = SyntheticSequence(cfg, n_frames, n_target, seed=0)        # untimed: builds the RGB-D frames on the GPU
         window = WindowParallel(rank, world, batch=args.window_batch) if (world > 1 or args.window_batch > 1) else None
@@ -373,10 +385,13 @@ def main():
     mpix = H * W * passes * renders * frame_equiv / elapsed / 1e6
 
     out = {
-        "metric": "SLAM frames/sec (track+map), TUM fr1/desk-shaped 640x480", "value": value, "unit": "frames/s",
+        "metric": "SLAM frames/sec (track+map), " + ("UT-MM-shaped 640x330 RGB-D + IMU" if c3 else "TUM fr1/desk-shaped 640x480"), "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, "
+        "config": {"workload": (f"UT-MM-shaped synthetic RGB-D + IMU {W}x{H} (configs/UTMM.yml: intrinsics x 1/2, isotropic Gaussians, pose prediction "
+                                f"by IMU dead-reckoning over synthetic 100 Hz samples, Pearson depth term and IMU relative-pose residual (weights 1.0 / 0.1) "
+                                f"in the tracking loss), {P_now} Gaussians, " if c3 else
+                                f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, ") +
                                f"full track+map per frame: {args.track_iters} tracking + {args.map_iters} mapping iterations "
                                f"(reference budget), frame-0 seeding thinned to {frac:.2f} of the pixels, render_mode={args.render_mode}, "
                                f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
@@ -417,7 +432,7 @@ def main():
         out["steady_state"] = {"frames": steady, "value": steady / el, "unit": "frames/s", "ms_per_frame": el / steady * 1e3,
                                "gaussians_at_end": int(slam.gaussians.get_xyz.shape[0]), "keyframes": len(slam.mapper.keyframes),
                                "note": f"frames {first}..{first + steady - 1} of the run above (same map, same budget, keyframe work included)"}
-    if extras and args.full_seed_steps and frac < 1.0:
+    if extras and args.full_seed_steps and frac < 1.0 and not c3:
         log("full-seed run (one Gaussian per valid frame-0 pixel)")
         del slam
         torch.cuda.empty_cache()

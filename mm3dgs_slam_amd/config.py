@@ -33,6 +33,36 @@ _TUM = {
 }
 
 
+# configs/UTMM.yml's hot-path settings that differ from TUM.yml (BASELINE.json configs[2]: RGB-D + IMU): 640x330, intrinsics of the
+# 1280x660 sensor scaled by 1/2 (gradslam_datasets/datautils.py:73-118), isotropic Gaussians, IMU dead-reckoning for the pose
+# prediction, Pearson term in tracking, 0.002 pose learning rates, size threshold 200.
+_UTMM_DELTA = {
+    "desired_height": 330, "desired_width": 640,
+    "pipeline": {"force_isotropic": True},
+    "tracking": {"dynamics_model": "imu", "use_depth_estimate_loss": True, "pearson_weight": 0.001, "position_lr": 0.002, "rotation_lr": 0.002},
+    "mapping": {"pearson_weight": 0.001, "cam_t_lr": 0.002, "cam_q_lr": 0.002, "size_threshold": 200},
+    "cam": {"image_height": 330, "image_width": 640, "fx": 642.6510620117188 / 2, "fy": 641.807373046875 / 2, "cx": 654.4762573242188 / 2,
+            "cy": 359.5939025878906 / 2, "png_depth_scale": 1000.0, "fps": 30},
+}
+
+
+def utmm_config(device="cuda:0", **overrides):
+    """configs/UTMM.yml's hot-path settings on the synthetic sequence (ground-truth depth, NIQE filter off)."""
+    cfg = copy.deepcopy(_TUM)
+    cfg["device"] = device
+    for k, v in _UTMM_DELTA.items():
+        if isinstance(v, dict):
+            cfg[k].update(v)
+        else:
+            cfg[k] = v
+    for k, v in overrides.items():
+        if isinstance(v, dict):
+            cfg[k].update(v)
+        else:
+            cfg[k] = v
+    return cfg
+
+
 def default_config(device="cuda:0", height=480, width=640, **overrides):
     """configs/TUM.yml's hot-path settings (iteration budgets, learning rates, pipeline flags) with ground-truth depth
     (no monocular network offline) and the NIQE keyframe filter off.  Intrinsics scale with the image size."""

@@ -57,12 +57,43 @@ class SyntheticSequence:
                 d = torch.where(sil > 0.5, r["depth"][0] / sil.clamp_min(1e-6), torch.zeros_like(sil))
                 self.frames.append((r["render"].clamp(0, 1).contiguous(), d.contiguous()))
 
+        self.dt_cam = 0.04                       # 25 frames/s: four IMU samples at 100 Hz between two frames
+        self.tstamps = [i * self.dt_cam for i in range(n_frames)]
+        self.tf = {"c2i": torch.eye(4)}          # camera and IMU frames coincide in the synthetic rig
+        self._imu = {}
+
     def __len__(self):
         return len(self.frames)
 
     def __getitem__(self, i):
         color, depth = self.frames[i]
         return color, depth, self.poses[i]
+
+    def imu(self, i):
+        """Synthetic IMU rows for the interval (frame i-1, frame i], in the layout utils/pose_utils.py:179-180 reads (angular
+        velocity in columns 13:16, linear acceleration incl. gravity in columns 25:28; 100 Hz): derived from the ground-truth
+        trajectory so that ``propagate_imu`` started at the true poses i-2, i-1 lands on the true pose i.
+        A fresh tensor per call: ``propagate_imu`` subtracts gravity from the sample in place, as the reference does."""
+        if i not in self._imu:
+            from .pose_utils import GRAVITY
+            n, dt = int(round(self.dt_cam / 0.01)), 0.01
+            inv = lambda p: torch.linalg.inv(get_camera_from_tensor(p.cpu()).double())
+            w1 = inv(self.poses[i - 1])
+            w0 = inv(self.poses[i - 2]) if i >= 2 else w1
+            w2 = inv(self.poses[i])
+            D = torch.linalg.inv(w1) @ w2                                   # motion over the interval, in the frame of pose i-1
+            # small-angle rotation vector of D spread over the n samples (euler 'sxyz' of small angles ~ rotation vector)
+            rv = torch.stack([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]]) * 0.5
+            omega = rv / (n * dt)
+            dt_prev = self.dt_cam if i >= 2 else 1.0
+            v = (torch.linalg.inv(w0) @ w1)[:3, 3] / dt_prev              # what propagate_imu uses as the (constant) velocity
+            acc = 2.0 * (D[:3, 3] / n - v * dt) / (dt * dt)
+            g_imu = w1[:3, :3].T @ torch.tensor(GRAVITY, dtype=torch.float64)
+            rows = torch.zeros(n, 30)
+            rows[:, 13:16] = omega.float()
+            rows[:, 25:28] = (acc + g_imu).float()
+            self._imu[i] = rows
+        return self._imu[i].clone()
 
 
 class _FixedMap:
@@ -96,7 +127,8 @@ class SLAM:
             from .fused import FusedMapper as MapperCls, FusedTracker as TrackerCls
         else:
             TrackerCls, MapperCls = Tracker, Mapper
-        self.tracker = TrackerCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list)
+        self.tracker = TrackerCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list, tf=getattr(sequence, "tf", None),
+                                  tstamps=getattr(sequence, "tstamps", None))
         self.mapper = MapperCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list, n_img=n, window=window)
 
     def step(self, idx):
@@ -105,7 +137,8 @@ class SLAM:
         if idx == 0 or self.cfg["tracking"]["use_gt_pose"]:
             self.estimate_pose_list[idx] = gt_pose.clone()
         else:
-            self.tracker.run_frame(idx, color, depth, depth)
+            imu = self.seq.imu(idx) if (self.cfg["tracking"].get("dynamics_model") or "").lower() == "imu" else None
+            self.tracker.run_frame(idx, color, depth, depth, imu_meas=imu)
         if idx == 0:
             self.mapper.camera_extent = float(depth.max()) / self.cfg["scene_radius_depth_ratio"]
         self.mapper.run_frame(idx, color, depth, depth)

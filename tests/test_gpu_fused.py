@@ -726,3 +726,29 @@ def test_native_bundle_adjustment_follows_the_torch_graph_loop():
     assert (a[0] - b[0]).abs().max() < 5e-4, (a[0], b[0])
     assert pu.rel_l2(b[2], a[2]) < 2e-3
     assert (c[1][1:] - c[3][1:]).abs().max() > 1e-4                        # the flag: window keyframe poses move too
+
+
+def test_utmm_shaped_config_with_imu_runs_natively_and_tracks():
+    """BASELINE.json configs[2] in miniature: configs/UTMM.yml settings (isotropic Gaussians, IMU dead-reckoning for the pose prediction
+    over the synthetic IMU rows, Pearson term, IMU relative-pose residual) through the native loops; the trajectory stays on the ground
+    truth and the IMU prediction is what the tracker starts from."""
+    from mm3dgs_slam_amd.config import utmm_config
+    from mm3dgs_slam_amd.pose_utils import propagate_imu
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg = utmm_config(device=DEV, tracking={"iters": 30, "use_imu_loss": True, "imu_T_weight": 1.0, "imu_q_weight": 0.1}, mapping={"iters": 20})
+    cfg["desired_height"], cfg["desired_width"] = 166, 320          # quarter-size image for the test, same intrinsics scaling
+    for k in ("fx", "fy", "cx", "cy"):
+        cfg["cam"][k] *= 0.5
+    seq = SyntheticSequence(cfg, 5, 30000, seed=3)
+    slam = SLAM(cfg, seq)
+    assert type(slam.tracker).__name__ == "FusedTracker" and type(slam.mapper).__name__ == "FusedMapper"
+    for i in range(5):
+        slam.step(i)
+    errs = slam.pose_errors()
+    assert max(errs[1:]) < 0.01, errs                       # < 1 cm on a trajectory that moves ~1-2 cm per frame
+    # the prediction the tracker started frame 4 from is the IMU propagation of its own estimates
+    pred = slam.tracker.predict_pose(4, seq.imu(4)).to(DEV)
+    want = propagate_imu(slam.estimate_pose_list[3], slam.estimate_pose_list[2], seq.imu(4), seq.tf["c2i"], seq.dt_cam, 0.01).to(DEV)
+    assert torch.allclose(pred, want, atol=1e-6)
+    assert (pred - seq.poses[4]).abs().max() < 5e-3
