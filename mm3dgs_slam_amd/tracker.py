@@ -123,11 +123,11 @@ class Tracker:
                 cam = torch.from_numpy(propagate_const_vel_np(both[0], both[1])).float()
         elif model == "imu":
             assert imu_meas is not None, "IMU measurements must be provided"
-            if idx - 2 >= 0:
-                cam = propagate_imu(poses[idx - 1], poses[idx - 2], imu_meas, self.tf["c2i"],
-                                    self.tstamps[idx - 1] - self.tstamps[idx - 2], 1 / 100.0)
-            else:
-                cam = propagate_imu(poses[idx - 1], poses[idx - 1], imu_meas, self.tf["c2i"], 1.0, 1 / 100.0)
+            # 4x4 algebra over a handful of samples: on the host (one 7-float copy; ~100 one-element device kernels otherwise)
+            p1 = poses[idx - 1].detach().cpu()
+            p2 = poses[idx - 2].detach().cpu() if idx - 2 >= 0 else p1
+            dt_cam = (self.tstamps[idx - 1] - self.tstamps[idx - 2]) if idx - 2 >= 0 else 1.0      # (zero velocity at the start)
+            cam = propagate_imu(p1, p2, imu_meas.cpu(), self.tf["c2i"].cpu(), dt_cam, 1 / 100.0)
         elif model:
             raise ValueError(f"Unknown dynamics model {self.dyn_model}")
         return cam

@@ -749,6 +749,6 @@ def test_utmm_shaped_config_with_imu_runs_natively_and_tracks():
     assert max(errs[1:]) < 0.01, errs                       # < 1 cm on a trajectory that moves ~1-2 cm per frame
     # the prediction the tracker started frame 4 from is the IMU propagation of its own estimates
     pred = slam.tracker.predict_pose(4, seq.imu(4)).to(DEV)
-    want = propagate_imu(slam.estimate_pose_list[3], slam.estimate_pose_list[2], seq.imu(4), seq.tf["c2i"], seq.dt_cam, 0.01).to(DEV)
+    want = propagate_imu(slam.estimate_pose_list[3].cpu(), slam.estimate_pose_list[2].cpu(), seq.imu(4), seq.tf["c2i"], seq.dt_cam, 0.01).to(DEV)
     assert torch.allclose(pred, want, atol=1e-6)
     assert (pred - seq.poses[4]).abs().max() < 5e-3
