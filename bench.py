@@ -403,22 +403,47 @@ def main():
         "render_iterations_per_s": renders * frame_equiv / elapsed,
         "num_rendered_pairs": N,
     }
-    # ---- roofline of the dominant kernel (backward compositor) ----------------------------------------------------
-    n_bwd, ms_bwd = prof["composite_bwd"]
-    if n_bwd:
-        alg_bytes = N * (28 + 4 * C) + H * W * (4 * C + 8) + N * (24 + 4 * C)      # SURVEY.md 8d "Backward" composite terms
-        dur = ms_bwd / n_bwd * 1e-3
+    # ---- roofline: the three compositing kernels of the timed region, each against the algorithmic bytes of SURVEY.md 8d with the
+    # measured N (HIP events recorded on the launch stream inside the library, every 16th launch); `roofline` is the one with the
+    # largest total time, the others follow in `roofline_other`
+    T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    r_passes = -(-(32 + max(T_tiles - 1, 1).bit_length()) // 8)
+    bwd_comp = N * (28 + 4 * C) + H * W * (4 * C + 8) + N * (24 + 4 * C)            # 8d "Backward": composite re-read + per-pixel + gradient scatter
+    loss_grad_pass = H * W * 4 * (9 + 3 + 3 + 3)                                    # folded mapping-loss gradient pass: 9 SSIM maps, rgb, gt, depth / silhouette / reference
+    fwd_sort_comp = 24 * N * r_passes + 8 * N + (8 * N + 8 * T_tiles) + N * (28 + 4 * C) + H * W * (4 * C + 8)   # 8d "Forward": sort + ranges + composite read + image write
+    kernels = {
+        "composite_bwd": ("composite_bwd_kernel<6,1> (mapping; the mapping loss's gradient-image pass runs in its prologue)", bwd_comp + loss_grad_pass,
+                          "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite] + 18 HW 4 [folded loss gradient pass: 9 SSIM maps + rgb + gt + depth/sil/ref]",
+                          args.map_iters * vps),
+        "composite_bwd_track": ("composite_bwd_kernel<6,2> (tracking; masked-L1 loss folded in)", bwd_comp, "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite]",
+                                args.track_iters),
+        "composite_fwd": ("sort_composite_fwd_kernel<6> (per-tile sort + block lists + forward compositing in one launch)", fwd_sort_comp,
+                          "24 N r + 8N [sort, r = %d radix passes of the contract] + 8N + 8T [ranges] + N(28+4C) + HW(4C+8) [composite] (SURVEY 8d forward)" % r_passes,
+                          args.track_iters + args.map_iters * vps),
+    }
+    recs = []
+    for key, (label, alg_bytes, formula, per_frame) in kernels.items():
+        n_k, ms_k = prof.get(key, (0, 0.0))
+        if not n_k:
+            continue
+        dur = ms_k / n_k * 1e-3
         ach = alg_bytes / dur / 1e9
+        recs.append({"bound": "hbm", "kernel": label, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_formula": formula, "avg_launch_us": dur * 1e6,
+                     "timed_launches": n_k, "launches_per_frame": per_frame, "ms_per_frame": dur * 1e3 * per_frame})
+    if recs:
+        recs.sort(key=lambda r_: -r_["ms_per_frame"])
         traffic, traffic_src = pmc_traffic()
-        out["roofline"] = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
-                           "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                           "avg_launch_us": dur * 1e6, "timed_launches": n_bwd,   # every 16th launch of the timed region carries an event pair
-                           # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any
-                           # early-out, ~25 flop + 1 exp each (SURVEY's figure), against the dense f32 VALU peak.  This
-                           # is the ceiling the kernel actually runs into (profiles/r01_sq_counters.md)
-                           "valu": {"evaluations_per_launch": 256 * N, "achieved_gevals_per_s": 256 * N / dur / 1e9,
-                                    "flop_per_evaluation": 25, "achieved_tflops": 256 * N * 25 / dur / 1e12,
-                                    "peak_tflops": 157.3, "frac": 256 * N * 25 / dur / 1e12 / 157.3}}
+        for r_ in recs:
+            if r_["kernel"].startswith("composite_bwd_kernel<6,1>"):
+                r_["traffic"], r_["traffic_source"] = traffic, traffic_src
+                # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any early-out, ~25 flop + 1 exp
+                # each, against the dense f32 VALU peak -- the ceiling this kernel actually runs into (profiles/r01_sq_counters.md)
+                d_ = r_["avg_launch_us"] * 1e-6
+                r_["valu"] = {"evaluations_per_launch": 256 * N, "achieved_gevals_per_s": 256 * N / d_ / 1e9, "flop_per_evaluation": 25,
+                              "achieved_tflops": 256 * N * 25 / d_ / 1e12, "peak_tflops": 157.3, "frac": 256 * N * 25 / d_ / 1e12 / 157.3}
+        out["roofline"] = recs[0]
+        out["roofline_other"] = recs[1:]
         out["kernel_us"] = {k: (v[1] / v[0] * 1e3) for k, v in prof.items() if v[0]}
     if steady:
         log(f"steady state: {steady} more frames of the same run")

@@ -131,11 +131,11 @@ def load():
     return lib
 
 
-PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam")
+PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam", "composite_bwd_track")
 
 
 def profile_enable(mode):
-    """0/False off, 1/True every kernel, 2 only the backward compositor."""
+    """0/False off, 1/True every kernel, 2 only the compositors (forward, backward mapping / generic, backward tracking), every 16th launch."""
     load().mm3dgs_profile_enable(int(mode))
 
 

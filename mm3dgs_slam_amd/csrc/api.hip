@@ -34,12 +34,13 @@ static std::mutex g_prof_mu;
 static int g_prof_on = 0;
 struct ProfScope {
   int k; hipStream_t s; hipEvent_t e1 = nullptr; bool on;
-  // g_prof_on: 0 off, 1 every kernel, 2 only the backward compositor (the roofline kernel) and only every 16th launch of
+  // g_prof_on: 0 off, 1 every kernel, 2 only the compositors (the roofline kernels) and only every 16th launch of
   // it: an event pair around EVERY launch costs ~4 % of the SLAM frame rate (measured), a 1-in-16 sample nothing
-  ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && k_ == MM3DGS_PROF_COMPOSITE_BWD)) {
+  ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && (k_ == MM3DGS_PROF_COMPOSITE_BWD || k_ == MM3DGS_PROF_COMPOSITE_BWD_TRACK ||
+                                                                                     k_ == MM3DGS_PROF_COMPOSITE_FWD))) {
     if (on && g_prof_on == 2) {
-      static unsigned long long sample = 0;
-      on = (sample++ & 15ull) == 0ull;
+      static unsigned long long sample[MM3DGS_PROF_KERNELS] = {};
+      on = (sample[k_]++ & 15ull) == 0ull;
     }
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -301,7 +302,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   // (58 % active; 61 us against 49 us at SLAM size, and no better at 1200x680 -- profiles/r02_bwd2_experiment.md).  Kept as a
   // checked alternative (tests/test_gpu_fused.py compares it with the first-generation kernel).
   const int bwd2 = bwd2_requested();   // read per call: tests compare both in one process
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_BWD, s);
+  { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, bwd2);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, bwd2 ? 1 : 0); }

@@ -354,7 +354,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
-  constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;   // record stride in floats: tracking records (7 floats) are packed at 32 B
+  constexpr int RECF = MODE == 0 ? SPLAT_F : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats (SLAM modes: packed, composite_common.h)
   // [buffer][wave][field A|B|C|pair index][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address
   // register per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
   // (the staging buffers share their 32 KB with the scratch of the folded mapping-loss gradient pass, which runs first)
@@ -427,10 +427,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + q; e < count; e += 16) {
-    float4* r = (float4*)(dsub + (size_t)list[e].y * RECF);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int f = 0; f < NF4; f++) r[f] = z;
+    zero_record<MODE == 0 ? 4 * NF4 : NV>(dsub + (size_t)list[e].y * RECF);
   }
   if (maxtodo == 0) return;   // wave-uniform
 

@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(128)
 composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
                       float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
   constexpr int C = 6;
-  constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;
-  constexpr int NG = MODE == 2 ? 2 : 3;                 // float4 groups of a record that carry data
+  constexpr int RECF = MODE == 2 ? REC_TRACK_F : REC_MAP_F;    // packed records (composite_common.h)
+  constexpr int NG = MODE == 2 ? 2 : 3;                 // float4 groups of a record that carry data (the last one partly)
   constexpr int ROW_CZ = MODE == 2 ? 3 : 6, ROW_MY = MODE == 2 ? 4 : 7, ROW_MXY = MODE == 2 ? 5 : 8, ROW_MYY = MODE == 2 ? 6 : 9;
   constexpr uint32_t CH = 16;                           // list entries staged per block and chunk
   const int T = cam.gx * cam.gy;
@@ -127,10 +127,7 @@ composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   {
     const uint32_t q8 = (uint32_t)(k * 2 + h);
     for (uint32_t e = todo + q8; e < count; e += 8) {
-      float4* r = (float4*)(dsub + (size_t)list[e].y * RECF);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int f = 0; f < NG; f++) r[f] = z;
+      zero_record<RECF>(dsub + (size_t)list[e].y * RECF);
     }
   }
   __syncthreads();                   // s_todo / s_list visible (both waves take the same path up to here)
@@ -223,7 +220,7 @@ composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
         R.z = D[2] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(D[2]), B2_QP_XOR1, 0xf, 0xf, true));
         R.w = D[3] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(D[3]), B2_QP_XOR1, 0xf, 0xf, true));
         // the block's lanes are the only writers of the (block, splat) record: NG lanes store 16 bytes each
-        if (blk_on && h == 0 && k < NG) *(float4*)(dsub + (size_t)rec * RECF + 4 * k) = R;
+        if (blk_on && h == 0 && k < NG) st_part(dsub + (size_t)rec * RECF + 4 * k, R, min(4, RECF - 4 * k));
       };
       // two register sets used alternately: the next step's LDS reads are in flight while the current one is evaluated
       float4 A0 = wS[0][bq], B0 = wS[1][bq], C0 = wS[2][bq];
@@ -259,8 +256,8 @@ __global__ void __launch_bounds__(256, 5)   // 5 waves per SIMD: the 4800 waves 
 composite_bwd3_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
                       float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
   constexpr int C = 6;
-  constexpr int RECF = MODE == 2 ? 8 : SPLAT_F;
-  constexpr int NG = MODE == 2 ? 2 : 3;                 // float4 groups of a record that carry data
+  constexpr int RECF = MODE == 2 ? REC_TRACK_F : REC_MAP_F;    // packed records (composite_common.h)
+  constexpr int NG = MODE == 2 ? 2 : 3;                 // float4 groups of a record that carry data (the last one partly)
   constexpr int ROW_CZ = MODE == 2 ? 3 : 6, ROW_MY = MODE == 2 ? 4 : 7, ROW_MXY = MODE == 2 ? 5 : 8, ROW_MYY = MODE == 2 ? 6 : 9;
   constexpr uint32_t CH = 16;                           // list entries staged per block and chunk
   const int T = cam.gx * cam.gy;
@@ -359,10 +356,7 @@ composite_bwd3_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   {
     const uint32_t q16 = (uint32_t)(k * 4 + x);
     for (uint32_t e = todo + q16; e < count; e += 16) {
-      float4* r = (float4*)(dsub + (size_t)list[e].y * RECF);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int f = 0; f < NG; f++) r[f] = z;
+      zero_record<RECF>(dsub + (size_t)list[e].y * RECF);
     }
   }
   __syncthreads();                   // s_todo / s_list visible (every wave takes the same path up to here)
@@ -445,7 +439,7 @@ composite_bwd3_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
           Rp[c] = v;
         }
         // the block's lanes are the only writers of the (block, splat) record: NG lanes store 16 bytes each
-        if (blk_on && x == 0 && k < NG) *(float4*)(dsub + (size_t)rec * RECF + 4 * k) = R;
+        if (blk_on && x == 0 && k < NG) st_part(dsub + (size_t)rec * RECF + 4 * k, R, min(4, RECF - 4 * k));
       };
       // two register sets used alternately: the next step's LDS reads are in flight while the current one is evaluated
       float4 A0 = wS[0][r16], B0 = wS[1][r16], C0 = wS[2][r16];

@@ -3,6 +3,32 @@
 #pragma once
 #include "mm3dgs_common.h"
 
+// Gradient records of the SLAM modes are packed at their real size: 10 floats (40 B) per (block, splat) in mapping, 7 floats
+// (28 B) in tracking -- round 1 wrote 48 / 32 B (the backward compositor's HBM traffic was 3.4x its algorithmic bytes).  Records
+// are then only 4-byte aligned: the wide accesses go through 4-byte-aligned vector types (global_load / store_dwordx4 need dword
+// alignment only), and a reader that fetches whole float4s past a record's end gets the head of the next record in lanes it ignores.
+#define REC_MAP_F 10
+#define REC_TRACK_F 7
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float4 ld4u(const float* p) { const f4u v = *(const f4u*)p; return make_float4(v.x, v.y, v.z, v.w); }
+// zero the NV floats of a record
+template <int NV>
+__device__ __forceinline__ void zero_record(float* r) {
+  const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f + 4 <= NV; f += 4) *(f4u*)(r + f) = z4;
+  if ((NV & 3) >= 2) { const f2u z2 = {0.f, 0.f}; *(f2u*)(r + (NV & ~3)) = z2; }
+  if (NV & 1) r[NV - 1] = 0.f;
+}
+// store the first `n` (1..4) floats of v at p
+__device__ __forceinline__ void st_part(float* p, const float4& v, int n) {
+  if (n >= 4) { const f4u t = {v.x, v.y, v.z, v.w}; *(f4u*)p = t; }
+  else if (n == 3) { const f2u t = {v.x, v.y}; *(f2u*)p = t; p[2] = v.z; }
+  else if (n == 2) { const f2u t = {v.x, v.y}; *(f2u*)p = t; }
+  else if (n == 1) p[0] = v.x;
+}
+
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 

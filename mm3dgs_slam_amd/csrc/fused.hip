@@ -223,7 +223,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = btile + toff;
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? 8 : SPLAT_F, FB>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0);
+    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};

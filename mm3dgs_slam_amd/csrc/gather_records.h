@@ -2,6 +2,7 @@
 // the SLAM backward projection kernels.  Every lane of the workgroup must call it (wave votes inside).
 #pragma once
 #include "mm3dgs_common.h"
+#include "composite_common.h"
 
 // NF4: float4s per record that carry data (2 or 3); RECF: record stride in floats; NTHREADS: workgroup size.
 // Inputs per lane: area (tiles in the splat's rectangle, 0 = culled), goff (first pair index), r0/r1 (tile rectangle),
@@ -64,9 +65,9 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
           const int oyp = pq == 0 ? oy[0] : (pq == 1 ? oy[1] : (pq == 2 ? oy[2] : oy[3]));
           const int bx = oxp + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oyp + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
           d0[u] = yshift ? sA.y - (4.f * (float)(by0 + by) + 1.5f) : 0.f;
-          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * RECF : (size_t)0));
-          a[u] = r[0]; b[u] = r[1];
-          c[u] = TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : r[2];
+          const float* r = dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * RECF : (size_t)0);
+          a[u] = ld4u(r); b[u] = ld4u(r + 4);      // (packed records: the lanes past a record's own floats are never used)
+          c[u] = TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4u(r + 8);
         }
 #pragma unroll
         for (int u = 0; u < UB; u++) {
@@ -184,9 +185,9 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
 #pragma unroll
         for (int u = 0; u < UF; u++) {
           on[u] = (mk[u] >> Lq[u]) & 1u;
-          const float4* r = (const float4*)(dsub + (on[u] ? (size_t)recq[u] * RECF : (size_t)0));
-          a[u] = r[0]; b4[u] = r[1];
-          if (!TRACK) c4[u] = r[2];
+          const float* r = dsub + (on[u] ? (size_t)recq[u] * RECF : (size_t)0);
+          a[u] = ld4u(r); b4[u] = ld4u(r + 4);
+          if (!TRACK) c4[u] = ld4u(r + 8);
         }
 #pragma unroll
         for (int u = 0; u < UF; u++) {
