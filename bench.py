@@ -160,10 +160,11 @@ def cpu_baseline(args):
             "sec_per_iteration": sec}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the backward compositor from the committed rocprofv3 PMC passes (profiles/*_pmc_*.csv,
-    produced by tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KB units, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950).  None when no such summary is committed."""
+def pmc_traffic(match):
+    """HBM bytes per launch of the kernel whose name contains every string in `match`, from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_*.csv, produced by tools/profile_round.sh over this same bench command: FETCH_SIZE and WRITE_SIZE in separate
+    passes, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950).  None when no such summary
+    is committed."""
     import csv
     import glob
     vals, used = {}, []
@@ -171,7 +172,7 @@ def pmc_traffic():
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_slam_pmc_{c}.csv")))
         if not files:
             return None, None
-        rows = [r for r in csv.DictReader(open(files[-1])) if "composite_bwd" in r["kernel"] and ("<6, 1>" in r["kernel"] or "map" in r["kernel"])]
+        rows = [r for r in csv.DictReader(open(files[-1])) if all(m in r["kernel"] for m in match)]
         if not rows:
             return None, None
         vals[c] = float(rows[0]["mean_counter_value"]) * 1024.0
@@ -433,10 +434,13 @@ def main():
                      "timed_launches": n_k, "launches_per_frame": per_frame, "ms_per_frame": dur * 1e3 * per_frame})
     if recs:
         recs.sort(key=lambda r_: -r_["ms_per_frame"])
-        traffic, traffic_src = pmc_traffic()
+        pmc_names = {"composite_bwd_kernel<6,1>": ("composite_bwd_kernel", "<6, 1>"), "composite_bwd_kernel<6,2>": ("composite_bwd_kernel", "<6, 2>"),
+                     "sort_composite_fwd_kernel<6>": ("sort_composite_fwd_kernel",)}
         for r_ in recs:
+            for pre, match in pmc_names.items():
+                if r_["kernel"].startswith(pre):
+                    r_["traffic"], r_["traffic_source"] = pmc_traffic(match)
             if r_["kernel"].startswith("composite_bwd_kernel<6,1>"):
-                r_["traffic"], r_["traffic_source"] = traffic, traffic_src
                 # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any early-out, ~25 flop + 1 exp
                 # each, against the dense f32 VALU peak -- the ceiling this kernel actually runs into (profiles/r01_sq_counters.md)
                 d_ = r_["avg_launch_us"] * 1e-6

@@ -12,6 +12,9 @@
 template <int KIND>
 __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed) {
   float r[8];
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v p[8], pseed = {seed, seed * 0.5f};
+  for (int i = 0; i < 8; i++) p[i] = f2v{seed + threadIdx.x * 0.001f + i, seed - i};
   for (int i = 0; i < 8; i++) r[i] = seed + threadIdx.x * 0.001f + i;
   __shared__ float4 lds[256];
   if (threadIdx.x < 256) lds[threadIdx.x] = make_float4(seed, seed, seed, seed);
@@ -74,6 +77,18 @@ __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed
 #define S(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[i]) : "v"(seed));
       OP32(S)
 #undef S
+    } else if (KIND == 14) {  // packed f32 fma (two floats per lane in a register pair)
+#define S(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(pseed));
+      OP32(S)
+#undef S
+    } else if (KIND == 15) {
+#define S(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pseed));
+      OP32(S)
+#undef S
+    } else if (KIND == 16) {
+#define S(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pseed));
+      OP32(S)
+#undef S
     } else if (KIND == 13) {  // cndmask with an SGPR-pair mask (VOP3)
       unsigned long long m = 0x5555555555555555ull;
 #define S(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(seed), "s"(m));
@@ -83,7 +98,7 @@ __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed
   }
   long long t1 = clock64();
   float s = acc4.x + acc4.y;
-  for (int i = 0; i < 8; i++) s += r[i];
+  for (int i = 0; i < 8; i++) s += r[i] + p[i].x + p[i].y;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -121,5 +136,8 @@ int main() {
   run<9>("ds_read_b128 broadcast", out, cyc);
   run<10>("ds_read_b128 per-lane", out, cyc);
   run<11>("fma -> dependent dpp (pairs)", out, cyc);
+  run<14>("v_pk_fma_f32", out, cyc);
+  run<15>("v_pk_mul_f32", out, cyc);
+  run<16>("v_pk_add_f32", out, cyc);
   return 0;
 }
