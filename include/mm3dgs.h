@@ -61,7 +61,12 @@ typedef struct Mm3dgsHeader {
   uint32_t fwd_wave_iters; /* (wave, splat) evaluations executed by the forward compositor  */
   uint32_t bwd_wave_iters; /* (wave, splat) evaluations that reached the gradient reduction */
   uint32_t bwd_wave_visits;/* (wave, splat) evaluations executed by the backward compositor */
-  uint32_t reserved1;
+  uint32_t bin_cap;        /* 0: the tile bins are packed (bin of tile t = [ranges[t], ranges[t+1])); otherwise every tile owns a
+                              fixed span of bin_cap pairs starting at t * bin_cap (MM3DGS_FWD_DIRECT_BINS) and ranges[t] holds
+                              its length.  Written by every forward. */
+  uint32_t max_group_records; /* direct bins: most gradient records of one projection workgroup (256 Gaussians) since the host
+                                 last cleared it (sticky); every workgroup owns 16 * N_capacity / ceil(P / 256) records of the
+                                 backward scratch, a workgroup that needs more sets `overflow` */
 } Mm3dgsHeader;
 
 /* ---- buffer sizing (pure host arithmetic) ------------------------------------------------------------- */
@@ -167,6 +172,11 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
 /* flags for mm3dgs_slam_forward */
 #define MM3DGS_FWD_STATE_CLEAN 1 /* image_state's header+tile counters are already zero (the library leaves them zero
                                     after every forward), so the per-call memset is skipped: for persistent state buffers */
+#define MM3DGS_FWD_DIRECT_BINS 4 /* N_capacity was sized as T x (per-tile capacity): projection and binning run as ONE launch that
+                                    drops every (Gaussian, tile) pair straight into the tile's fixed span (no tile counting pass, no
+                                    scan).  A tile with more pairs than N_capacity / T sets `overflow`.  Needs STATE_CLEAN and
+                                    SHORT_LISTS; ignored (packed bins) otherwise or when P > 524288.  The gradient records are
+                                    then laid out per projection workgroup (see Mm3dgsHeader.max_group_records). */
 #define MM3DGS_FWD_SHORT_LISTS 2 /* hint: no tile list exceeds 2048 splats -> one sort launch (longer lists stay correct
                                     through the global-memory path, only slower)                                        */
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color /*[6,H,W]*/,
@@ -176,7 +186,7 @@ int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs*
                          const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                          const float* dL_dout /*[6,H,W]*/, void* backward_scratch, const Mm3dgsSlamGrads* grads,
                          float* dL_dpose /*[7] or NULL*/, const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam,
-                         void* stream);
+                         int flags /* the flags of the mm3dgs_slam_forward call whose state this is */, void* stream);
 
 /* Visibility of the map from one pose with the projection stage alone (no binning, no compositing): radii[P] as the forward pass
  * would report them, and seen_count[i] += (radii[i] > 0) when seen_count != NULL -- what get_covisible_gaussians needs

@@ -90,7 +90,7 @@ _SIGS = {
     "mm3dgs_slam_forward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                       C.c_int, _P]),
     "mm3dgs_slam_backward": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, C.c_size_t, _P, _P,
-                                       C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), C.POINTER(Mm3dgsMapAdam), _P]),
+                                       C.POINTER(Mm3dgsSlamGrads), _P, C.POINTER(Mm3dgsPoseAdam), C.POINTER(Mm3dgsMapAdam), C.c_int, _P]),
     "mm3dgs_slam_visibility": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P]),
     "mm3dgs_slam_track": (C.c_int, [C.c_int, C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), _P, _P, _P, _P, _P, C.c_size_t,
                                     C.c_int, C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, C.POINTER(Mm3dgsPoseAdam), _P]),

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "mm3dgs_common.h"
+#include <algorithm>
 #include "fused_api.h"
 
 static thread_local char g_err[512] = "";
@@ -200,6 +201,24 @@ static bool slam_fused_sort(int flags) {
   return (flags & MM3DGS_FWD_SHORT_LISTS) && !no_fused_sort;
 }
 
+// direct bins (MM3DGS_FWD_DIRECT_BINS): one decision for the forward and the backward of a render
+struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks; };
+static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_capacity) {
+  static const int no_direct = env_flag("MM3DGS_NO_DIRECT_BINS", 0);
+  static const int no_fused_scan = env_flag("MM3DGS_NO_FUSED_SCAN", 0);
+  DirectBins d;
+  const int T = cd.gx * cd.gy;
+  d.nblocks = (P + 255) / 256;
+  const size_t nb = (size_t)std::max(d.nblocks, 1);
+  d.bin_cap = (uint32_t)std::min<size_t>(N_capacity / (size_t)std::max(T, 1), DIRECT_MAX_CAP);
+  // records of the backward scratch per projection workgroup (the scratch holds NLIST records per pair of capacity)
+  d.rec_cap = (uint32_t)std::min<size_t>((size_t)NLIST * N_capacity / nb, 0xffffffffull / nb);
+  d.on = (flags & MM3DGS_FWD_DIRECT_BINS) && (flags & MM3DGS_FWD_STATE_CLEAN) && slam_fused_sort(flags) && !no_direct && !no_fused_scan &&
+         P > 0 && P <= DIRECT_MAX_P && T <= MAX_FUSED_SCAN_TILES && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
+         N_capacity >= 4 * (size_t)P;
+  return d;
+}
+
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                              void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
                              const TrackLoss* tl) {
@@ -216,11 +235,18 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
   // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
-  if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
   const bool fused_sort = slam_fused_sort(flags);
   if (tl && !fused_sort) return fail(-1, "internal: folded tracking loss needs the fused sort path");
+  // direct bins: the host sized the binning state as T x (per-tile capacity), so projection and binning are one launch
+  const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
+  if (db.on) {
+    { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, s); }
+    { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks); }
+    return check_launch("slam_forward");
+  }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
+  if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
     if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
@@ -248,7 +274,7 @@ int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* 
 static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
-                              const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream, const TrackLoss* tl,
+                              const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, int flags, void* stream, const TrackLoss* tl,
                               float* prior_loss4 = nullptr, int dl_planes = 6) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
@@ -305,16 +331,16 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, bwd2);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, bwd2 ? 1 : 0); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, bwd2 ? 1 : 0, slam_direct_bins(flags, cd, P, N_capacity).on); }
   return check_launch("slam_backward");
 }
 
 int mm3dgs_slam_backward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
                          const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                          const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
-                         const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, void* stream) {
+                         const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, int flags, void* stream) {
   return slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, grads, dL_dpose,
-                            pose_adam, map_adam, stream, nullptr);
+                            pose_adam, map_adam, flags, stream, nullptr);
 }
 
 static size_t loss_rows(int H, int W) { return (size_t)((W + 15) / 16) * ((H + 15) / 16); }
@@ -381,7 +407,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
       if (rc) return rc;
     }
     rc = slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                            nullptr, pose_adam, nullptr, stream, fold ? &tl : nullptr, loss4);
+                            nullptr, pose_adam, nullptr, fwd_flags, stream, fold ? &tl : nullptr, loss4);
     if (rc) return rc;
   }
   return 0;
@@ -437,14 +463,14 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       if (rc) return rc;
       tl.dmaps = fold_grad ? dmaps : nullptr;
       rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
-                              views[it].pose_adam_or_null, map_adam ? &ad : nullptr, stream, fold_grad ? &tl : nullptr, nullptr, 4);
+                              views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream, fold_grad ? &tl : nullptr, nullptr, 4);
     } else {
       rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
       if (rc) return rc;
       rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
       if (rc) return rc;
       rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
-                                nullptr, views[it].pose_adam_or_null, map_adam ? &ad : nullptr, stream);
+                                nullptr, views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream);
     }
     if (rc) return rc;
     ad.step++;

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
     iv.hdr->max_tile_len = sticky ? max(iv.hdr->max_tile_len, maxlen_s) : maxlen_s;
     iv.hdr->max_num_rendered = sticky ? max(iv.hdr->max_num_rendered, total) : total;
     if (!sticky) iv.hdr->overflow = 0;
+    iv.hdr->bin_cap = 0;
   }
   __syncthreads();
   // tiles touched per preprocess workgroup -> exclusive prefix (first pair index of each workgroup's Gaussians)
@@ -199,6 +200,7 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
       iv.hdr->max_tile_len = max(iv.hdr->max_tile_len, maxlen_s);
       iv.hdr->max_num_rendered = max(iv.hdr->max_num_rendered, total);
       if (total > N_cap) iv.hdr->overflow = 1u;
+      iv.hdr->bin_cap = 0;   // packed bins
     }
   }
   if (blockIdx.x == (gridDim.x > 1 ? 1 : 0)) {

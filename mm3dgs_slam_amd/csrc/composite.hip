@@ -34,7 +34,7 @@ template <int C>
 __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
                                                    uint32_t N_cap, float* __restrict__ out, float4 (*stg)[4][3][64],
                                                    const uint32_t* counts_lds, const TrackLoss* tl = nullptr,
-                                                   double (*red)[12] = nullptr) {
+                                                   double (*red)[12] = nullptr, const SortShared* span = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
@@ -42,8 +42,9 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
-  const uint32_t len = end - start;
+  uint32_t start, len;
+  if (span) { start = span->start; len = span->len; }        // fused with the sort: the same workgroup just determined the bin
+  else tile_span(iv, tile, N_cap, start, len);
   const int L = 4 * wv + row;
   const uint32_t count = len ? min(counts_lds ? counts_lds[L] : iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
   uint32_t maxcount = count;
@@ -173,7 +174,7 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 template <int C>
 __global__ void __launch_bounds__(256)
 sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean, int has_tl,
-                          TrackLoss tl) {
+                          TrackLoss tl, int direct_blocks) {
   __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * 64];   // 24 KB >= 2048 keys (16 KB)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
@@ -181,9 +182,11 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks);
+  if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
-  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, has_tl ? &tl : nullptr, red);
+  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
+
 }
 
 // ---- multi-value wave reduction ---------------------------------------------------------------------------------
@@ -345,8 +348,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
-  const uint32_t len = end - start;
+  uint32_t start, len;
+  tile_span(iv, tile, N_cap, start, len);
   const int L = 4 * wv + row;
   const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
@@ -579,12 +582,12 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
 }
 
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
-                                const TrackLoss* tl) {
+                                const TrackLoss* tl, int direct_blocks) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
-  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none);
+  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,

@@ -54,7 +54,9 @@ composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   const int py = (tile / cam.gx) * TILE + 4 * by + k;
   const bool in0 = px0 < cam.W && py < cam.H, in1 = px0 + 1 < cam.W && py < cam.H;
   const float pxf0 = (float)px0, pxf1 = (float)(px0 + 1), pyf = (float)py;
-  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
+  uint32_t start, len_;
+  tile_span(iv, tile, N_cap, start, len_);
+  const uint32_t end = start + len_;
   const uint32_t len = end - start;
   const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
@@ -270,7 +272,9 @@ composite_bwd3_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (bq >> 1) * 4 + k;
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
-  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
+  uint32_t start, len_;
+  tile_span(iv, tile, N_cap, start, len_);
+  const uint32_t end = start + len_;
   const uint32_t len = end - start;
   const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;

@@ -12,6 +12,7 @@
 #include "mm3dgs_math.h"
 #include "fused_api.h"
 #include "gather_records.h"
+#include "tile_mask.h"
 
 #define FB 256
 #define SH_C0F 0.28209479177387814f
@@ -59,14 +60,11 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
   slam_cov3d_vals(q, ls, in.isotropic != 0, mod, S3, R, sm, qn, qinv);
 }
 
-__global__ void __launch_bounds__(FB)
-slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles,
-                           int vis_only, uint32_t* __restrict__ seen) {
-  extern __shared__ uint32_t hist[];
-  const int T = cam.gx * cam.gy;
-  for (int t = threadIdx.x; t < lds_tiles; t += FB) hist[t] = 0;
-  if (lds_tiles) __syncthreads();
-  const int idx = blockIdx.x * FB + threadIdx.x;
+// Projection of one Gaussian (lane): pose transform, activations, EWA, SH degree 0 -> RGB, [z, 1, z^2], tile rectangle, block
+// rectangle.  Writes the splat record, depth, clamp bits, radii and rect; returns what the binning half of the kernels needs.
+struct Projected { uint32_t r0, r1, nblk; float4 sA, sB; BlkRect br; float z; int32_t rad; };
+__device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, int idx, const SlamIn& in, int32_t* __restrict__ radii,
+                                                      const GeomView& g) {
   const bool live = idx < P;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
@@ -85,8 +83,10 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
 #pragma unroll
     for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
   }
-  int32_t rad = 0;
-  uint32_t r0 = 0, r1 = 0, nblk = 0;
+  Projected o;
+  o.r0 = 0; o.r1 = 0; o.nblk = 0; o.rad = 0; o.z = 0.f;
+  o.sA = make_float4(0.f, 0.f, 0.f, 0.f); o.sB = o.sA;
+  o.br.bx0 = 0; o.br.by0 = 0; o.br.bw = 0; o.br.bh = 0;
   if (live && p[2] > 0.2f) {
     float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
     float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
@@ -110,30 +110,46 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
       int maxx = min(cam.gx, max(0, (int)fminf(fmaxf((px + rf + (TILE - 1)) / TILE, -1.f), gxf)));
       int maxy = min(cam.gy, max(0, (int)fminf(fmaxf((py + rf + (TILE - 1)) / TILE, -1.f), gyf)));
       if ((maxx - minx) * (maxy - miny) > 0) {
-        rad = (int32_t)fminf(rf, 2.0e9f);
-        r0 = (uint32_t)minx | ((uint32_t)miny << 16);
-        r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
+        o.rad = (int32_t)fminf(rf, 2.0e9f);
+        o.r0 = (uint32_t)minx | ((uint32_t)miny << 16);
+        o.r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
         const float* fd = fd_raw;
         float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
         g.clamped[idx] = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
         const float z = p[2];
         const float op = 1.f / (1.f + __expf(-op_raw));
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
-        const float4 sA = make_float4(px, py, e.c * dinv, -e.b * dinv), sB = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
-        sp[0] = sA;
-        sp[1] = sB;
-        const BlkRect br = block_rect(sA, sB, r0, r1);
-        nblk = (uint32_t)(br.bw * br.bh);
+        o.sA = make_float4(px, py, e.c * dinv, -e.b * dinv); o.sB = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
+        sp[0] = o.sA;
+        sp[1] = o.sB;
+        o.br = block_rect(o.sA, o.sB, o.r0, o.r1);
+        o.nblk = (uint32_t)(o.br.bw * o.br.bh);
         sp[2] = make_float4(fmaxf(c2, 0.f), z, 1.f, z * z);
         g.depth[idx] = z;
+        o.z = z;
       }
     }
   }
   if (live) {
-    radii[idx] = rad;
-    g.rect[(size_t)idx * 2] = r0;
-    g.rect[(size_t)idx * 2 + 1] = r1;
+    radii[idx] = o.rad;
+    g.rect[(size_t)idx * 2] = o.r0;
+    g.rect[(size_t)idx * 2 + 1] = o.r1;
   }
+  return o;
+}
+
+__global__ void __launch_bounds__(FB)
+slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles,
+                           int vis_only, uint32_t* __restrict__ seen) {
+  extern __shared__ uint32_t hist[];
+  const int T = cam.gx * cam.gy;
+  for (int t = threadIdx.x; t < lds_tiles; t += FB) hist[t] = 0;
+  if (lds_tiles) __syncthreads();
+  const int idx = blockIdx.x * FB + threadIdx.x;
+  const bool live = idx < P;
+  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
+  const uint32_t r0 = pr.r0, r1 = pr.r1, nblk = pr.nblk;
+  const int32_t rad = pr.rad;
   if (vis_only) {      // mm3dgs_slam_visibility: the projection stage alone (workgroup-uniform): no tile counting, no scans
     if (live && seen && rad > 0) seen[idx] += 1u;
     return;
@@ -190,9 +206,129 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
                      iv, lds_tiles, visibility_only ? 1 : 0, seen);
 }
 
+// ---- projection + binning in ONE launch (direct bins) -----------------------------------------------------------------------------
+// Every tile owns a fixed span of `cap` pairs at tile * cap (the host sized the binning state as T x cap from the longest
+// list it has seen), so a pair's slot does not depend on a global prefix: no tile-count pass, no scan, no second kernel.  One
+// lane per Gaussian, two sweeps over its tile rectangle around a per-workgroup LDS histogram: sweep 1 counts the workgroup's
+// pairs per tile, one returning global atomic per *touched tile* reserves slots in the tile's span, sweep 2 hands them out
+// with LDS atomics and writes, per pair, the key (depth bits | id | slot) and the payload the sort needs to emit the block
+// lists without touching the splat again: the 16-bit block mask (tile_mask.h), the width of the splat's block rectangle and
+// the gradient record of the tile's first block.  Records need no global prefix either: projection workgroup w owns records
+// [w * rec_cap, (w + 1) * rec_cap) of the backward scratch (rec_cap = scratch capacity / workgroups, ~7x what a SLAM map
+// uses) and publishes its base as g.block_blk[w], where the backward projection looks it up as before.  A tile with more
+// than `cap` pairs drops the excess and the sort flags the overflow; a workgroup with more than rec_cap records flags it
+// here and lists none of the splats that do not fit (both sticky, like a packed bin that runs out of capacity).
+struct PairCtx {           // what a lane needs to emit the pairs of ITS Gaussian (broadcast lane by lane for huge splats)
+  MaskConsts mc; BlkRect br; uint32_t rec0; uint32_t khi, idbits; int minx, miny, w, area;   // rec0: first record (absolute)
+};
+__device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t* hist, int gx, uint32_t cap, const BinView& b) {
+  const int ttx = c.minx + k % c.w, tty = c.miny + k / c.w;
+  const int t = tty * gx + ttx;
+  const uint32_t slot = atomicAdd(&hist[t], 1u);
+  uint32_t mask = 0;
+  if (slot < cap) {
+    mask = clip_mask_to_rect(tile_block_mask(c.mc, ttx, tty), ttx, tty, c.br);
+    const uint32_t rec_local = c.rec0 + (uint32_t)((tty * 4 - c.br.by0) * c.br.bw + (ttx * 4 - c.br.bx0));
+    const size_t at = (size_t)t * cap + slot;
+    b.keys[at] = ((unsigned long long)c.khi << 32) | (unsigned long long)(c.idbits | slot);
+    b.payload[at] = (unsigned long long)mask | ((unsigned long long)(uint32_t)min(c.br.bw, 0xffff) << 16) | ((unsigned long long)rec_local << 32);
+  }
+  return mask;
+}
+
+__global__ void __launch_bounds__(FB)
+slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
+                        uint32_t rec_cap) {
+  extern __shared__ uint32_t hist[];     // [T]: pairs of this workgroup per tile, then the next slot of each touched tile
+  const int T = cam.gx * cam.gy;
+  const int tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
+  for (int t = tid; t < T; t += FB) hist[t] = 0;
+  if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
+  const int idx = blockIdx.x * FB + tid;
+  const bool live = idx < P;
+  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
+  PairCtx c;
+  c.mc = mask_consts(pr.sA, pr.sB);
+  c.br = pr.br;
+  c.minx = pr.r0 & 0xffff; c.miny = pr.r0 >> 16;
+  c.w = (int)(pr.r1 & 0xffff) - c.minx;
+  c.area = c.w * ((int)(pr.r1 >> 16) - c.miny);
+  c.khi = __float_as_uint(pr.z);
+  c.idbits = (uint32_t)idx << DIRECT_SLOT_BITS;
+  {   // workgroup-local exclusive scan of the gradient records (4x4 blocks of the block rectangles) + the workgroup's pairs
+    __shared__ uint32_t wtot[FB / 64], wtot2[FB / 64];
+    uint32_t x = pr.nblk, x2 = (uint32_t)c.area;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
+      if (lane >= off) { x += y; x2 += y2; }
+    }
+    if (lane == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
+    __syncthreads();                      // (also orders the histogram clear before sweep 1)
+    uint32_t pre = 0, pre2 = 0;
+    for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
+    const uint32_t local = pre + x - pr.nblk;
+    if (live) g.blkoff[idx] = local;
+    const uint32_t base = (uint32_t)blockIdx.x * rec_cap;
+    c.rec0 = base + local;
+    if (local + pr.nblk > rec_cap) { c.br.bw = 0; c.br.bh = 0; }     // does not fit: listed nowhere (clip_mask_to_rect), flagged below
+    if (tid == FB - 1) {
+      const uint32_t tot = pre + x;
+      g.block_blk[blockIdx.x] = base;     // first record of this workgroup's splats (read by the backward projection)
+      g.tileoff[blockIdx.x] = pre2 + x2;  // pairs of this workgroup (summed into num_rendered by the sort)
+      if (tot > rec_cap) iv.hdr->overflow = 1u;
+      if (tot > iv.hdr->max_group_records) atomicMax(&iv.hdr->max_group_records, tot);   // (rare: the maximum is sticky)
+    }
+  }
+  // sweep 1: count (a rectangle of more than 32 tiles is spread over the wave)
+  unsigned long long big = __ballot(c.area > 32);
+  if (c.area > 0 && c.area <= 32)
+    for (int k = 0; k < c.area; k++) atomicAdd(&hist[(c.miny + k / c.w) * cam.gx + c.minx + k % c.w], 1u);
+  for (unsigned long long bb = big; bb; bb &= bb - 1) {
+    const int src = __ffsll((long long)bb) - 1;
+    const int sminx = __builtin_amdgcn_readlane(c.minx, src), sminy = __builtin_amdgcn_readlane(c.miny, src);
+    const int sw = __builtin_amdgcn_readlane(c.w, src), sarea = __builtin_amdgcn_readlane(c.area, src);
+    for (int k = lane; k < sarea; k += 64) atomicAdd(&hist[(sminy + k / sw) * cam.gx + sminx + k % sw], 1u);
+  }
+  __syncthreads();
+  for (int t = tid; t < T; t += FB) {
+    const uint32_t n = hist[t];
+    if (n) hist[t] = atomicAdd(&iv.cursor[t], n);
+  }
+  __syncthreads();
+  // sweep 2: slots, keys, payloads
+  // the block masks of a splat of up to four tiles (nearly all of a SLAM map) also go, as one 64-bit word, where the backward
+  // projection finds them by Gaussian index (the submask region of the binning state, read as u64[P]; pair k = bits 16k..16k+15)
+  unsigned long long m64 = 0ull;
+  if (c.area > 0 && c.area <= 32)
+    for (int k = 0; k < c.area; k++) {
+      const uint32_t mk = emit_pair(c, k, hist, cam.gx, cap, b);
+      if (k < 4) m64 |= (unsigned long long)mk << (16 * k);
+    }
+  if (live) ((unsigned long long*)b.submask)[idx] = c.area <= 4 ? m64 : 0ull;
+  for (unsigned long long bb = big; bb; bb &= bb - 1) {
+    const int src = __ffsll((long long)bb) - 1;
+    PairCtx s;
+    auto rl = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
+    auto rf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
+    s.mc.cx = rf(c.mc.cx); s.mc.cy = rf(c.mc.cy); s.mc.hx = rf(c.mc.hx); s.mc.hy = rf(c.mc.hy); s.mc.r2 = rf(c.mc.r2); s.mc.mode = rl(c.mc.mode);
+    s.br.bx0 = rl(c.br.bx0); s.br.by0 = rl(c.br.by0); s.br.bw = rl(c.br.bw); s.br.bh = rl(c.br.bh);
+    s.rec0 = (uint32_t)rl((int)c.rec0); s.khi = (uint32_t)rl((int)c.khi); s.idbits = (uint32_t)rl((int)c.idbits);
+    s.minx = rl(c.minx); s.miny = rl(c.miny); s.w = rl(c.w); s.area = rl(c.area);
+    for (int k = lane; k < s.area; k += 64) emit_pair(s, k, hist, cam.gx, cap, b);
+  }
+}
+
+void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
+                             uint32_t rec_cap, hipStream_t s) {
+  if (P <= 0) return;
+  const int T = cam.gx * cam.gy;
+  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
-template <bool TRACK>
+template <bool TRACK, bool DIRECT>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma, int yshift) {
@@ -212,10 +348,13 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     // one round of independent loads for everything the gather needs (this kernel is a chain of memory latencies: every
     // dependent step costs ~2 us).  A culled Gaussian has rect = 0 (and an unwritten splat record, read but never used).
     uint32_t r0 = 0, r1 = 0, toff = 0, boff = 0, btile = 0, bblk = 0;
+    unsigned long long m64 = 0ull;   // direct bins: the block masks of a splat of up to four tiles, left at submask-as-u64[idx]
     if (idx < P) {
       rad = radii[idx];
       r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
-      toff = g.tileoff[idx]; boff = g.blkoff[idx]; btile = g.block_tiles[idx >> 8]; bblk = g.block_blk[idx >> 8];
+      boff = g.blkoff[idx]; bblk = g.block_blk[idx >> 8];
+      if (DIRECT) m64 = ((const unsigned long long*)bn.submask)[idx];
+      else { toff = g.tileoff[idx]; btile = g.block_tiles[idx >> 8]; }
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
       sA = spl[0]; sB = spl[1];
     }
@@ -223,7 +362,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = btile + toff;
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0);
+    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0, m64);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -539,17 +678,15 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4, int yshift) {
+                                const PoseLossScale* pls, float* loss4, int yshift, bool direct) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
   if (P > 0) {
-    if (out.d_xyz || ma.on)
-      hipLaunchKernelGGL(slam_preprocess_bwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, partial, out, ma, yshift);
-    else
-      hipLaunchKernelGGL(slam_preprocess_bwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap,
-                         bw.dsub, partial, out, ma, yshift);
+    const bool map = out.d_xyz || ma.on;
+    auto kern = map ? (direct ? slam_preprocess_bwd_kernel<false, true> : slam_preprocess_bwd_kernel<false, false>)
+                    : (direct ? slam_preprocess_bwd_kernel<true, true> : slam_preprocess_bwd_kernel<true, false>);
+    hipLaunchKernelGGL(kern, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, yshift);
   }
   if (want_pose)
   {

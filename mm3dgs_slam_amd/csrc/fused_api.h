@@ -47,7 +47,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
                                 uint32_t* seen_only = nullptr, bool visibility_only = false);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls = nullptr, float* loss4 = nullptr, int yshift = 0);
+                                const PoseLossScale* pls = nullptr, float* loss4 = nullptr, int yshift = 0, bool direct = false);
 // second-generation backward compositor (composite_bwd2.hip): 2 pixels per lane, MFMA block reduction; its records need yshift = 1
 void launch_composite_bwd2_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
                                 float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes, int gen = 2);
@@ -57,7 +57,10 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
                                float* dsub, hipStream_t s, const TrackLoss* tl = nullptr, int dl_planes = 6);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
-                                const TrackLoss* tl = nullptr);
+                                const TrackLoss* tl = nullptr, int direct_blocks = 0);
+// projection + binning in one launch (direct bins: every tile owns bin_cap pairs at tile * bin_cap)
+void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
+                             uint32_t rec_cap, hipStream_t s);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s);

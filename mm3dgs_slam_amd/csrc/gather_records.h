@@ -3,6 +3,7 @@
 #pragma once
 #include "mm3dgs_common.h"
 #include "composite_common.h"
+#include "tile_mask.h"
 
 // NF4: float4s per record that carry data (2 or 3); RECF: record stride in floats; NTHREADS: workgroup size.
 // Inputs per lane: area (tiles in the splat's rectangle, 0 = culled), goff (first pair index), r0/r1 (tile rectangle),
@@ -29,10 +30,13 @@ __device__ __forceinline__ void add_record(bool on, bool ys, float d0, const flo
   }
 }
 
-template <int NF4, int RECF, int NTHREADS>
+// DIRECT (direct bins, which have no Gaussian-major pair index to address submask[] with): the block masks of a small splat
+// arrive as one 64-bit word (m64: written per Gaussian by the binning kernel), the blocks of a big splat are re-tested with
+// the very rule the lists were built with (tile_mask.h).
+template <int NF4, int RECF, int NTHREADS, bool DIRECT = false>
 __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t r0, uint32_t r1, const float4& sA, const float4& sB,
                                                uint32_t rec_first, const float* __restrict__ dsub, const BinView& bn, uint32_t N_cap,
-                                               float4& acc0, float4& acc1, float4& acc2, bool yshift = false) {
+                                               float4& acc0, float4& acc1, float4& acc2, bool yshift = false, unsigned long long m64 = 0ull) {
   constexpr bool TRACK = NF4 == 2;
   {
     // Gradient records: one per (splat, 4x4 block), dense and contiguous per Gaussian (row-major over its block rectangle,
@@ -43,10 +47,17 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
     BlkRect br = {0, 0, 0, 0};
     uint32_t rec0 = 0;
     int tminx = 0, tminy = 0, tw = 1;
+    MaskConsts mc;
+    mc.cx = mc.cy = mc.hx = mc.hy = mc.r2 = 0.f; mc.mode = 0;
     if (area > 0) {
       br = block_rect(sA, sB, r0, r1);
       rec0 = rec_first;
       tminx = r0 & 0xffff; tminy = r0 >> 16; tw = max((int)(r1 & 0xffff) - tminx, 1);
+      if (DIRECT) {
+        mc = mask_consts(sA, sB);
+        // records beyond the scratch capacity were never written (the forward flagged the overflow): read nothing
+        if ((size_t)rec0 + (size_t)br.bw * br.bh > (size_t)NLIST * N_cap) area = 0;
+      }
     }
     // M: block masks of up to four pairs; (ox[p], oy[p]) = block coordinates of pair p's tile relative to the block rectangle
     auto drain = [&](unsigned long long M, const int (&ox)[4], const int (&oy)[4], int bw, uint32_t base, int by0) {
@@ -97,7 +108,8 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
         int ox[4], oy[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          M |= mask_of(goff + (uint32_t)(k0 + k), k0 + k < area) << (16 * k);
+          if (DIRECT) M = m64;          // (a small splat has at most four tiles: one round)
+          else M |= mask_of(goff + (uint32_t)(k0 + k), k0 + k < area) << (16 * k);
           ox[k] = (tminx + tx) * 4 - br.bx0; oy[k] = (tminy + ty) * 4 - br.by0;
           if (++tx == tw) { tx = 0; ty++; }
         }
@@ -110,7 +122,7 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
     // crosses to that owner's accumulator in LDS.  Same code, same data, same lane order every run -> deterministic.
     const int lane = threadIdx.x & 63, wvq = threadIdx.x >> 6;
     if (__ballot(isbig && area > 0) != 0ull) {
-      __shared__ int s_par[NTHREADS / 64][64][9];      // [8]: the splat's centre y (float bits), for the y-shift
+      __shared__ int s_par[NTHREADS / 64][64][DIRECT ? 15 : 9];      // [8]: the splat's centre y (float bits), for the y-shift; [9..14]: mask constants
       __shared__ uint32_t s_pref[NTHREADS / 64][64];
       __shared__ float s_acc[NTHREADS / 64][64][12];
       const bool own = isbig && area > 0;
@@ -125,6 +137,10 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
       int* par = s_par[wvq][lane];
       par[0] = (int)rec0; par[1] = br.bw; par[2] = br.bx0; par[3] = br.by0; par[4] = tminx; par[5] = tminy; par[6] = tw; par[7] = (int)goff;
       par[8] = __float_as_int(sA.y);
+      if (DIRECT) {
+        par[9] = __float_as_int(mc.cx); par[10] = __float_as_int(mc.cy); par[11] = __float_as_int(mc.hx); par[12] = __float_as_int(mc.hy);
+        par[13] = __float_as_int(mc.r2); par[14] = mc.mode;
+      }
 #pragma unroll
       for (int qv = 0; qv < 12; qv++) s_acc[wvq][lane][qv] = 0.f;
       __builtin_amdgcn_wave_barrier();
@@ -177,8 +193,15 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
           const int k = ((ay >> 2) - pp[5]) * pp[6] + ((ax >> 2) - pp[4]);
           Lq[u] = 4 * ((((ay >> 1) & 1) * 2) + ((ax >> 1) & 1)) + (ay & 1) * 2 + (ax & 1);
           recq[u] = (uint32_t)pp[0] + (uint32_t)j;
-          const uint32_t gi = (uint32_t)pp[7] + (uint32_t)k;
-          mk[u] = (have[u] && gi < N_cap) ? (uint32_t)bn.submask[gi] : 0u;
+          if (DIRECT) {
+            MaskConsts om;
+            om.cx = __int_as_float(pp[9]); om.cy = __int_as_float(pp[10]); om.hx = __int_as_float(pp[11]); om.hy = __int_as_float(pp[12]);
+            om.r2 = __int_as_float(pp[13]); om.mode = pp[14];
+            mk[u] = (have[u] && block_listed(om, ax, ay)) ? (1u << Lq[u]) : 0u;
+          } else {
+            const uint32_t gi = (uint32_t)pp[7] + (uint32_t)k;
+            mk[u] = (have[u] && gi < N_cap) ? (uint32_t)bn.submask[gi] : 0u;
+          }
         }
         float4 a[UF], b4[UF], c4[UF];
         bool on[UF];

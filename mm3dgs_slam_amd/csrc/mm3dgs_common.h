@@ -98,10 +98,11 @@ struct BinView {
   unsigned long long* keys;  // [N_cap]
   uint2* sublist;            // [16*N_cap]
   uint16_t* submask;         // [N_cap]
+  unsigned long long* payload;  // [N_cap] direct bins only: block mask | block-rectangle width << 16 | record of the tile's first block << 32
 };
 static inline size_t binning_bytes_impl(size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 8, 256) + align_up(N * NLIST * 8, 256) + align_up(N * 2, 256);
+  return align_up(N * 8, 256) + align_up(N * NLIST * 8, 256) + align_up(N * 2, 256) + align_up(N * 8, 256);
 }
 static inline BinView bin_view(void* base, size_t N) {
   if (N < 1) N = 1;
@@ -109,9 +110,26 @@ static inline BinView bin_view(void* base, size_t N) {
   BinView b;
   b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
   b.sublist = (uint2*)c;            c += align_up(N * NLIST * 8, 256);
-  b.submask = (uint16_t*)c;
+  b.submask = (uint16_t*)c;         c += align_up(N * 2, 256);
+  b.payload = (unsigned long long*)c;
   return b;
 }
+
+// Direct bins (Mm3dgsHeader.bin_cap != 0): key = depth bits << 32 | Gaussian id << DIRECT_SLOT_BITS | slot in the tile's span
+// (ids are unique inside a tile, so the slot never decides the order; it leads the sorted entry back to its payload).
+#define DIRECT_SLOT_BITS 13
+#define DIRECT_MAX_P (1 << (32 - DIRECT_SLOT_BITS))
+#define DIRECT_MAX_CAP ((1 << DIRECT_SLOT_BITS) - 1)
+
+#ifdef __HIPCC__
+// bin of a tile: [start, start + len) of keys / payload; its block lists start at sublist + NLIST * start
+__device__ __forceinline__ void tile_span(const ImageView& iv, int tile, uint32_t N_cap, uint32_t& start, uint32_t& len) {
+  const uint32_t cap = iv.hdr->bin_cap;
+  const uint32_t a = iv.ranges[tile], b = iv.ranges[tile + 1];
+  if (cap) { start = (uint32_t)tile * cap; len = min(a, cap); }
+  else { start = min(a, N_cap); len = min(b, N_cap) - start; }
+}
+#endif
 
 struct BwdView {
   float* dsub;        // [16*N_cap][12] per-(4x4 block, splat) screen-space gradient records
@@ -144,15 +162,17 @@ __device__ __forceinline__ BlkRect block_rect(const float4 A, const float4 B, ui
   BlkRect q;
   q.bx0 = X0; q.by0 = Y0; q.bw = X1 - X0; q.bh = Y1 - Y0;
   if (q.bw <= 0 || q.bh <= 0) { q.bw = 0; q.bh = 0; return q; }
-  const float tau = __logf(255.f * B.y);
-  const float det = A.z * B.x - A.w * A.w;
+  // (rounded intrinsics: the rectangle is recomputed in several kernels and must come out identical in all of them)
+  const float tau = __logf(__fmul_rn(255.f, B.y));
+  const float det = __fsub_rn(__fmul_rn(A.z, B.x), __fmul_rn(A.w, A.w));
   if (!(det > 0.f)) return q;                      // degenerate conic: no culling
   if (!(tau > 0.f)) { q.bw = 0; q.bh = 0; return q; }
-  const float k = 2.f * tau / det;
-  const float hx = sqrtf(k * B.x) * 1.0002f + 0.012f, hy = sqrtf(k * A.z) * 1.0002f + 0.012f;
+  const float k = __fdiv_rn(__fmul_rn(2.f, tau), det);
+  const float hx = __fadd_rn(__fmul_rn(__fsqrt_rn(__fmul_rn(k, B.x)), 1.0002f), 0.012f);
+  const float hy = __fadd_rn(__fmul_rn(__fsqrt_rn(__fmul_rn(k, A.z)), 1.0002f), 0.012f);
   // block b covers pixel centres [4b, 4b+3]:  overlap  <=>  c - h <= 4b + 3  and  c + h >= 4b
-  const int bx0 = max(X0, (int)ceilf((A.x - hx - 3.f) * 0.25f)), bx1 = min(X1 - 1, (int)floorf((A.x + hx) * 0.25f));
-  const int by0 = max(Y0, (int)ceilf((A.y - hy - 3.f) * 0.25f)), by1 = min(Y1 - 1, (int)floorf((A.y + hy) * 0.25f));
+  const int bx0 = max(X0, (int)ceilf(__fmul_rn(__fsub_rn(__fsub_rn(A.x, hx), 3.f), 0.25f))), bx1 = min(X1 - 1, (int)floorf(__fmul_rn(__fadd_rn(A.x, hx), 0.25f)));
+  const int by0 = max(Y0, (int)ceilf(__fmul_rn(__fsub_rn(__fsub_rn(A.y, hy), 3.f), 0.25f))), by1 = min(Y1 - 1, (int)floorf(__fmul_rn(__fadd_rn(A.y, hy), 0.25f)));
   q.bx0 = bx0; q.by0 = by0; q.bw = max(bx1 - bx0 + 1, 0); q.bh = max(by1 - by0 + 1, 0);
   if (q.bw == 0 || q.bh == 0) { q.bw = 0; q.bh = 0; }
   return q;

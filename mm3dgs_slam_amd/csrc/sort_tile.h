@@ -2,12 +2,16 @@
 // (binning.hip) and the fused sort + forward-composite kernel (composite.hip).
 #pragma once
 #include "mm3dgs_common.h"
+#include "tile_mask.h"
 
 struct SortShared {            // LDS of one sorting workgroup besides the key array
   uint32_t wcnt[4][NLIST];     // per-wave entry counts of a 256-entry chunk, per block list
   uint32_t pre[4][NLIST];      // write cursor of (wave, list) for the chunk
   uint32_t run[NLIST];         // entries emitted so far per list (the final list lengths)
+  uint32_t start, len;         // the tile's bin (for the compositing phase of the same workgroup)
+  uint32_t scan_tot[4];        // direct bins: wave totals of the pair count (tile 0's workgroup)
 };
+
 
 // ---- 4. per-tile sort -------------------------------------------------------------------------------------------
 // All-ascending bitonic network ("flip" first sub-step, then half-cleaners): with every comparator pointing the
@@ -48,14 +52,46 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 // Every lane of the 256-lane workgroup must call it (barriers inside).
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
-                                               uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh) {
+                                               uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
+                                               int direct_blocks = 0) {
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
   uint32_t* run = sh.run;
-  const uint32_t start = min(iv.ranges[tile], N_cap), end = min(iv.ranges[tile + 1], N_cap);
-  const int len = (int)(end - start);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (clean && tid == 0) { iv.tile_count[tile] = 0; iv.cursor[tile] = 0; }   // scatter_scan_kernel's counters stay zero
+  // direct bins (direct_blocks = number of projection workgroups, 0 = packed bins): the tile's pairs sit in its fixed span,
+  // their number is the tile's cursor, and every pair's payload carries its block mask and gradient-record index
+  const bool direct = direct_blocks != 0;
+  uint32_t start, ulen;
+  if (direct) {
+    const uint32_t cap = iv.hdr->bin_cap, cnt = iv.cursor[tile], seen_max = iv.hdr->max_tile_len;
+    start = (uint32_t)tile * cap; ulen = min(cnt, cap);
+    if (tid == 0) {
+      iv.ranges[tile] = cnt;                     // (tile_span clamps to the span)
+      if (cnt > cap) iv.hdr->overflow = 1u;
+      if (cnt > seen_max) atomicMax(&iv.hdr->max_tile_len, cnt);     // (rare: the maximum is sticky)
+    }
+    if (tile == 0) {
+      // N = pairs touched = sum of the projection workgroups' totals (g.tileoff[0..direct_blocks)); ONE writer -- 1200
+      // same-address atomics would serialise in L2 for ~20 us
+      uint32_t x = 0;
+      for (int i = tid; i < direct_blocks; i += 256) x += g.tileoff[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      if (lane == 0) sh.scan_tot[wv] = x;
+      __syncthreads();
+      if (tid == 0) {
+        const uint32_t n = sh.scan_tot[0] + sh.scan_tot[1] + sh.scan_tot[2] + sh.scan_tot[3];
+        iv.hdr->num_rendered = n;
+        iv.hdr->max_num_rendered = max(iv.hdr->max_num_rendered, n);
+      }
+    }
+  } else {
+    start = min(iv.ranges[tile], N_cap);
+    ulen = min(iv.ranges[tile + 1], N_cap) - start;
+    if (clean && tid == 0) { iv.tile_count[tile] = 0; iv.cursor[tile] = 0; }   // scatter_scan_kernel's counters stay zero
+  }
+  const int len = (int)ulen;
+  if (tid == 0) { sh.start = start; sh.len = ulen; }
   if (lo == 0 && len == 0) {
     if (tid < NLIST) { iv.subcount[NLIST * tile + tid] = 0; run[tid] = 0; }
     return true;
@@ -64,7 +100,10 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
   if (!GLOBAL_TAIL && len > CAP) return false;
   unsigned long long* gk = b.keys + start;
   const bool in_lds = len <= CAP;
-  if (in_lds && len <= RANK_SORT_MAX) {
+  if (in_lds && (ex & 8)) {   // MM3DGS_EXP probe: no sort (timing only)
+    for (int i = tid; i < len; i += 256) sk[i] = gk[i];
+    __syncthreads();
+  } else if (in_lds && len <= RANK_SORT_MAX) {
     // Run sort + rank merge (keys are unique).  (1) every wave bitonic-sorts 64-key runs in registers (21 compare-exchange
     // steps through the LDS crossbar, no barriers); (2) the rank of a key = its position in its own run + its lower bound
     // in every other run (7-step binary searches, four runs interleaved), and the key goes straight to its final slot.
@@ -119,69 +158,39 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     __syncthreads();
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
   }
+  if (ex & 4) return true;   // MM3DGS_EXP probe: no emission (timing only)
   // ---- emit the 16 block lists (order preserving) ----
   const int ttx = tile % gx, tty = tile / gx;
-  const float tx0 = (float)(ttx * TILE), ty0 = (float)(tty * TILE);
   if (tid < NLIST) run[tid] = 0;
   __syncthreads();
+  // the binning kernel's counters stay zero (reset only now: every wave has read the count, none can still see the zero)
+  if (direct && tid == 0) iv.cursor[tile] = 0;
   uint2* sub = b.sublist + (size_t)NLIST * start;
   for (int base = 0; base < len; base += 256) {
     const int i = base + tid;
     const bool have = i < len;
-    uint32_t id = 0, pidx = 0, mask = 0, rec0 = 0;
-    BlkRect br = {0, 0, 0, 0};
-    if (have) {
+    uint32_t id = 0, mask = 0, recT = 0, bw = 0;
+    if (have && direct) {
+      const uint32_t low = (uint32_t)(in_lds ? sk[i] : gk[i]);
+      id = low >> DIRECT_SLOT_BITS;
+      const unsigned long long pl = b.payload[start + (low & DIRECT_MAX_CAP)];
+      mask = (uint32_t)(pl & 0xffffu);
+      bw = (uint32_t)(pl >> 16) & 0xffffu;
+      recT = (uint32_t)(pl >> 32);
+    } else if (have) {
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
       const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
       const float4 A = sp[0], B = sp[1];
-      // alpha >= 1/255  <=>  d^T Q d <= 2 tau, tau = ln(255 o), Q = [[A.z, A.w],[A.w, B.x]]
-      const float tau = __logf(255.f * B.y);
-      const float det = A.z * B.x - A.w * A.w;
-      if (det > 0.f) {
-        // a 4x4 block (pixel centres [x0, x0+3] x [y0, y0+3]) is listed only where the {alpha >= 1/255} region can reach:
-        // its axis-aligned bound must overlap the block AND the block must come within sqrt(2 tau lambda_max) of the centre
-        // (exact for isotropic splats, where the box test alone keeps the corners a disc cannot reach).  Both necessary.
-        const float t2 = 2.f * fmaxf(tau, 0.f);
-        const float k = t2 / det;
-        const float hx = sqrtf(k * B.x) * 1.0002f + 0.002f;
-        const float hy = sqrtf(k * A.z) * 1.0002f + 0.002f;
-        const float sxx = B.x / det, syy = A.z / det, mid = 0.5f * (sxx + syy);
-        const float lam = mid + sqrtf(fmaxf(mid * mid - 1.f / det, 0.f));
-        const float r2 = t2 * lam * 1.0004f + 0.01f;
-        const float cx = A.x - tx0, cy = A.y - ty0;
-        const bool live = tau > 0.f;
-        bool bx[4], by[4];
-        float ex[4], ey[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float lo = 4.f * q, hi = 4.f * q + 3.f;
-          bx[q] = live && (cx - hx <= hi) && (cx + hx >= lo);
-          by[q] = live && (cy - hy <= hi) && (cy + hy >= lo);
-          const float dxq = fmaxf(fmaxf(lo - cx, cx - hi), 0.f), dyq = fmaxf(fmaxf(lo - cy, cy - hi), 0.f);
-          ex[q] = dxq * dxq; ey[q] = dyq * dyq;
-        }
-#pragma unroll
-        for (int my = 0; my < 4; my++)
-#pragma unroll
-          for (int kx = 0; kx < 4; kx++) {
-            const int L = 4 * ((my >> 1) * 2 + (kx >> 1)) + (my & 1) * 2 + (kx & 1);   // 4 * sub-tile + block in sub-tile
-            if (bx[kx] && by[my] && (ex[kx] + ey[my] <= r2)) mask |= 1u << L;
-          }
-      } else {
-        mask = 0xffffu;  // degenerate conic: no culling, the exact per-pixel rule decides
-      }
       // pair index of (Gaussian, tile) in Gaussian-major order (-> submask), and the splat's first gradient record
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
-      pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
-      br = block_rect(A, B, r0, r1);
-      rec0 = g.block_blk[id >> 8] + g.blkoff[id];
-      // blocks outside the block rectangle cannot be listed (it bounds the same region with slack); belt and braces
-#pragma unroll
-      for (int L = 0; L < NLIST; L++) {
-        const int bx = ttx * 4 + ((L >> 2) & 1) * 2 + (L & 1) - br.bx0, by = tty * 4 + (L >> 3) * 2 + ((L >> 1) & 1) - br.by0;
-        if (bx < 0 || by < 0 || bx >= br.bw || by >= br.bh) mask &= ~(1u << L);
-      }
+      const uint32_t pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
+      const BlkRect br = block_rect(A, B, r0, r1);
+      const uint32_t rec0 = g.block_blk[id >> 8] + g.blkoff[id];
+      mask = clip_mask_to_rect(tile_block_mask(mask_consts(A, B), ttx, tty), ttx, tty, br);
+      bw = (uint32_t)br.bw;
+      // entry = {splat id, gradient record of (splat, block)}: row-major position of the block in the splat's rectangle
+      recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
       if (pidx < N_cap && (size_t)rec0 + (size_t)br.bw * br.bh <= (size_t)NLIST * N_cap) b.submask[pidx] = (uint16_t)mask;
       else mask = 0;   // only on capacity overflow (flagged in the header)
     }
@@ -204,12 +213,10 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     __syncthreads();
     if (mask) {
       const unsigned long long lt = (1ull << lane) - 1ull;
-      // entry = {splat id, gradient record of (splat, block)}: row-major position of the block in the splat's rectangle
-      const uint32_t recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
 #pragma unroll
       for (int L = 0; L < NLIST; L++)
         if ((mask >> L) & 1u) {
-          const uint32_t rec = recT + (uint32_t)(((L >> 3) * 2 + ((L >> 1) & 1)) * br.bw + ((L >> 2) & 1) * 2 + (L & 1));
+          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
           sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = make_uint2(id, rec);
         }
     }

@@ -38,6 +38,7 @@ def _p(t):
 class FusedEngine:
     """Owns the reusable device buffers of the fused render (state, output, gradients) for one Renderer."""
     MIN_PAIRS = 65536      # floor of the binning capacity (pairs)
+    DIRECT_BINS = True     # size the binning state as tiles x (per-tile capacity) so that projection + binning are one launch
 
     def __init__(self, renderer):
         self.r = renderer
@@ -84,6 +85,14 @@ class FusedEngine:
             self.P = P
             self.grads = None
         want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + self.MIN_PAIRS
+        self.direct = False
+        if self.DIRECT_BINS and self.max_tile_len <= 1400 and P <= (1 << 19) - 4096:
+            # direct bins (MM3DGS_FWD_DIRECT_BINS): every tile owns n_cap / T pairs; sized from the longest list seen so far
+            T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+            want = max(want, T * (int(self.max_tile_len * 1.5) + 128))
+            # ... and every projection workgroup (256 Gaussians) 16 * n_cap / workgroups gradient records
+            want = max(want, ((P + 255) // 256) * (int(getattr(self, "max_group_records", 0) * 1.5) + 1024) // 16 + 1)
+            self.direct = True
         if want > self.n_cap or (self.ratio is not None and self.n_cap > 4 * want):
             u8 = dict(dtype=torch.uint8, device=self.dev)
             self.n_cap = int(want * 1.25) if self.ratio is not None else want
@@ -99,6 +108,10 @@ class FusedEngine:
             self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))
             self.stat_delta = (torch.zeros(P, device=self.dev), v(5, (P, 1)), v(6, (P, 1)))   # max radii | accum | denom
 
+    def _flags(self):
+        """STATE_CLEAN | SHORT_LISTS (hint from the last header check) | DIRECT_BINS (the capacity was sized per tile)."""
+        return 1 | (2 if self.max_tile_len <= 1400 else 0) | (4 if self.direct else 0)
+
     def inputs(self, pose, g):
         si = _lib.Mm3dgsSlamInputs()
         si.pose = pose.data_ptr()
@@ -111,7 +124,7 @@ class FusedEngine:
         P = int(g._xyz.shape[0])
         self._ensure(P, need_grads)
         si = self.inputs(pose, g)
-        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)      # STATE_CLEAN | SHORT_LISTS (hint from the last check)
+        flags = self._flags()
         _lib.check(self.lib.mm3dgs_slam_forward(C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                                 _p(self.img_state), _p(self.binning), self.n_cap, flags, _stream()))
         return si
@@ -121,7 +134,7 @@ class FusedEngine:
         P = int(g._xyz.shape[0])
         self._ensure(P, False)
         si = self.inputs(pose, g)
-        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)
+        flags = self._flags()
         _lib.check(self.lib.mm3dgs_slam_track(n_iter, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                               _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(gt_color),
                                               _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
@@ -147,7 +160,7 @@ class FusedEngine:
             if grads is not None:
                 sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
                 sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
-        flags = 1 | (2 if self.max_tile_len <= 1400 else 0)
+        flags = self._flags()
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
@@ -168,10 +181,12 @@ class FusedEngine:
         covers every iteration and every view of it.  Updates the capacity model from the LARGEST pair count seen, clears the
         sticky words, and returns False if any forward overflowed (its tile lists were clamped, so the loop's results are
         invalid: the caller restores its state and re-runs with the capacity this call has already raised)."""
-        h = self.img_state[:16].view(torch.int32).cpu()
+        h = self.img_state[:36].view(torch.int32).cpu()
         overflow, n_max = int(h[1]), int(h[3])
         self.max_tile_len = int(h[2])
+        self.max_group_records = max(getattr(self, "max_group_records", 0), int(h[8]))
         self.img_state[4:16].zero_()
+        self.img_state[32:36].zero_()
         self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
         self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
         return not overflow
@@ -190,7 +205,7 @@ class FusedEngine:
         _lib.check(self.lib.mm3dgs_slam_backward(C.byref(self.cam), self.P, C.byref(si), _p(self.radii), _p(self.geom), _p(self.img_state),
                                                  _p(self.binning), self.n_cap, _p(self.dL), _p(self.scratch), C.byref(sg), _p(dpose),
                                                  C.byref(pose_adam) if pose_adam is not None else None,
-                                                 C.byref(map_adam) if map_adam is not None else None, _stream()))
+                                                 C.byref(map_adam) if map_adam is not None else None, self._flags(), _stream()))
 
 
 def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr):

@@ -248,11 +248,12 @@ def test_fused_mapper_window_parallel_two_ranks(tmp_path):
 
 
 @pytest.mark.parametrize("long_lists", [False, True])
-def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists):
+def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists, monkeypatch):
     """MM3DGS_FWD_SHORT_LISTS selects the sort + forward-composite kernel; it must reproduce the separate launches bit for
     bit (same sort order, same lists, same records) -- also when a tile list exceeds its 2048-key LDS tier and takes the
-    global-memory path inside the fused kernel."""
+    global-memory path inside the fused kernel.  (Packed bins on both sides; the direct bins have their own test below.)"""
     from mm3dgs_slam_amd.fused import FusedEngine
+    monkeypatch.setattr(FusedEngine, "DIRECT_BINS", False)
     if long_lists:
         cfg, g, R, pose, color, depth = _setup(P=12000, H=48, W=64, seed=3)
         with torch.no_grad():
@@ -272,6 +273,41 @@ def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists):
     a, b = outs
     if long_lists:
         assert a[4] > 2048, a[4]       # the case really exercises the long-list path
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("huge", [False, True])
+def test_direct_bins_reproduce_the_packed_bins_bit_for_bit(huge, monkeypatch):
+    """MM3DGS_FWD_DIRECT_BINS (projection + binning in one launch, one fixed span of pairs per tile, block masks and record
+    indices produced per pair by the binning kernel) against the packed bins (projection, scatter with its own scan, masks
+    computed by the sort): same lists, same records, hence the same image, radii, pose gradient and Gaussian gradients bit for
+    bit -- also with splats that cover more than 32 tiles (the wave-cooperative path of the binning kernel)."""
+    from mm3dgs_slam_amd.fused import FusedEngine
+    cfg, g, R, pose, color, depth = _setup(P=8000, H=120, W=168, seed=3)
+    if huge:
+        with torch.no_grad():
+            g._scaling[::97] += 3.5          # ~80 splats of 100+ pixels
+    outs = []
+    for direct in (False, True):
+        monkeypatch.setattr(FusedEngine, "DIRECT_BINS", direct)
+        eng = FusedEngine(R)
+        eng.forward(pose, g, need_grads=True)
+        assert eng.check_capacity()
+        for rep in range(2):                  # twice: the persistent counters must be left clean
+            si = eng.forward(pose, g, need_grads=True)
+            assert eng.direct == direct, (eng.max_tile_len, eng.P, eng.n_cap)
+            eng.dL.copy_(torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)))
+            eng.backward(si, grads=eng.grads, dpose=eng.dpose)
+        torch.cuda.synchronize()
+        hdr = eng.img_state[:32].view(torch.int32).cpu()
+        assert int(hdr[1]) == 0
+        assert (int(hdr[7]) != 0) == direct
+        outs.append((eng.out.clone(), eng.radii.clone(), eng.dpose.clone(), {k: v.clone() for k, v in eng.grads.items()}, int(hdr[0]), int(hdr[2])))
+    a, b = outs
+    assert a[4] == b[4] and a[5] == b[5], (a[4:], b[4:])      # same N, same longest list
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(a[2], b[2])
     for k in a[3]:
@@ -482,23 +518,27 @@ def test_native_tracker_with_imu_prior_follows_the_torch_graph_tracker():
     assert (torch.cat([q.detach(), T.detach()]) - pb).abs().max() > 1e-4
 
 
-def test_binning_overflow_is_sticky_and_the_loops_recover():
+@pytest.mark.parametrize("direct", [False, True])
+def test_binning_overflow_is_sticky_and_the_loops_recover(direct, monkeypatch):
     """A capacity far too small for the scene: the header's overflow flag must survive later (non-overflowing) forwards until
-    the host reads it, and FusedTracker / FusedMapper must end where a run with ample capacity ends (restore + re-run)."""
+    the host reads it, and FusedTracker / FusedMapper must end where a run with ample capacity ends (restore + re-run).
+    Packed bins run out of total capacity, direct bins (one fixed span per tile) out of per-tile capacity."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.fused import FusedEngine, _engine
     from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    monkeypatch.setattr(FusedEngine, "DIRECT_BINS", direct)
     cfg, g, R, pose, color, depth = _setup(P=12000, H=120, W=160, seed=9)
     eng = FusedEngine(R)
     eng.forward(pose, g, need_grads=True)
     assert eng.check_capacity()
     n_true = int(eng.ratio * eng.P + 0.5)
     true_ratio = eng.ratio
-    # a capacity model that claims ~0 pairs per Gaussian -> tiny binning buffer -> overflow (flagged); then a view that fits:
-    # the flag, the maximum N and the maximum list length must still be there
+    # a capacity model that claims ~0 pairs per Gaussian (and one-entry tile lists) -> tiny binning buffer -> overflow (flagged);
+    # then a view that fits: the flag, the maximum N and the maximum list length must still be there
     eng.MIN_PAIRS = 64
-    eng.ratio, eng.n_cap = 0.01, 0
+    eng.ratio, eng.n_cap, eng.max_tile_len = 0.01, 0, 1
     eng.forward(pose, g, need_grads=True)
+    assert eng.direct == direct
     assert eng.n_cap < n_true
     far = pose.clone(); far[6] -= 1000.0                    # the whole map behind the camera: nothing rendered, no overflow
     eng.forward(far, g, need_grads=True)
@@ -521,6 +561,7 @@ def test_binning_overflow_is_sticky_and_the_loops_recover():
             e.MIN_PAIRS = 64
             e.ratio = 0.02                                   # capacity model claims ~0 pairs per Gaussian -> tiny buffers
             e.n_cap = 0
+            e.max_tile_len = 1
         random.seed(5)
         slam.step(1); slam.step(2)
         results.append((torch.stack(slam.estimate_pose_list[:3]).cpu(), slam.gaussians._xyz.detach().cpu(), getattr(e, "overflows", 0)))
