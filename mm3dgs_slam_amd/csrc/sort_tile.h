@@ -129,6 +129,8 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     __syncthreads();
     for (int i = tid; i < len; i += 256) {
       const unsigned long long mine = sk2[i];
+      // direct bins: the entry's payload is requested now and lands while the rank is being computed
+      const unsigned long long pl = direct ? b.payload[start + ((uint32_t)mine & DIRECT_MAX_CAP)] : 0ull;
       const int own = i >> 6;
       int rank = i & 63;
       for (int r0 = 0; r0 < nruns; r0 += 4) {
@@ -148,6 +150,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
         }
       }
       sk[rank] = mine;
+      if (direct) sk[2 * RANK_SORT_MAX + rank] = pl;     // (fused kernel: 24 KB of LDS = keys | runs | payloads)
     }
     __syncthreads();
   } else if (in_lds) {
@@ -159,6 +162,40 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
   }
   if (ex & 4) return true;   // MM3DGS_EXP probe: no emission (timing only)
+  if (direct && in_lds && len <= RANK_SORT_MAX && !(ex & 8)) {
+    // ---- direct bins: every wave builds the four lists of ITS OWN 8x8 sub-tile (the ones it composites) from the sorted ids
+    // and payloads in LDS: ballots and running counts inside the wave, no barriers, no cross-wave prefix
+    if (tid == 0) iv.cursor[tile] = 0;       // (every wave has read the count: the barrier after the rank merge is behind us)
+    const unsigned long long* spl = sk + 2 * RANK_SORT_MAX;
+    uint2* sub = b.sublist + (size_t)NLIST * start;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+    for (int base = 0; base < len; base += 64) {
+      const int i = base + lane;
+      const bool have = i < len;
+      const unsigned long long pl = have ? spl[i] : 0ull;
+      const uint32_t id = have ? ((uint32_t)sk[i] >> DIRECT_SLOT_BITS) : 0u;
+      const uint32_t m4 = ((uint32_t)pl >> (4 * wv)) & 0xfu;
+      const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
+#pragma unroll
+      for (int bq = 0; bq < 4; bq++) {
+        const int L = 4 * wv + bq;
+        const bool on = (m4 >> bq) & 1u;
+        const unsigned long long bal = __ballot(on);
+        if (on) {
+          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
+          sub[(size_t)L * len + cnt[bq] + __popcll(bal & lt)] = make_uint2(id, rec);
+        }
+        cnt[bq] += (uint32_t)__popcll(bal);
+      }
+    }
+    if (lane < 4) {
+      const uint32_t c = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
+      iv.subcount[NLIST * tile + 4 * wv + lane] = c;
+      run[4 * wv + lane] = c;
+    }
+    return true;
+  }
   // ---- emit the 16 block lists (order preserving) ----
   const int ttx = tile % gx, tty = tile / gx;
   if (tid < NLIST) run[tid] = 0;
