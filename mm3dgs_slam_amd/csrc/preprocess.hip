@@ -12,6 +12,27 @@
 #include "mm3dgs_math.h"
 #include "gather_records.h"
 
+// SH rows as float4s: a lane's [M,3] coefficient row is 12 M contiguous bytes (192 B at degree 3), so with scalar accesses
+// every one of its 3 M load (store) instructions touches 64 different cache lines for 4 useful bytes each.  With M in {4, 16}
+// and a 16-byte aligned base the row is read / written as 3 M / 4 float4s per lane: a quarter of the line visits.
+// (MV = M for this path, 0 = the scalar path for every other M or an unaligned base.)
+template <int MV>
+__device__ __forceinline__ void sh_row_load(const float* __restrict__ row, float (&v)[MV * 3]) {
+  const float4* r = (const float4*)row;
+#pragma unroll
+  for (int j = 0; j < MV * 3 / 4; j++) {
+    const float4 q = r[j];
+    v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+  }
+}
+template <int MV>
+__device__ __forceinline__ void sh_row_store(float* __restrict__ row, const float (&v)[MV * 3]) {
+  float4* r = (float4*)row;
+#pragma unroll
+  for (int j = 0; j < MV * 3 / 4; j++) r[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+template <int MV>
 __global__ void __launch_bounds__(PP_BLOCK)
 preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
                       const float* __restrict__ shs, const float* __restrict__ colors,
@@ -71,7 +92,15 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           int nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
           const float* sh = shs + (size_t)idx * M * 3;
           float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-          for (int k = 0; k < nb; k++) { c0 += b[k] * sh[k * 3]; c1 += b[k] * sh[k * 3 + 1]; c2 += b[k] * sh[k * 3 + 2]; }
+          if (MV) {
+            float sv[(MV ? MV : 4) * 3];
+            sh_row_load<(MV ? MV : 4)>(sh, sv);
+#pragma unroll
+            for (int k = 0; k < MV; k++)
+              if (k < nb) { c0 += b[k] * sv[k * 3]; c1 += b[k] * sv[k * 3 + 1]; c2 += b[k] * sv[k * 3 + 2]; }
+          } else {
+            for (int k = 0; k < nb; k++) { c0 += b[k] * sh[k * 3]; c1 += b[k] * sh[k * 3 + 1]; c2 += b[k] * sh[k * 3 + 2]; }
+          }
           c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
           uint8_t cl = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
           g.clamped[idx] = cl;
@@ -147,7 +176,9 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
   const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), (size_t)lds_tiles * 4, s, cam,
+  const bool vec = shs && (((uintptr_t)shs & 15) == 0);
+  auto kern = (vec && M == 16) ? preprocess_fwd_kernel<16> : ((vec && M == 4) ? preprocess_fwd_kernel<4> : preprocess_fwd_kernel<0>);
+  hipLaunchKernelGGL(kern, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), (size_t)lds_tiles * 4, s, cam,
                      P, M, C, means3D, shs, colors, opac, scales, rots, cov3d, radii, g, iv, lds_tiles);
 }
 
@@ -157,6 +188,7 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
 // are reduced wave -> workgroup in registers/LDS, one partial row per workgroup is written, and a single-wave
 // finishing kernel adds the rows in double precision in a fixed order (deterministic, no atomics).
 #define NCAM 27
+template <int MV>
 __global__ void __launch_bounds__(PP_BLOCK)
 preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
                       const float* __restrict__ shs, const float* __restrict__ colors,
@@ -305,8 +337,18 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           float bb[16];
           sh_basis(deg, ux, uy, uz, bb);
           float* o = dshs + (size_t)idx * M * 3;
-          for (int k = 0; k < nb; k++) { o[k * 3] = bb[k] * gc0; o[k * 3 + 1] = bb[k] * gc1; o[k * 3 + 2] = bb[k] * gc2; }
-          for (int k = nb; k < M; k++) { o[k * 3] = 0.f; o[k * 3 + 1] = 0.f; o[k * 3 + 2] = 0.f; }
+          if (MV) {
+            float ov[(MV ? MV : 4) * 3];
+#pragma unroll
+            for (int k = 0; k < (MV ? MV : 4); k++) {
+              const float bk = k < nb ? bb[k] : 0.f;
+              ov[k * 3] = bk * gc0; ov[k * 3 + 1] = bk * gc1; ov[k * 3 + 2] = bk * gc2;
+            }
+            sh_row_store<(MV ? MV : 4)>(o, ov);
+          } else {
+            for (int k = 0; k < nb; k++) { o[k * 3] = bb[k] * gc0; o[k * 3 + 1] = bb[k] * gc1; o[k * 3 + 2] = bb[k] * gc2; }
+            for (int k = nb; k < M; k++) { o[k * 3] = 0.f; o[k * 3 + 1] = 0.f; o[k * 3 + 2] = 0.f; }
+          }
         }
         if (deg > 0) {
           float bx[16], by[16], bz[16];
@@ -315,9 +357,20 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           // in double: the tangential projection below is a small difference of large terms, and its sum over the map is the
           // camera-position gradient (held to 1e-5; the float version sat at 1.2e-5 on the degree-2 case)
           double ddx = 0.0, ddy = 0.0, ddz = 0.0;
-          for (int k = 1; k < nb; k++) {
-            const double w = (double)sh[k * 3] * gc0 + (double)sh[k * 3 + 1] * gc1 + (double)sh[k * 3 + 2] * gc2;
-            ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+          if (MV) {
+            float sv[(MV ? MV : 4) * 3];
+            sh_row_load<(MV ? MV : 4)>(sh, sv);
+#pragma unroll
+            for (int k = 1; k < (MV ? MV : 4); k++)
+              if (k < nb) {
+                const double w = (double)sv[k * 3] * gc0 + (double)sv[k * 3 + 1] * gc1 + (double)sv[k * 3 + 2] * gc2;
+                ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+              }
+          } else {
+            for (int k = 1; k < nb; k++) {
+              const double w = (double)sh[k * 3] * gc0 + (double)sh[k * 3 + 1] * gc1 + (double)sh[k * 3 + 2] * gc2;
+              ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
+            }
           }
           const double dot = ux * ddx + uy * ddy + uz * ddz;
           float mx = (float)((ddx - ux * dot) * inv), my = (float)((ddy - uy * dot) * inv), mz = (float)((ddz - uz * dot) * inv);
@@ -357,7 +410,12 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       }
     } else if (!skip_g && shs && dshs) {
       float* o = dshs + (size_t)idx * M * 3;
-      for (int k = 0; k < M * 3; k++) o[k] = 0.f;
+      if (MV) {
+#pragma unroll
+        for (int j = 0; j < (MV ? MV : 4) * 3 / 4; j++) ((float4*)o)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        for (int k = 0; k < M * 3; k++) o[k] = 0.f;
+      }
     }
     // every Gaussian writes its slots (culled ones write zeros): no memset of the outputs is needed
     if (dmeans3D) { dmeans3D[(size_t)idx * 3] = dmean[0]; dmeans3D[(size_t)idx * 3 + 1] = dmean[1]; dmeans3D[(size_t)idx * 3 + 2] = dmean[2]; }
@@ -428,7 +486,9 @@ void launch_preprocess_bwd(const CamDev& cam, int P, int M, int C, const float* 
                            float* dmeans3D, float* dmeans2D, float* dshs, float* dcolors, float* dopac, float* dscales,
                            float* drots, float* dcov3d, bool want_cam, int flags, hipStream_t s) {
   if (P <= 0) return;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
+  const bool vec = shs && (((uintptr_t)shs & 15) == 0) && (!dshs || ((uintptr_t)dshs & 15) == 0);
+  auto kern = (vec && M == 16) ? preprocess_bwd_kernel<16> : ((vec && M == 4) ? preprocess_bwd_kernel<4> : preprocess_bwd_kernel<0>);
+  hipLaunchKernelGGL(kern, dim3((P + PP_BLOCK - 1) / PP_BLOCK), dim3(PP_BLOCK), 0, s, cam, P, M, C,
                      means3D, shs, colors, opac, scales, rots, cov3d, radii, g, b,
                      (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap), bw.dsub, bw.campartial, dmeans3D,
                      dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3d, want_cam ? 1 : 0, flags);
