@@ -51,8 +51,8 @@ def test_sh_colour(deg, seed, strict):
 @pytest.mark.parametrize("seed,strict", [(44, True), (45, True), (42, False)])
 def test_six_channels_posed_camera(seed, strict):
     """The family __graft_entry__.smoke() draws from (SH degree 0 + 3 extra channels, posed camera, all camera gradients).  Seed 42 is a
-    decision-flip scene in float32 (image error 9e-7 against 2.4e-7 for its neighbours; the oracle's own float32 run is clean on it,
-    the kernel's fast exp takes one alpha >= 1/255 decision the other way): dL/dproj 2.4e-5, kept at the flip tolerance."""
+    decision-flip scene in float32 (image error 9e-7 against 2.4e-7 for its neighbours; the oracle's own float32 run is clean on it, so it
+    is the kernel's float32 evaluation order that takes one skip / stop decision the other way): dL/dproj 2.4e-5, kept at the flip tolerance."""
     _check(pu.compare(pu.make_case(P=4000, H=120, W=160, seed=seed, sh_degree=0, extras=3, posed=True), verbose=True),
            pose_tol=pu.POSE_TOL if strict else FLIP_TOL)
 
