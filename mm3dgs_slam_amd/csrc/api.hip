@@ -221,7 +221,7 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
 
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                              void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
-                             const TrackLoss* tl) {
+                             const TrackLoss* tl, float* track_dsub = nullptr) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -242,14 +242,17 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
   if (db.on) {
     { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, s); }
-    { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s); launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks); }
+    { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
+      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub);
+      else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks); }
     return check_launch("slam_forward");
   }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
   { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
-    if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
+    if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, *tl, 0, track_dsub);
+    else if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
     else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");
 }
@@ -275,7 +278,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
                               const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, int flags, void* stream, const TrackLoss* tl,
-                              float* prior_loss4 = nullptr, int dl_planes = 6) {
+                              float* prior_loss4 = nullptr, int dl_planes = 6, bool compositor_done = false) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
@@ -328,6 +331,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   // (58 % active; 61 us against 49 us at SLAM size, and no better at 1200x680 -- profiles/r02_bwd2_experiment.md).  Kept as a
   // checked alternative (tests/test_gpu_fused.py compares it with the first-generation kernel).
   const int bwd2 = bwd2_requested();   // read per call: tests compare both in one process
+  if (!compositor_done)
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, bwd2);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
@@ -394,8 +398,14 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
     tl.defer_scale = loss_cfg->w_pearson == 0.f ? 1 : 0;   // masked L1 only: no loss-finish launch, 1/n goes to the pose gradient
     if (loss_cfg->H != cam->image_height || loss_cfg->W != cam->image_width) return fail(-1, "loss and camera image sizes differ");
   }
+  // masked L1 alone (normalisation deferred to the pose gradient): the backward compositor runs in the forward launch
+  const bool fuse_track = fold && tl.defer_scale && !bwd2_requested() && !env_flag("MM3DGS_NO_FUSED_TRACK", 0) && backward_scratch;
+  float* track_dsub = nullptr;
+  if (fuse_track) {
+    track_dsub = bwd_view(backward_scratch, P, N_capacity).dsub;
+  }
   for (int it = 0; it < n_iter; it++) {
-    int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr);
+    int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr, track_dsub);
     if (rc) return rc;
     if (fold) {
       if (!tl.defer_scale) {
@@ -407,7 +417,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
       if (rc) return rc;
     }
     rc = slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                            nullptr, pose_adam, nullptr, fwd_flags, stream, fold ? &tl : nullptr, loss4);
+                            nullptr, pose_adam, nullptr, fwd_flags, stream, fold ? &tl : nullptr, loss4, 6, fuse_track);
     if (rc) return rc;
   }
   return 0;

@@ -334,13 +334,12 @@ struct SepReduce {
 // MODE 1: SLAM mapping (C = 6, colours = rgb | z 1 z^2): [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy] with cz = sum w (dL_3 + 2 z dL_5)
 //         -- the chain rule of the depth bundle folded into the reduction -- and dopacity = M0 / opacity (10 floats, not 12).
 // MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
+// (a device function: the tracking loop runs it in the same launch as the sort and the forward compositor, see below)
+#define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * 64 + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
 template <int C, int MODE>
-__global__ void __launch_bounds__(256)
-composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
-                     float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
-  const int T = cam.gx * cam.gy;
-  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
-  if (tile >= T) return;
+__device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
+                                                   uint32_t N_cap, const float* __restrict__ dL_dout, float* __restrict__ dsub, int has_tl,
+                                                   const TrackLoss& tl, int dl_planes, unsigned char* smem_raw, const SortShared* span = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
@@ -349,21 +348,22 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const bool inside = px < cam.W && py < cam.H;
   const float pxf = (float)px, pyf = (float)py;
   uint32_t start, len;
-  tile_span(iv, tile, N_cap, start, len);
+  if (span) { start = span->start; len = span->len; }
+  else tile_span(iv, tile, N_cap, start, len);
   const int L = 4 * wv + row;
-  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
+  const uint32_t count = len ? min(span ? span->run[L] : iv.subcount[NLIST * tile + L], len) : 0u;   // this row's list length
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int NF4 = (NV + 3) / 4;
   constexpr int RECF = MODE == 0 ? SPLAT_F : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats (SLAM modes: packed, composite_common.h)
-  // [buffer][wave][field A|B|C|pair index][row * 16 + entry]: lane-contiguous (conflict-free) writes, and ONE address
-  // register per splat for the row-uniform reads (fields are a constant 1 KB apart -> immediate offsets)
-  // (the staging buffers share their 32 KB with the scratch of the folded mapping-loss gradient pass, which runs first)
-  __shared__ __align__(16) unsigned char smem_raw[sizeof(float4) * 2 * 4 * 4 * 64];
-  static_assert(sizeof(smem_raw) >= sizeof(LossGradSmem) + 4 * 256 * sizeof(float), "LDS union too small for the loss pass");
-  float4 (*stg)[4][4][64] = (float4 (*)[4][4][64])smem_raw;
+  // [buffer][wave][field A|B|C][row * 16 + entry] + [buffer][wave][row * 16 + entry] record indices: lane-contiguous
+  // (conflict-free) writes, and ONE address register per splat for the row-uniform reads (fields are a constant 1 KB apart ->
+  // immediate offsets).  (The caller's LDS block is shared with the scratch of the folded mapping-loss gradient pass, which
+  // runs first, and -- in the fused tracking kernel -- with the sort keys and the forward compositor's staging buffers.)
+  float4 (*stg)[4][3][64] = (float4 (*)[4][3][64])smem_raw;
+  uint32_t (*stgi)[4][64] = (uint32_t (*)[4][64])(smem_raw + sizeof(float4) * 2 * 4 * 3 * 64);
   constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -448,7 +448,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     stg[0][wv][0][lane] = r0.A;
     stg[0][wv][1][lane] = r0.B;
     if (C > 2) stg[0][wv][2][lane] = r0.C;
-    ((uint32_t*)&stg[0][wv][3][lane])[0] = e0.y;
+    stgi[0][wv][lane] = e0.y;
   }
   uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
@@ -463,7 +463,8 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
     const float4 (*wS)[64] = stg[cur][wv];
     const int r16 = row * 16;
-    auto pair_of = [&](int j) { return ((const uint32_t*)&wS[3][r16 + j])[0]; };
+    const uint32_t* wI = stgi[cur][wv];
+    auto pair_of = [&](int j) { return wI[r16 + j]; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti, const int j) {
@@ -543,7 +544,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     stg[cur ^ 1][wv][0][lane] = rec_n.A;
     stg[cur ^ 1][wv][1][lane] = rec_n.B;
     if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
-    ((uint32_t*)&stg[cur ^ 1][wv][3][lane])[0] = ent_nxt.y;
+    stgi[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   };
@@ -553,6 +554,39 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
     atomicAdd(&iv.hdr->bwd_wave_visits, n_visit);
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);
   }
+}
+
+template <int C, int MODE>
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
+                     float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
+  constexpr size_t LOSS_BYTES = MODE == 1 ? sizeof(LossGradSmem) + 4 * 256 * sizeof(float) : 0;
+  __shared__ __align__(16) unsigned char smem_raw[BWD_STG_BYTES > LOSS_BYTES ? BWD_STG_BYTES : LOSS_BYTES];
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  composite_bwd_body<C, MODE>(tile, cam, g, iv, b, N_cap, dL_dout, dsub, has_tl, tl, dl_planes, smem_raw);
+}
+
+// A tracking iteration with the masked-L1 loss alone (its 1/n is applied to the pose gradient afterwards, so the per-pixel loss
+// gradient needs nothing from other tiles): sort, forward compositing and backward compositing of a tile in ONE launch.  The
+// backward pass picks its pixel's final transmittance, contributor count and colours up from memory the same lane wrote a
+// moment ago; one launch, its ramp and the backward prologue's cold misses less per iteration.
+__global__ void __launch_bounds__(256)
+sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean,
+                                    TrackLoss tl, int direct_blocks, float* __restrict__ dsub) {
+  __shared__ __align__(16) unsigned char smem[BWD_STG_BYTES];     // >= forward staging (24 KB) >= sort keys (+ payloads)
+  __shared__ SortShared sh;
+  __shared__ double red[4][12];
+  static_assert(BWD_STG_BYTES >= sizeof(float4) * 2 * 4 * 3 * 64, "LDS union too small for the forward staging buffers");
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks);
+  __syncthreads();
+  composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, &tl, red, &sh);
+  __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free
+  composite_bwd_body<6, 2>(tile, cam, g, iv, b, N_cap, nullptr, dsub, 1, tl, 6, smem, &sh);
 }
 
 template <int C>
@@ -588,6 +622,14 @@ void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, Bin
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
   hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks);
+}
+
+void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
+                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub) {
+  uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  int T = cam.gx * cam.gy;
+  int grid = ((T + 7) / 8) * 8;
+  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,
