@@ -412,15 +412,20 @@ def main():
     bwd_comp = N * (28 + 4 * C) + H * W * (4 * C + 8) + N * (24 + 4 * C)            # 8d "Backward": composite re-read + per-pixel + gradient scatter
     loss_grad_pass = H * W * 4 * (9 + 3 + 3 + 3)                                    # folded mapping-loss gradient pass: 9 SSIM maps, rgb, gt, depth / silhouette / reference
     fwd_sort_comp = 24 * N * r_passes + 8 * N + (8 * N + 8 * T_tiles) + N * (28 + 4 * C) + H * W * (4 * C + 8)   # 8d "Forward": sort + ranges + composite read + image write
+    fused_track = bool(prof.get("track_fwd_bwd", (0, 0.0))[0])      # the tracking iterations ran sort + forward + backward compositing as one launch
     kernels = {
         "composite_bwd": ("composite_bwd_kernel<6,1> (mapping; the mapping loss's gradient-image pass runs in its prologue)", bwd_comp + loss_grad_pass,
                           "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite] + 18 HW 4 [folded loss gradient pass: 9 SSIM maps + rgb + gt + depth/sil/ref]",
                           args.map_iters * vps),
         "composite_bwd_track": ("composite_bwd_kernel<6,2> (tracking; masked-L1 loss folded in)", bwd_comp, "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite]",
                                 args.track_iters),
+        "track_fwd_bwd": ("sort_composite_fwd_bwd_track_kernel (tracking: per-tile sort + block lists + forward + backward compositing in one launch; masked-L1 loss folded in)",
+                          fwd_sort_comp + bwd_comp,
+                          "24 N r + 8N + 8N + 8T + N(28+4C) + HW(4C+8) [SURVEY 8d forward] + N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite], r = %d" % r_passes,
+                          args.track_iters),
         "composite_fwd": ("sort_composite_fwd_kernel<6> (per-tile sort + block lists + forward compositing in one launch)", fwd_sort_comp,
                           "24 N r + 8N [sort, r = %d radix passes of the contract] + 8N + 8T [ranges] + N(28+4C) + HW(4C+8) [composite] (SURVEY 8d forward)" % r_passes,
-                          args.track_iters + args.map_iters * vps),
+                          args.map_iters * vps + (0 if fused_track else args.track_iters)),
     }
     recs = []
     for key, (label, alg_bytes, formula, per_frame) in kernels.items():
@@ -435,7 +440,7 @@ def main():
     if recs:
         recs.sort(key=lambda r_: -r_["ms_per_frame"])
         pmc_names = {"composite_bwd_kernel<6,1>": ("composite_bwd_kernel", "<6, 1>"), "composite_bwd_kernel<6,2>": ("composite_bwd_kernel", "<6, 2>"),
-                     "sort_composite_fwd_kernel<6>": ("sort_composite_fwd_kernel",)}
+                     "sort_composite_fwd_kernel<6>": ("sort_composite_fwd_kernel",), "sort_composite_fwd_bwd_track_kernel": ("sort_composite_fwd_bwd_track_kernel",)}
         for r_ in recs:
             for pre, match in pmc_names.items():
                 if r_["kernel"].startswith(pre):

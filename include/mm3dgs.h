@@ -279,7 +279,8 @@ int mm3dgs_seed_gaussians(int H, int W, const float* color /*[3,H,W]*/, const fl
 #define MM3DGS_PROF_LOSS 6
 #define MM3DGS_PROF_ADAM 7
 #define MM3DGS_PROF_COMPOSITE_BWD_TRACK 8 /* the tracking-mode backward compositor of the fused SLAM path (COMPOSITE_BWD: every other form) */
-#define MM3DGS_PROF_KERNELS 9
+#define MM3DGS_PROF_TRACK_FWD_BWD 9 /* sort + forward + backward compositing of a tracking iteration in one launch */
+#define MM3DGS_PROF_KERNELS 10
 void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 16th launch of the forward (sort +) compositor and of the backward compositors only */
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 

@@ -131,7 +131,7 @@ def load():
     return lib
 
 
-PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam", "composite_bwd_track")
+PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composite_bwd", "preprocess_bwd", "loss", "adam", "composite_bwd_track", "track_fwd_bwd")
 
 
 def profile_enable(mode):

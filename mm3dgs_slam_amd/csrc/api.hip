@@ -38,7 +38,7 @@ struct ProfScope {
   // g_prof_on: 0 off, 1 every kernel, 2 only the compositors (the roofline kernels) and only every 16th launch of
   // it: an event pair around EVERY launch costs ~4 % of the SLAM frame rate (measured), a 1-in-16 sample nothing
   ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && (k_ == MM3DGS_PROF_COMPOSITE_BWD || k_ == MM3DGS_PROF_COMPOSITE_BWD_TRACK ||
-                                                                                     k_ == MM3DGS_PROF_COMPOSITE_FWD))) {
+                                                                                     k_ == MM3DGS_PROF_COMPOSITE_FWD || k_ == MM3DGS_PROF_TRACK_FWD_BWD))) {
     if (on && g_prof_on == 2) {
       static unsigned long long sample[MM3DGS_PROF_KERNELS] = {};
       on = (sample[k_]++ & 15ull) == 0ull;
@@ -242,7 +242,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
   if (db.on) {
     { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, s); }
-    { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
+    { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
       if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub);
       else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks); }
     return check_launch("slam_forward");
@@ -250,7 +250,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
-  { ProfScope ps(MM3DGS_PROF_COMPOSITE_FWD, s);
+  { ProfScope ps((fused_sort && track_dsub) ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
     if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, *tl, 0, track_dsub);
     else if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
     else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
