@@ -280,7 +280,7 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
       if (tot > iv.hdr->max_group_records) atomicMax(&iv.hdr->max_group_records, tot);   // (rare: the maximum is sticky)
     }
   }
-  // sweep 1: count (a rectangle of more than 32 tiles is spread over the wave)
+  // sweep 1: count (cheap per pair; a rectangle of more than 32 tiles is spread over the wave)
   unsigned long long big = __ballot(c.area > 32);
   if (c.area > 0 && c.area <= 32)
     for (int k = 0; k < c.area; k++) atomicAdd(&hist[(c.miny + k / c.w) * cam.gx + c.minx + k % c.w], 1u);
@@ -296,26 +296,41 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
     if (n) hist[t] = atomicAdd(&iv.cursor[t], n);
   }
   __syncthreads();
-  // sweep 2: slots, keys, payloads
-  // the block masks of a splat of up to four tiles (nearly all of a SLAM map) also go, as one 64-bit word, where the backward
-  // projection finds them by Gaussian index (the submask region of the binning state, read as u64[P]; pair k = bits 16k..16k+15)
+  // sweep 2: slots, keys, payloads (~200 instructions per pair).  Every lane emits the first four pairs of its own splat --
+  // all the pairs of nearly every splat of a SLAM map; their block masks also go, as one 64-bit word, where the backward
+  // projection finds them by Gaussian index (the submask region of the binning state, read as u64[P]; pair k = bits
+  // 16k..16k+15).  The pairs beyond the fourth form the wave's flat work list, cut into equal shares: the few 20-90 pixel
+  // splats that grow in a map would otherwise keep one lane busy for dozens of iterations while its wave waits (this kernel
+  // went from 19 to 44 us over 100 frames of a run before).
+  constexpr int OWN = 4;
   unsigned long long m64 = 0ull;
-  if (c.area > 0 && c.area <= 32)
-    for (int k = 0; k < c.area; k++) {
-      const uint32_t mk = emit_pair(c, k, hist, cam.gx, cap, b);
-      if (k < 4) m64 |= (unsigned long long)mk << (16 * k);
+  for (int k = 0; k < min(c.area, OWN); k++) m64 |= (unsigned long long)emit_pair(c, k, hist, cam.gx, cap, b) << (16 * k);
+  if (live) ((unsigned long long*)b.submask)[idx] = c.area <= OWN ? m64 : 0ull;
+  uint32_t incl = (uint32_t)max(c.area - OWN, 0);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += y;
+  }
+  const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (S) {   // wave-uniform
+    __shared__ uint32_t s_pref[FB / 64][64];
+    __shared__ PairCtx s_ctx[FB / 64][64];
+    s_pref[wvi][lane] = incl;
+    s_ctx[wvi][lane] = c;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = (uint32_t)lane; i < S; i += 64u) {
+      int lo = 0, hi = 63;     // owner: smallest o with pref[o] > i
+#pragma unroll
+      for (int st = 0; st < 6; st++) {
+        const int mid = (lo + hi) >> 1;
+        if (s_pref[wvi][mid] > i) hi = mid; else lo = mid + 1;
+      }
+      const int o = min(lo, 63);
+      const uint32_t excl = o ? s_pref[wvi][o - 1] : 0u;
+      const PairCtx oc = s_ctx[wvi][o];
+      emit_pair(oc, OWN + (int)(i - excl), hist, cam.gx, cap, b);
     }
-  if (live) ((unsigned long long*)b.submask)[idx] = c.area <= 4 ? m64 : 0ull;
-  for (unsigned long long bb = big; bb; bb &= bb - 1) {
-    const int src = __ffsll((long long)bb) - 1;
-    PairCtx s;
-    auto rl = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
-    auto rf = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); };
-    s.mc.cx = rf(c.mc.cx); s.mc.cy = rf(c.mc.cy); s.mc.hx = rf(c.mc.hx); s.mc.hy = rf(c.mc.hy); s.mc.r2 = rf(c.mc.r2); s.mc.mode = rl(c.mc.mode);
-    s.br.bx0 = rl(c.br.bx0); s.br.by0 = rl(c.br.by0); s.br.bw = rl(c.br.bw); s.br.bh = rl(c.br.bh);
-    s.rec0 = (uint32_t)rl((int)c.rec0); s.khi = (uint32_t)rl((int)c.khi); s.idbits = (uint32_t)rl((int)c.idbits);
-    s.minx = rl(c.minx); s.miny = rl(c.miny); s.w = rl(c.w); s.area = rl(c.area);
-    for (int k = lane; k < s.area; k += 64) emit_pair(s, k, hist, cam.gx, cap, b);
   }
 }
 
