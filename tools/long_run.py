@@ -31,3 +31,4 @@ for i in range(1, n):
         print(f"frames {i-9:3d}-{i:3d}: {(t1 - t0) * 100:.1f} ms/frame  P={slam.gaussians.get_xyz.shape[0]}  keyframes={len(slam.mapper.keyframes)}  "
               f"n_cap={eng.n_cap} ratio={eng.ratio:.2f} max_tile_len={eng.max_tile_len} direct={eng.direct} overflows={getattr(eng, 'overflows', 0)}", flush=True)
         t0 = time.perf_counter()
+
