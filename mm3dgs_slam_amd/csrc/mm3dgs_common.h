@@ -184,7 +184,7 @@ struct CamDev {
   int H, W, gx, gy;
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int sh_degree;
-  int tilemap;  // 0: tile = workgroup id; 1: contiguous tile span per XCD
+  int tilemap;  // 0: tile = workgroup id; 1 (default): contiguous tile span per XCD
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
   int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
@@ -207,7 +207,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.focal_y = d.H / (2.0f * c->tanfovy);
   d.scale_modifier = c->scale_modifier;
   d.sh_degree = c->sh_degree;
-  d.tilemap = env_flag("MM3DGS_TILEMAP", 0);
+  d.tilemap = env_flag("MM3DGS_TILEMAP", 1);   // contiguous tile span per XCD: the backward compositor measured 4 % faster (splat records and lists stay in one L2)
   d.stats = env_flag("MM3DGS_STATS", 0);
   d.exp = env_flag("MM3DGS_EXP", 0);
   d.sort_single = 0;
