@@ -561,7 +561,11 @@ __global__ void __launch_bounds__(256)
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
                      float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
   constexpr size_t LOSS_BYTES = MODE == 1 ? sizeof(LossGradSmem) + 4 * 256 * sizeof(float) : 0;
-  __shared__ __align__(16) unsigned char smem_raw[BWD_STG_BYTES > LOSS_BYTES ? BWD_STG_BYTES : LOSS_BYTES];
+  // (generic mode: 32 KB on purpose -- five workgroups per CU; with the 26 KB the staging buffers need, six fit and the 1080p /
+  //  3 M-Gaussian pass ran 14 % slower: every workgroup gathers ~1000 splat records by id, and six of them overflow the L1)
+  constexpr size_t MIN_BYTES = MODE == 0 ? 32768 : 0;
+  constexpr size_t NEED = BWD_STG_BYTES > LOSS_BYTES ? BWD_STG_BYTES : LOSS_BYTES;
+  __shared__ __align__(16) unsigned char smem_raw[NEED > MIN_BYTES ? NEED : MIN_BYTES];
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
@@ -593,7 +597,8 @@ template <int C>
 static void launch_fwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b, uint32_t ncap, float* out, hipStream_t s) {
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL((composite_fwd_kernel<C>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out);
+  static const int pad = env_flag("MM3DGS_FWD_LDS_PAD", 0);
+  hipLaunchKernelGGL((composite_fwd_kernel<C>), dim3(grid), dim3(256), (size_t)pad, s, cam, g, iv, b, ncap, out);
 }
 template <int C>
 static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b, uint32_t ncap, const float* dL, float* dsub,
@@ -601,7 +606,9 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
-  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none, C);
+  // (dynamic LDS is never touched: it only limits how many workgroups share a CU, see composite_bwd_kernel)
+  static const int pad = env_flag("MM3DGS_BWD_LDS_PAD", 0);
+  hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), (size_t)pad, s, cam, g, iv, b, ncap, dL, dsub, 0, none, C);
 }
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
