@@ -285,7 +285,7 @@ void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 16th lau
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 
 const char* mm3dgs_last_error(void);
-int mm3dgs_version(void);
+int mm3dgs_version(void);   /* 100: round 1; 200: this header */
 
 #ifdef __cplusplus
 }
