@@ -25,6 +25,12 @@
 #include "loss_pixel.h"
 #include "loss_tile.h"
 
+// Staging of splat records for the row-uniform LDS reads: a 16-lane row keeps its 16 entries at [row * STG_ROW, +16).  The odd
+// row stride puts the four rows of a wave -- which read four DIFFERENT addresses in one ds_read_b128 -- on different banks
+// (with a stride of 16 float4s = 256 B all four hit the same four banks: SQ_LDS_BANK_CONFLICT was 35-47 % of the LDS cycles).
+#define STG_ROW 17
+#define STG_N (4 * STG_ROW)
+
 #include "composite_common.h"
 
 // Forward compositing of one tile by a 256-lane workgroup.  stg: [buffer][wave][field A|B|C][row * 16 + entry] staging
@@ -32,12 +38,13 @@
 // nullptr (read from image_state).
 template <int C>
 __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
-                                                   uint32_t N_cap, float* __restrict__ out, float4 (*stg)[4][3][64],
+                                                   uint32_t N_cap, float* __restrict__ out, float4 (*stg)[4][3][STG_N],
                                                    const uint32_t* counts_lds, const TrackLoss* tl = nullptr,
                                                    double (*red)[12] = nullptr, const SortShared* span = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
+  const int slane = row * STG_ROW + q;     // this lane's slot in the staging buffers
   const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (row & 1) * 4 + (q & 3);
   const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
@@ -71,9 +78,9 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   {
     const uint32_t id0 = (uint32_t)q < count ? list[q].x : 0u;
     const SplatRec r0 = load_rec<C>(g.splat, id0, (uint32_t)q < count);
-    stg[0][wv][0][lane] = r0.A;
-    stg[0][wv][1][lane] = r0.B;
-    if (C > 2) stg[0][wv][2][lane] = r0.C;
+    stg[0][wv][0][slane] = r0.A;
+    stg[0][wv][1][slane] = r0.B;
+    if (C > 2) stg[0][wv][2][slane] = r0.C;
   }
   uint32_t id_nxt = CH + q < count ? list[CH + q].x : 0u;
   int cur = 0;
@@ -82,8 +89,8 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
     // issue the gathers for the following chunks before touching this one; they land while it is composited
     const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + CH + q < count);
     const uint32_t id_nn = base + 2 * CH + q < count ? list[base + 2 * CH + q].x : 0u;
-    const float4 (*wS)[64] = stg[cur][wv];
-    const int r16 = row * 16;
+    const float4 (*wS)[STG_N] = stg[cur][wv];
+    const int r16 = row * STG_ROW;
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxcount - base));
     auto splat_fwd = [&](const float4& A, const float4& B, const float4& Cc, const int j) {
@@ -119,9 +126,9 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
       }
     }
     if (__ballot(!done && base + CH < count) == 0ull) break;
-    stg[cur ^ 1][wv][0][lane] = rec_n.A;
-    stg[cur ^ 1][wv][1][lane] = rec_n.B;
-    if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
+    stg[cur ^ 1][wv][0][slane] = rec_n.A;
+    stg[cur ^ 1][wv][1][slane] = rec_n.B;
+    if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
     id_nxt = id_nn;
   }
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
@@ -159,7 +166,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
 template <int C>
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out) {
-  __shared__ float4 stg[2][4][3][64];
+  __shared__ float4 stg[2][4][3][STG_N];
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
@@ -175,7 +182,7 @@ template <int C>
 __global__ void __launch_bounds__(256)
 sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean, int has_tl,
                           TrackLoss tl, int direct_blocks) {
-  __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * 64];   // 24 KB >= 2048 keys (16 KB)
+  __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * STG_N];   // 24 KB >= 2048 keys (16 KB)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
   static_assert(sizeof(smem) >= 2048 * sizeof(unsigned long long), "LDS union too small for the key array");
@@ -185,7 +192,7 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks);
   if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
-  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
+  composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
 
 }
 
@@ -335,7 +342,7 @@ struct SepReduce {
 //         -- the chain rule of the depth bundle folded into the reduction -- and dopacity = M0 / opacity (10 floats, not 12).
 // MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
 // (a device function: the tracking loop runs it in the same launch as the sort and the forward compositor, see below)
-#define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * 64 + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
+#define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * STG_N + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
 template <int C, int MODE>
 __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
                                                    uint32_t N_cap, const float* __restrict__ dL_dout, float* __restrict__ dsub, int has_tl,
@@ -343,6 +350,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
+  const int slane = row * STG_ROW + q;     // this lane's slot in the staging buffers
   const int px = (tile % cam.gx) * TILE + (wv & 1) * 8 + (row & 1) * 4 + (q & 3);
   const int py = (tile / cam.gx) * TILE + (wv >> 1) * 8 + (row >> 1) * 4 + (q >> 2);
   const bool inside = px < cam.W && py < cam.H;
@@ -362,8 +370,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   // (conflict-free) writes, and ONE address register per splat for the row-uniform reads (fields are a constant 1 KB apart ->
   // immediate offsets).  (The caller's LDS block is shared with the scratch of the folded mapping-loss gradient pass, which
   // runs first, and -- in the fused tracking kernel -- with the sort keys and the forward compositor's staging buffers.)
-  float4 (*stg)[4][3][64] = (float4 (*)[4][3][64])smem_raw;
-  uint32_t (*stgi)[4][64] = (uint32_t (*)[4][64])(smem_raw + sizeof(float4) * 2 * 4 * 3 * 64);
+  float4 (*stg)[4][3][STG_N] = (float4 (*)[4][3][STG_N])smem_raw;
+  uint32_t (*stgi)[4][64] = (uint32_t (*)[4][64])(smem_raw + sizeof(float4) * 2 * 4 * 3 * STG_N);
   constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -445,9 +453,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   {
     const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
     const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
-    stg[0][wv][0][lane] = r0.A;
-    stg[0][wv][1][lane] = r0.B;
-    if (C > 2) stg[0][wv][2][lane] = r0.C;
+    stg[0][wv][0][slane] = r0.A;
+    stg[0][wv][1][slane] = r0.B;
+    if (C > 2) stg[0][wv][2][slane] = r0.C;
     stgi[0][wv][lane] = e0.y;
   }
   uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
@@ -461,10 +469,11 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
     const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
-    const float4 (*wS)[64] = stg[cur][wv];
-    const int r16 = row * 16;
+    const float4 (*wS)[STG_N] = stg[cur][wv];
+    const int r16i = row * 16;
+    const int r16 = row * STG_ROW;
     const uint32_t* wI = stgi[cur][wv];
-    auto pair_of = [&](int j) { return wI[r16 + j]; };
+    auto pair_of = [&](int j) { return wI[r16i + j]; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti, const int j) {
@@ -541,9 +550,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         splat_bwd(A1, B1, C1, t1, j1);
       }
     }
-    stg[cur ^ 1][wv][0][lane] = rec_n.A;
-    stg[cur ^ 1][wv][1][lane] = rec_n.B;
-    if (C > 2) stg[cur ^ 1][wv][2][lane] = rec_n.C;
+    stg[cur ^ 1][wv][0][slane] = rec_n.A;
+    stg[cur ^ 1][wv][1][slane] = rec_n.B;
+    if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
     stgi[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
@@ -582,13 +591,13 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   __shared__ __align__(16) unsigned char smem[BWD_STG_BYTES];     // >= forward staging (24 KB) >= sort keys (+ payloads)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
-  static_assert(BWD_STG_BYTES >= sizeof(float4) * 2 * 4 * 3 * 64, "LDS union too small for the forward staging buffers");
+  static_assert(BWD_STG_BYTES >= sizeof(float4) * 2 * 4 * 3 * STG_N, "LDS union too small for the forward staging buffers");
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
   sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks);
   __syncthreads();
-  composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][64])smem, sh.run, &tl, red, &sh);
+  composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, &tl, red, &sh);
   __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free
   composite_bwd_body<6, 2>(tile, cam, g, iv, b, N_cap, nullptr, dsub, 1, tl, 6, smem, &sh);
 }
