@@ -243,8 +243,8 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   if (db.on) {
     { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, s); }
     { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
-      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub);
-      else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks); }
+      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap);
+      else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks, db.bin_cap); }
     return check_launch("slam_forward");
   }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }

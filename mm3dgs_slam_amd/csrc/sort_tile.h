@@ -53,7 +53,7 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0) {
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
   uint32_t* run = sh.run;
@@ -62,9 +62,17 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
   // their number is the tile's cursor, and every pair's payload carries its block mask and gradient-record index
   const bool direct = direct_blocks != 0;
   uint32_t start, ulen;
+  unsigned long long pre0 = ~0ull, pre1 = ~0ull;   // direct bins: the keys of this wave's first two runs, requested before the count is known
   if (direct) {
-    const uint32_t cap = iv.hdr->bin_cap, cnt = iv.cursor[tile], seen_max = iv.hdr->max_tile_len;
-    start = (uint32_t)tile * cap; ulen = min(cnt, cap);
+    // (the span's position comes from a kernel argument -- the same value the binning kernel left in hdr->bin_cap -- so that
+    //  the first keys can be requested together with the tile's count instead of one memory round trip after it; reads inside
+    //  the span are always in bounds, entries past the count are discarded below)
+    const uint32_t cap = direct_cap;
+    start = (uint32_t)tile * cap;
+    if ((uint32_t)(wv * 64 + lane) < cap) pre0 = b.keys[start + (uint32_t)(wv * 64 + lane)];
+    if ((uint32_t)((wv + 4) * 64 + lane) < cap) pre1 = b.keys[start + (uint32_t)((wv + 4) * 64 + lane)];
+    const uint32_t cnt = iv.cursor[tile], seen_max = iv.hdr->max_tile_len;
+    ulen = min(cnt, cap);
     if (tid == 0) {
       iv.ranges[tile] = cnt;                     // (tile_span clamps to the span)
       if (cnt > cap) iv.hdr->overflow = 1u;
@@ -112,7 +120,8 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     const int nruns = (len + 63) >> 6;
     for (int r = wv; r < nruns; r += 4) {
       const int i = r * 64 + lane;
-      unsigned long long key = i < len ? gk[i] : ~0ull;   // padding sorts to the end of the last run
+      unsigned long long key = ~0ull;                      // padding sorts to the end of the last run
+      if (i < len) key = (direct && r == wv) ? pre0 : ((direct && r == wv + 4) ? pre1 : gk[i]);
 #pragma unroll
       for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
