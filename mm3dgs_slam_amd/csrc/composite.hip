@@ -364,8 +364,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
 
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
-  constexpr int NF4 = (NV + 3) / 4;
-  constexpr int RECF = MODE == 0 ? SPLAT_F : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats (SLAM modes: packed, composite_common.h)
+  constexpr int RECF = MODE == 0 ? NV : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats: packed at the record's real size (composite_common.h; generic: 6 + C)
   // [buffer][wave][field A|B|C][row * 16 + entry] + [buffer][wave][row * 16 + entry] record indices: lane-contiguous
   // (conflict-free) writes, and ONE address register per splat for the row-uniform reads (fields are a constant 1 KB apart ->
   // immediate offsets).  (The caller's LDS block is shared with the scratch of the folded mapping-loss gradient pass, which
@@ -438,7 +437,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
 
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + q; e < count; e += 16) {
-    zero_record<MODE == 0 ? 4 * NF4 : NV>(dsub + (size_t)list[e].y * RECF);
+    zero_record<NV>(dsub + (size_t)list[e].y * RECF);
   }
   if (maxtodo == 0) return;   // wave-uniform
 

@@ -5,7 +5,8 @@
 #include "composite_common.h"
 #include "tile_mask.h"
 
-// NF4: float4s per record that carry data (2 or 3); RECF: record stride in floats; NTHREADS: workgroup size.
+// NF4: float4s per record that carry data (2 or 3); RECF: record stride in floats (0: run-time stride `recf`, the generic path's
+// 6 + C); NTHREADS: workgroup size.
 // Inputs per lane: area (tiles in the splat's rectangle, 0 = culled), goff (first pair index), r0/r1 (tile rectangle),
 // sA/sB (first 32 bytes of the splat record), bblk + boff (first record).  Output: acc0..acc2 = sum of the records.
 // yshift (SLAM record layouts only): the records were written by composite_bwd2_kernel, whose y-moments are taken about the
@@ -33,10 +34,11 @@ __device__ __forceinline__ void add_record(bool on, bool ys, float d0, const flo
 // DIRECT (direct bins, which have no Gaussian-major pair index to address submask[] with): the block masks of a small splat
 // arrive as one 64-bit word (m64: written per Gaussian by the binning kernel), the blocks of a big splat are re-tested with
 // the very rule the lists were built with (tile_mask.h).
-template <int NF4, int RECF, int NTHREADS, bool DIRECT = false>
+template <int NF4, int RECF_T, int NTHREADS, bool DIRECT = false>
 __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t r0, uint32_t r1, const float4& sA, const float4& sB,
                                                uint32_t rec_first, const float* __restrict__ dsub, const BinView& bn, uint32_t N_cap,
-                                               float4& acc0, float4& acc1, float4& acc2, bool yshift = false, unsigned long long m64 = 0ull) {
+                                               float4& acc0, float4& acc1, float4& acc2, bool yshift = false, unsigned long long m64 = 0ull, int recf = 0) {
+  const int RECF = RECF_T ? RECF_T : recf;
   constexpr bool TRACK = NF4 == 2;
   {
     // Gradient records: one per (splat, 4x4 block), dense and contiguous per Gaussian (row-major over its block rectangle,
