@@ -320,6 +320,7 @@ def test_tracking_loss_folded_into_the_compositors_matches_the_loss_kernels(pear
     match the three-kernel loss path (same arithmetic per pixel, only the summation order of the tile sums differs)."""
     from mm3dgs_slam_amd import _lib
     from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
+    monkeypatch.setattr(FusedEngine, "DIRECT_BINS", False)      # (the "short lists" hint below is not a real list length: packed bins)
     cfg, g, R, pose0, color, depth = _setup(P=20000, H=120, W=168, seed=4)
     with torch.no_grad():
         gt = torch.cat([R.render(g, pose0)["render"]], 0).contiguous()
@@ -343,6 +344,40 @@ def test_tracking_loss_folded_into_the_compositors_matches_the_loss_kernels(pear
     assert sa == sb == 12
     assert (pa - pb).abs().max() < 2e-5, (pa, pb)
     assert (la - lb).abs().max() < 1e-5 * max(1.0, float(la.abs().max())), (la, lb)
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_tracking_iteration_in_one_compositor_launch_matches_the_separate_launches(direct, monkeypatch):
+    """mm3dgs_slam_track with the masked-L1 loss runs sort + forward + backward compositing as ONE launch (the backward pass picks
+    its pixel's transmittance, contributor count and colours up from memory the same lane just wrote); MM3DGS_NO_FUSED_TRACK=1
+    keeps the two compositor launches.  Same arithmetic, same order: the pose trajectories must be identical."""
+    from mm3dgs_slam_amd import _lib
+    from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
+    monkeypatch.setattr(FusedEngine, "DIRECT_BINS", direct)
+    cfg, g, R, pose0, color, depth = _setup(P=8000, H=120, W=168, seed=4)
+    with torch.no_grad():
+        gt = torch.cat([R.render(g, pose0)["render"]], 0).contiguous()
+    results = []
+    for no_fuse in ("1", "0"):
+        monkeypatch.setenv("MM3DGS_NO_FUSED_TRACK", no_fuse)
+        eng = FusedEngine(R)
+        eng.forward(pose0, g)
+        assert eng.check_capacity() and eng.max_tile_len <= 1400
+        pose = (pose0 + torch.tensor([0.0, 0.004, -0.003, 0.002, 0.01, -0.008, 0.012], device=DEV)).contiguous()
+        m, v = torch.zeros(7, device=DEV), torch.zeros(7, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.0, 1, 0, 1, 0.99)
+        ad = _lib.Mm3dgsPoseAdam()
+        ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
+        ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = 0.002, 0.002, 0.9, 0.999, 1e-8
+        eng.track_loop(12, pose, g, lcfg, gt, None, ad)
+        torch.cuda.synchronize()
+        assert eng.check_capacity() and eng.direct == direct
+        results.append((pose.clone(), eng.loss.clone(), eng.out.clone(), int(step)))
+    (pa, la, oa, sa), (pb, lb, ob, sb) = results
+    assert sa == sb == 12
+    assert torch.equal(pa, pb), (pa, pb)
+    assert torch.equal(la, lb) and torch.equal(oa, ob)
 
 
 def test_fused_path_with_huge_splats_matches_torch_graph():
