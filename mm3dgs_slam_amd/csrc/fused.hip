@@ -581,9 +581,23 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     const int col = k & 15, grp = k >> 4;
     double a0 = 0.0, a1 = 0.0;
     if (col < NPOSE) {
+      // (all of a lane's rows are requested before the first one is added: with the loads inside the loop every pair of rows
+      //  cost a memory round trip of its own -- 5 in a row at 157 k Gaussians -- in this one-workgroup kernel)
       int r = grp;
-      for (; r + 64 < nrows; r += 128) { a0 += (double)posepartial[(size_t)r * 32 + col]; a1 += (double)posepartial[(size_t)(r + 64) * 32 + col]; }
-      if (r < nrows) a0 += (double)posepartial[(size_t)r * 32 + col];
+      for (; r + 7 * 64 < nrows; r += 8 * 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = posepartial[(size_t)(r + u * 64) * 32 + col];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
+      }
+      {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (r + u * 64 < nrows) ? posepartial[(size_t)(r + u * 64) * 32 + col] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
+      }
     } else if (pls.rows) {   // columns 12, 13 and their helpers 14, 15 (odd row groups): L1 sum, pixel count
       // deferred masked-L1 normalisation: columns 12 / 13 sum the loss rows' L1 sum / pixel count
       // (four independent accumulators: 19 dependent loads in a row cost ~6 us of latency in this one-workgroup kernel)
