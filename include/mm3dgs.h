@@ -175,7 +175,9 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
 #define MM3DGS_FWD_DIRECT_BINS 4 /* N_capacity was sized as T x (per-tile capacity): projection and binning run as ONE launch that
                                     drops every (Gaussian, tile) pair straight into the tile's fixed span (no tile counting pass, no
                                     scan).  A tile with more pairs than N_capacity / T sets `overflow`.  Needs STATE_CLEAN and
-                                    SHORT_LISTS; ignored (packed bins) otherwise or when P > 524288.  The gradient records are
+                                    SHORT_LISTS; ignored (packed bins) otherwise, or when the map is too large for the key layout
+                                    (id and slot share 32 bits: spans of up to 8191 pairs to 512 k Gaussians, 4095 at 1 M, none
+                                    beyond 4 M).  The gradient records are
                                     then laid out per projection workgroup (see Mm3dgsHeader.max_group_records). */
 #define MM3DGS_FWD_SHORT_LISTS 2 /* hint: no tile list exceeds 2048 splats -> one sort launch (longer lists stay correct
                                     through the global-memory path, only slower)                                        */

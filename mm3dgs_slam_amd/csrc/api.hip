@@ -202,7 +202,7 @@ static bool slam_fused_sort(int flags) {
 }
 
 // direct bins (MM3DGS_FWD_DIRECT_BINS): one decision for the forward and the backward of a render
-struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks; };
+struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks, slot_bits; };
 static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_capacity) {
   static const int no_direct = env_flag("MM3DGS_NO_DIRECT_BINS", 0);
   static const int no_fused_scan = env_flag("MM3DGS_NO_FUSED_SCAN", 0);
@@ -210,11 +210,12 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
   const int T = cd.gx * cd.gy;
   d.nblocks = (P + 255) / 256;
   const size_t nb = (size_t)std::max(d.nblocks, 1);
-  d.bin_cap = (uint32_t)std::min<size_t>(N_capacity / (size_t)std::max(T, 1), DIRECT_MAX_CAP);
+  d.slot_bits = direct_slot_bits(P);
+  d.bin_cap = (uint32_t)std::min<size_t>(N_capacity / (size_t)std::max(T, 1), (size_t)((1u << std::max(d.slot_bits, 1)) - 1u));
   // records of the backward scratch per projection workgroup (the scratch holds NLIST records per pair of capacity)
   d.rec_cap = (uint32_t)std::min<size_t>((size_t)NLIST * N_capacity / nb, 0xffffffffull / nb);
   d.on = (flags & MM3DGS_FWD_DIRECT_BINS) && (flags & MM3DGS_FWD_STATE_CLEAN) && slam_fused_sort(flags) && !no_direct && !no_fused_scan &&
-         P > 0 && P <= DIRECT_MAX_P && T <= MAX_FUSED_SCAN_TILES && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
+         P > 0 && d.slot_bits >= DIRECT_SLOT_BITS_MIN && T <= MAX_FUSED_SCAN_TILES && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
          N_capacity >= 4 * (size_t)P;
   return d;
 }
@@ -241,10 +242,10 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   // direct bins: the host sized the binning state as T x (per-tile capacity), so projection and binning are one launch
   const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
   if (db.on) {
-    { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, s); }
+    { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s); }
     { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
-      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap);
-      else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks, db.bin_cap); }
+      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap, db.slot_bits);
+      else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks, db.bin_cap, db.slot_bits); }
     return check_launch("slam_forward");
   }
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }

@@ -181,7 +181,7 @@ composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 template <int C>
 __global__ void __launch_bounds__(256)
 sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean, int has_tl,
-                          TrackLoss tl, int direct_blocks, uint32_t direct_cap) {
+                          TrackLoss tl, int direct_blocks, uint32_t direct_cap, int slot_bits) {
   __shared__ __align__(16) unsigned char smem[sizeof(float4) * 2 * 4 * 3 * STG_N];   // 24 KB >= 2048 keys (16 KB)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
@@ -189,7 +189,7 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap, slot_bits);
   if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
   composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
@@ -586,7 +586,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
 // moment ago; one launch, its ramp and the backward prologue's cold misses less per iteration.
 __global__ void __launch_bounds__(256)
 sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean,
-                                    TrackLoss tl, int direct_blocks, float* __restrict__ dsub, uint32_t direct_cap) {
+                                    TrackLoss tl, int direct_blocks, float* __restrict__ dsub, uint32_t direct_cap, int slot_bits) {
   __shared__ __align__(16) unsigned char smem[BWD_STG_BYTES];     // >= forward staging (24 KB) >= sort keys (+ payloads)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
@@ -594,7 +594,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits);
   __syncthreads();
   composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, &tl, red, &sh);
   __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free
@@ -631,20 +631,20 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
 }
 
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
-                                const TrackLoss* tl, int direct_blocks, uint32_t direct_cap) {
+                                const TrackLoss* tl, int direct_blocks, uint32_t direct_cap, int slot_bits) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
-  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks, direct_cap);
+  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks, direct_cap, slot_bits);
 }
 
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
-                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap) {
+                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap, int slot_bits) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap);
+  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,

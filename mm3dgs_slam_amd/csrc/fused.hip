@@ -238,7 +238,7 @@ __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t*
 
 __global__ void __launch_bounds__(FB)
 slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
-                        uint32_t rec_cap) {
+                        uint32_t rec_cap, int slot_bits) {
   extern __shared__ uint32_t hist[];     // [T]: pairs of this workgroup per tile, then the next slot of each touched tile
   const int T = cam.gx * cam.gy;
   const int tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
@@ -254,7 +254,7 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   c.w = (int)(pr.r1 & 0xffff) - c.minx;
   c.area = c.w * ((int)(pr.r1 >> 16) - c.miny);
   c.khi = __float_as_uint(pr.z);
-  c.idbits = (uint32_t)idx << DIRECT_SLOT_BITS;
+  c.idbits = (uint32_t)idx << slot_bits;
   {   // workgroup-local exclusive scan of the gradient records (4x4 blocks of the block rectangles) + the workgroup's pairs
     __shared__ uint32_t wtot[FB / 64], wtot2[FB / 64];
     uint32_t x = pr.nblk, x2 = (uint32_t)c.area;
@@ -335,10 +335,10 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
 }
 
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
-                             uint32_t rec_cap, hipStream_t s) {
+                             uint32_t rec_cap, int slot_bits, hipStream_t s) {
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
-  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap);
+  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -57,13 +57,13 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
                                float* dsub, hipStream_t s, const TrackLoss* tl = nullptr, int dl_planes = 6);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
-                                const TrackLoss* tl = nullptr, int direct_blocks = 0, uint32_t direct_cap = 0);
+                                const TrackLoss* tl = nullptr, int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX);
 // the same + the backward compositor of a tracking iteration (masked-L1 loss, deferred normalisation) in that launch
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
-                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap = 0);
+                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX);
 // projection + binning in one launch (direct bins: every tile owns bin_cap pairs at tile * bin_cap)
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
-                             uint32_t rec_cap, hipStream_t s);
+                             uint32_t rec_cap, int slot_bits, hipStream_t s);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s);

@@ -115,11 +115,18 @@ static inline BinView bin_view(void* base, size_t N) {
   return b;
 }
 
-// Direct bins (Mm3dgsHeader.bin_cap != 0): key = depth bits << 32 | Gaussian id << DIRECT_SLOT_BITS | slot in the tile's span
+// Direct bins (Mm3dgsHeader.bin_cap != 0): key = depth bits << 32 | Gaussian id << slot_bits | slot in the tile's span
 // (ids are unique inside a tile, so the slot never decides the order; it leads the sorted entry back to its payload).
-#define DIRECT_SLOT_BITS 13
-#define DIRECT_MAX_P (1 << (32 - DIRECT_SLOT_BITS))
-#define DIRECT_MAX_CAP ((1 << DIRECT_SLOT_BITS) - 1)
+// The split of the low word adapts to the map: slot_bits = 32 - bits(P - 1), at most DIRECT_SLOT_BITS_MAX (13: spans of up to
+// 8191 pairs for maps of up to 512 k Gaussians; 12 bits at 1 M, 10 bits -- spans of 1023 -- at 4 M).
+#define DIRECT_SLOT_BITS_MAX 13
+#define DIRECT_SLOT_BITS_MIN 10
+static inline int direct_slot_bits(int P) {
+  int idb = 1;
+  while (idb < 31 && (1ll << idb) < (long long)P) idb++;
+  int sb = 32 - idb;
+  return sb > DIRECT_SLOT_BITS_MAX ? DIRECT_SLOT_BITS_MAX : sb;
+}
 
 #ifdef __HIPCC__
 // bin of a tile: [start, start + len) of keys / payload; its block lists start at sublist + NLIST * start

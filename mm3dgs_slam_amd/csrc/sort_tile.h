@@ -53,7 +53,8 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0, uint32_t direct_cap = 0) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX) {
+  const uint32_t slot_mask = (1u << slot_bits) - 1u;
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
   uint32_t* run = sh.run;
@@ -139,7 +140,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     for (int i = tid; i < len; i += 256) {
       const unsigned long long mine = sk2[i];
       // direct bins: the entry's payload is requested now and lands while the rank is being computed
-      const unsigned long long pl = direct ? b.payload[start + ((uint32_t)mine & DIRECT_MAX_CAP)] : 0ull;
+      const unsigned long long pl = direct ? b.payload[start + ((uint32_t)mine & slot_mask)] : 0ull;
       const int own = i >> 6;
       int rank = i & 63;
       for (int r0 = 0; r0 < nruns; r0 += 4) {
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       const int i = base + lane;
       const bool have = i < len;
       const unsigned long long pl = have ? spl[i] : 0ull;
-      const uint32_t id = have ? ((uint32_t)sk[i] >> DIRECT_SLOT_BITS) : 0u;
+      const uint32_t id = have ? ((uint32_t)sk[i] >> slot_bits) : 0u;
       const uint32_t m4 = ((uint32_t)pl >> (4 * wv)) & 0xfu;
       const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
 #pragma unroll
@@ -218,8 +219,8 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     uint32_t id = 0, mask = 0, recT = 0, bw = 0;
     if (have && direct) {
       const uint32_t low = (uint32_t)(in_lds ? sk[i] : gk[i]);
-      id = low >> DIRECT_SLOT_BITS;
-      const unsigned long long pl = b.payload[start + (low & DIRECT_MAX_CAP)];
+      id = low >> slot_bits;
+      const unsigned long long pl = b.payload[start + (low & slot_mask)];
       mask = (uint32_t)(pl & 0xffffu);
       bw = (uint32_t)(pl >> 16) & 0xffffu;
       recT = (uint32_t)(pl >> 32);

@@ -86,10 +86,14 @@ class FusedEngine:
             self.grads = None
         want = int((self.ratio if self.ratio is not None else 24.0) * max(P, 1) * 2.0) + self.MIN_PAIRS
         self.direct = False
-        if self.DIRECT_BINS and self.max_tile_len <= 1400 and P <= (1 << 19) - 4096:
-            # direct bins (MM3DGS_FWD_DIRECT_BINS): every tile owns n_cap / T pairs; sized from the longest list seen so far
-            T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-            want = max(want, T * (int(self.max_tile_len * 1.5) + 128))
+        # direct bins (MM3DGS_FWD_DIRECT_BINS): every tile owns n_cap / T pairs, sized from the longest list seen so far; the key's low
+        # word holds the Gaussian id and the slot in the span, so the span is limited to 2^(32 - bits(P)) - 1 pairs (8191 up to 512 k
+        # Gaussians, 4095 at 1 M)
+        T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        per_tile = int(self.max_tile_len * 1.5) + 128
+        slot_bits = min(13, 32 - max(int(P - 1).bit_length(), 1)) if P > 0 else 0
+        if self.DIRECT_BINS and self.max_tile_len <= 1400 and slot_bits >= 10 and int(per_tile * 1.25) + 1 <= (1 << slot_bits) - 1:
+            want = max(want, T * per_tile)
             # ... and every projection workgroup (256 Gaussians) 16 * n_cap / workgroups gradient records
             want = max(want, ((P + 255) // 256) * (int(getattr(self, "max_group_records", 0) * 1.5) + 1024) // 16 + 1)
             self.direct = True

@@ -120,3 +120,38 @@ def test_native_engine_agrees_with_generic_path_at_full_size(name):
     # (against the float64 oracle each of them is at ~1e-5, tests/test_gpu_fused.py)
     assert pu.rel_l2(eng.dpose, p.grad) < 5e-3
     assert pu.rel_l2(eng.grads["xyz"], g._xyz.grad) < 5e-3 and pu.rel_l2(eng.grads["opacity"], g._opacity.grad) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["C2_tum_150k", "C4_replica_1M"])
+def test_direct_bins_equal_packed_bins_at_full_size(name):
+    """The native engine's first render of a map uses packed bins (it has not seen a tile list yet), the following ones direct bins
+    (projection + binning in one launch; at 1 M Gaussians the key's low word splits 20 id bits / 12 slot bits): same image, same
+    radii, same gradients, bit for bit."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import FusedEngine
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+    from mm3dgs_slam_amd.renderer import Renderer
+    from mm3dgs_slam_amd import synthetic as syn
+    H, W, P, iso, _ = CONFIGS[name]
+    cfg = default_config(device=DEV, height=H, width=W, pipeline={"force_isotropic": iso})
+    c = cfg["cam"]
+    color, depth = syn.rgbd_frame(H, W, seed=1)
+    G = {k: v.to(DEV) for k, v in syn.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], P, seed=1, isotropic=iso).items()}
+    g = GaussianModel(cfg)
+    g.training_setup()
+    g.densification_postfix(G["xyz"], G["f_dc"], torch.zeros(P, 0, 3, device=DEV), G["opacity"], G["scaling"], G["rotation"], G["rgb"])
+    pose = torch.tensor([0.999, 0.01, -0.02, 0.015, 0.02, -0.01, 0.03], device=DEV)
+    eng = FusedEngine(Renderer(cfg))
+    w = torch.randn(6, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    outs = []
+    for want_direct in (False, True):
+        si = eng.forward(pose, g, need_grads=True)
+        assert eng.direct == want_direct, (eng.direct, eng.max_tile_len, eng.n_cap)
+        eng.dL.copy_(w)
+        eng.backward(si, grads=eng.grads, dpose=eng.dpose)
+        outs.append((eng.out.clone(), eng.radii.clone(), eng.dpose.clone(), {k: v.clone() for k, v in eng.grads.items()}))
+        assert eng.check_capacity()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
