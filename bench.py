@@ -50,9 +50,11 @@ def parse():
     ap.add_argument("--profile", type=int, default=2, help="HIP-event timing inside the library during the timed region: "
                     "2 = only the roofline kernel (backward compositor), 1 = every kernel (adds ~16 events/iteration), 0 = off")
     ap.add_argument("--cpu-baseline-gaussians", type=int, default=50000)
-    ap.add_argument("--workload", default="slam", choices=["slam", "c3", "c5"],
+    ap.add_argument("--workload", default="slam", choices=["slam", "c3", "c4", "c5"],
                     help="slam = BASELINE.json configs[1] (the headline line); c3 = configs[2]: UT-MM-shaped 640x330 RGB-D + IMU (configs/UTMM.yml "
                          "settings, IMU dead-reckoning for the pose prediction + the IMU relative-pose residual in the tracking loss), full track+map; "
+                         "c4 = configs[3]: Replica-room0-shaped 1200x680, one Gaussian per valid frame-0 pixel (~0.78 M; the map of the 8-GPU window run), "
+                         "full track+map on the GPUs given (with --gpus N the mapping window is sharded N ways like the headline workload); "
                          "c5 = configs[4]: synthetic 1920x1080, 3 M Gaussians, SH degree 3, rasterizer forward+backward sweep (a step = one render + "
                          "backward of one view)")
     ap.add_argument("--steady-frames", type=int, default=100,
@@ -323,6 +325,11 @@ def main():
     if c3:
         args.height, args.width = 330, 640
         frac = args.seed_fraction or 1.0      # 640x330 has ~200 k valid pixels: the reference's one-Gaussian-per-pixel seeding, not thinned
+    c4 = args.workload == "c4"
+    if c4:
+        args.height, args.width = 680, 1200
+        frac = args.seed_fraction or 1.0      # the reference's seeding: ~0.78 M Gaussians from frame 0, growing with every keyframe
+        steady = 0
 
     def build(frac_, n_frames, n_target):
         if c3:
@@ -386,13 +393,14 @@ def main():
     mpix = H * W * passes * renders * frame_equiv / elapsed / 1e6
 
     out = {
-        "metric": "SLAM frames/sec (track+map), " + ("UT-MM-shaped 640x330 RGB-D + IMU" if c3 else "TUM fr1/desk-shaped 640x480"), "value": value, "unit": "frames/s",
+        "metric": "SLAM frames/sec (track+map), " + ("UT-MM-shaped 640x330 RGB-D + IMU" if c3 else ("Replica-room0-shaped 1200x680" if c4 else "TUM fr1/desk-shaped 640x480")), "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"UT-MM-shaped synthetic RGB-D + IMU {W}x{H} (configs/UTMM.yml: intrinsics x 1/2, isotropic Gaussians, pose prediction "
                                 f"by IMU dead-reckoning over synthetic 100 Hz samples, Pearson depth term and IMU relative-pose residual (weights 1.0 / 0.1) "
                                 f"in the tracking loss), {P_now} Gaussians, " if c3 else
-                                f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, ") +
+                                (f"Replica-room0-shaped synthetic RGB-D {W}x{H} (TUM intrinsics scaled to the image), {P_now} Gaussians, " if c4 else
+                                 f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, ")) +
                                f"full track+map per frame: {args.track_iters} tracking + {args.map_iters} mapping iterations "
                                f"(reference budget), frame-0 seeding thinned to {frac:.2f} of the pixels, render_mode={args.render_mode}, "
                                f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
@@ -466,7 +474,7 @@ def main():
         out["steady_state"] = {"frames": steady, "value": steady / el, "unit": "frames/s", "ms_per_frame": el / steady * 1e3,
                                "gaussians_at_end": int(slam.gaussians.get_xyz.shape[0]), "keyframes": len(slam.mapper.keyframes),
                                "note": f"frames {first}..{first + steady - 1} of the run above (same map, same budget, keyframe work included)"}
-    if extras and args.full_seed_steps and frac < 1.0 and not c3:
+    if extras and args.full_seed_steps and frac < 1.0 and not c3 and not c4:
         log("full-seed run (one Gaussian per valid frame-0 pixel)")
         del slam
         torch.cuda.empty_cache()

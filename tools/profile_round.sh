@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profile: the headline bench line, rocprofv3 kernel stats of the same command, HBM traffic counters of the same command
 # (FETCH_SIZE and WRITE_SIZE in their own --pmc passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), and the bench lines +
-# kernel stats of the other BASELINE configurations (C3 = UTMM-shaped RGB-D + IMU, C5 = 1080p / 3 M Gaussians / SH degree 3).
+# kernel stats of the other BASELINE configurations (C3 = UTMM-shaped RGB-D + IMU, C4 = Replica-shaped 1200x680 / 0.8 M Gaussians on one GPU,
+# C5 = 1080p / 3 M Gaussians / SH degree 3).
 # Run on the GPU box from the repo root: bash tools/profile_round.sh r02
 set -u
 TAG=${1:-r02}
@@ -33,6 +34,7 @@ python bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 > $OUT/bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 python bench.py --workload c3 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 2>/dev/null | tee $OUT/bench_c3.json | cut -c1-300
+python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_c4.json | cut -c1-300
 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_c5.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o c5 -- python bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/p_c5 -name "*kernel_stats.csv" | head -1) $OUT/bench_c5_kernel_stats.csv
