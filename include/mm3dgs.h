@@ -269,6 +269,14 @@ int mm3dgs_seed_gaussians(int H, int W, const float* color /*[3,H,W]*/, const fl
                           const float* pose, float fx, float fy, float cx, float cy, uint32_t row0, const Mm3dgsSeedOutputs* out, int n_rest,
                           void* stream);
 
+/* Keyframe test (slam/mapper.py:141-216: need_new_keyframe -> get_depth_pointcloud + is_covisible): back-project the last keyframe's
+ * rendered surface (depth where silhouette > 0.99, minus points that round to the world origin at 4 decimals) to the world and
+ * project it into the current view.  counts[0] = points inside the image in front of the camera, counts[1] = points tested
+ * (device memory, zeroed by the call); the covisibility ratio is counts[0] / max(counts[1], 1).  Poses are world->camera
+ * (qw,qx,qy,qz,tx,ty,tz) on the device. */
+int mm3dgs_covisibility_ratio(int H, int W, const float* depth /*[H,W]*/, const float* silhouette /*[H,W]*/, const float* keyframe_pose,
+                              const float* current_pose, float fx, float fy, float cx, float cy, uint32_t* counts /*[2]*/, void* stream);
+
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
  * (timed) launches and their summed duration since the previous read, and resets the counters. */

@@ -508,6 +508,13 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double be
 }
 
 // ---- map surgery (compact.hip) -----------------------------------------------------------------------------------------
+int mm3dgs_covisibility_ratio(int H, int W, const float* depth, const float* silhouette, const float* keyframe_pose, const float* current_pose,
+                              float fx, float fy, float cx, float cy, uint32_t* counts, void* stream) {
+  if (H < 0 || W < 0 || !depth || !silhouette || !keyframe_pose || !current_pose || !counts) return fail(-1, "covisibility_ratio: bad argument");
+  launch_covisibility_ratio(H, W, depth, silhouette, keyframe_pose, current_pose, fx, fy, cx, cy, counts, (hipStream_t)stream);
+  return check_launch("covisibility_ratio");
+}
+
 int mm3dgs_prune_mask(int P, const float* opacity, const float* log_scales, const float* max_radii2D, float min_opacity, float max_scale,
                       float max_screen_size, uint8_t* keep, uint32_t* n_pruned_accum, void* stream) {
   if (P < 0) return fail(-1, "P < 0");

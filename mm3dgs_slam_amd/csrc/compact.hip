@@ -9,6 +9,7 @@
 // Compaction = three small launches over `n` flagged elements (Gaussians or pixels): per-256 counts, one workgroup scanning the
 // counts, scatter by rank.  Order preserving and deterministic (no atomics decide a position).
 #include "mm3dgs_common.h"
+#include <algorithm>
 #include "fused_api.h"
 
 #define CB 256
@@ -131,6 +132,59 @@ seed_gaussians_kernel(int H, int W, const float* __restrict__ color, const float
   o.rotation[(size_t)r * 4] = 1.f; o.rotation[(size_t)r * 4 + 1] = 0.f; o.rotation[(size_t)r * 4 + 2] = 0.f; o.rotation[(size_t)r * 4 + 3] = 0.f;
 }
 
+// ---- keyframe test: covisibility ratio of two views (slam/mapper.py:141-173 need_new_keyframe -> get_depth_pointcloud :175-196 +
+// is_covisible :198-216): the surface points of the last keyframe (its rendered depth where the silhouette is > 0.99, minus points
+// that round to the world origin at 4 decimals) back-projected to the world and projected into the current view;
+// counts[0] = points that land inside the image in front of the camera, counts[1] = points tested.  One pass over the rendered
+// depth / silhouette planes instead of ~30 element-wise torch launches; a fixed small grid, so only a handful of atomics per counter.
+__device__ __forceinline__ void pose_to_Rt(const float* __restrict__ pose, float R[3][3], float t[3]) {
+  float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+  const float n = 1.f / sqrtf(w * w + x * x + y * y + z * z);
+  w *= n; x *= n; y *= n; z *= n;
+  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - w * z); R[0][2] = 2.f * (x * z + w * y);
+  R[1][0] = 2.f * (x * y + w * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - w * x);
+  R[2][0] = 2.f * (x * z - w * y); R[2][1] = 2.f * (y * z + w * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+  t[0] = pose[4]; t[1] = pose[5]; t[2] = pose[6];
+}
+__global__ void __launch_bounds__(CB)
+covisibility_ratio_kernel(int H, int W, const float* __restrict__ depth, const float* __restrict__ sil, const float* __restrict__ kf_pose,
+                          const float* __restrict__ cur_pose, float fx, float fy, float cx, float cy, uint32_t* __restrict__ counts) {
+  float Rk[3][3], tk[3], Rc[3][3], tc[3];
+  pose_to_Rt(kf_pose, Rk, tk);
+  pose_to_Rt(cur_pose, Rc, tc);
+  const int n = H * W;
+  uint32_t n_in = 0, n_sel = 0;
+  for (int i = blockIdx.x * CB + threadIdx.x; i < n; i += gridDim.x * CB) {
+    const float z = sil[i] > 0.99f ? depth[i] : 0.f;
+    const float u = (float)(i % W), v = (float)(i / W);
+    const float c[3] = {(u - cx) / fx * z, (v - cy) / fy * z, z};
+    // camera -> world of the keyframe (closed-form rigid inverse: R^T x - R^T t), then world -> current camera
+    const float tt[3] = {-(Rk[0][0] * tk[0] + Rk[1][0] * tk[1] + Rk[2][0] * tk[2]), -(Rk[0][1] * tk[0] + Rk[1][1] * tk[1] + Rk[2][1] * tk[2]),
+                         -(Rk[0][2] * tk[0] + Rk[1][2] * tk[1] + Rk[2][2] * tk[2])};
+    float pw[3], p[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) pw[a] = c[0] * Rk[0][a] + c[1] * Rk[1][a] + c[2] * Rk[2][a] + tt[a];
+    // torch.round(pts, decimals=4).abs().sum(1) > 0  <=>  some coordinate does not round (half to even) to zero
+    const bool sel = z > 0.f && (fabsf(pw[0] * 10000.f) > 0.5f || fabsf(pw[1] * 10000.f) > 0.5f || fabsf(pw[2] * 10000.f) > 0.5f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) p[a] = pw[0] * Rc[a][0] + pw[1] * Rc[a][1] + pw[2] * Rc[a][2] + tc[a];
+    const float zc = p[2] + 1e-5f;
+    const float uu = (fx * p[0] + cx * p[2]) / zc, vv = (fy * p[1] + cy * p[2]) / zc;
+    const bool inside = sel && uu < (float)W && uu > 0.f && vv < (float)H && vv > 0.f && zc > 0.f;
+    n_in += inside ? 1u : 0u; n_sel += sel ? 1u : 0u;
+  }
+  __shared__ uint32_t red[2][CB / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { n_in += __shfl_down(n_in, off, 64); n_sel += __shfl_down(n_sel, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = n_in; red[1][threadIdx.x >> 6] = n_sel; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t t = 0;
+    for (int w = 0; w < CB / 64; w++) t += red[threadIdx.x][w];
+    if (t) atomicAdd(&counts[threadIdx.x], t);
+  }
+}
+
 // ---- launchers (called from api.hip) ------------------------------------------------------------------------------------------
 void launch_prune_mask(int P, const float* opacity, const float* scaling, const float* max_radii2D, float min_opacity, float max_scale,
                        float max_screen_size, int use_screen, uint8_t* keep, uint32_t* n_pruned, hipStream_t s) {
@@ -153,4 +207,11 @@ void launch_seed_gaussians(int H, int W, const float* color, const float* depth,
   if (n <= 0) return;
   hipLaunchKernelGGL(seed_gaussians_kernel, dim3((n + CB - 1) / CB), dim3(CB), 0, s, H, W, color, depth, keep, block_pre, pose, fx, fy, cx, cy,
                      row0, o);
+}
+void launch_covisibility_ratio(int H, int W, const float* depth, const float* sil, const float* kf_pose, const float* cur_pose, float fx, float fy,
+                               float cx, float cy, uint32_t* counts, hipStream_t s) {
+  (void)hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s);
+  if (H * W <= 0) return;
+  const int nb = std::min((H * W + CB - 1) / CB, 64);
+  hipLaunchKernelGGL(covisibility_ratio_kernel, dim3(nb), dim3(CB), 0, s, H, W, depth, sil, kf_pose, cur_pose, fx, fy, cx, cy, counts);
 }

@@ -80,3 +80,5 @@ void launch_compact_rows(int n, const uint8_t* keep, const uint32_t* block_pre, 
 void launch_seed_gaussians(int H, int W, const float* color, const float* depth, const uint8_t* keep, const uint32_t* block_pre,
                            const float* pose, float fx, float fy, float cx, float cy, uint32_t row0, const SeedOut& o, hipStream_t s);
 
+void launch_covisibility_ratio(int H, int W, const float* depth, const float* sil, const float* kf_pose, const float* cur_pose, float fx, float fy,
+                               float cx, float cy, uint32_t* counts, hipStream_t s);

@@ -280,6 +280,21 @@ class FusedMapper(Mapper):
                 return eng.out[3], eng.out[4]
         raise RuntimeError("mm3dgs: render kept overflowing its binning capacity")
 
+    def covisibility_ratio_dense(self, depth, sil, kf_pose, cur_pose):
+        """The keyframe test's covisibility ratio (slam/mapper.py:141-216) as ONE kernel over the rendered depth / silhouette
+        planes (mm3dgs_covisibility_ratio) instead of ~30 element-wise torch launches: two counters come back."""
+        if not (FusedEngine.eligible(self.cfg, self.gaussians) and depth.is_cuda and depth.is_contiguous() and sil.is_contiguous()):
+            return super().covisibility_ratio_dense(depth, sil, kf_pose, cur_pose)
+        eng = _engine(self.renderer)
+        fx, fy, cx, cy = self._intr()
+        H, W = depth.shape
+        counts = torch.empty(2, dtype=torch.int32, device=depth.device)
+        kp, cp = kf_pose.detach().float().to(depth.device).contiguous(), cur_pose.detach().float().to(depth.device).contiguous()
+        _lib.check(eng.lib.mm3dgs_covisibility_ratio(H, W, _p(depth), _p(sil), _p(kp), _p(cp), float(fx), float(fy), float(cx), float(cy),
+                                                     _p(counts), _stream()))
+        c = counts.cpu()                      # (the caller synchronises on the decision anyway)
+        return torch.tensor(float(c[0]) / max(float(c[1]), 1.0))
+
     def get_covisible_gaussians(self, keyframe_idx_list, curr_camera_tensor, min_kf=2):
         """Gaussians visible from >= 2 views of the window (slam/mapper.py:690-716; the reference ignores `min_kf` and uses 2):
         one projection-only launch per view accumulating a per-Gaussian counter -- no render."""

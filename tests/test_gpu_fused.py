@@ -764,6 +764,30 @@ def test_covisible_gaussians_from_the_projection_stage_alone():
     assert int((a != b).sum()) <= 2          # (two float32 projection pipelines: a borderline radius may differ)
 
 
+def test_keyframe_covisibility_ratio_kernel_matches_the_torch_formulation():
+    """mm3dgs_covisibility_ratio (one kernel over the rendered depth / silhouette planes) against Mapper.covisibility_ratio_dense
+    (the reference's get_depth_pointcloud + is_covisible, slam/mapper.py:141-216, as element-wise torch operators): the same
+    points pass the same tests -- also with a view that loses part of the surface and with invalid (zero-silhouette) pixels."""
+    from mm3dgs_slam_amd.fused import FusedMapper
+    from mm3dgs_slam_amd.mapper import Mapper
+    cfg, g, R, pose, color, depth = _setup(P=12000, H=120, W=160, seed=13)
+    fm = FusedMapper.__new__(FusedMapper)
+    fm.cfg, fm.gaussians, fm.renderer = cfg, g, R
+    with torch.no_grad():
+        d, sil = fm._render_depth_sil(pose)
+        d, sil = d.clone(), sil.clone()
+        sil[:10, :] = 0.5                                      # not surface
+        for shift in (0.0, 0.4, 1.5):
+            cur = pose.clone(); cur[4] += shift; cur[1] += 0.05 * shift
+            a = float(FusedMapper.covisibility_ratio_dense(fm, d, sil, pose, cur))
+            b = float(Mapper.covisibility_ratio_dense(fm, d, sil, pose, cur))
+            # (same pose: every pixel of image column 0 / row 0 re-projects onto the boundary uu = 0 / vv = 0 itself, and lands on
+            #  either side of it in float32 -- in both implementations; elsewhere only a stray boundary pixel can differ)
+            assert abs(a - b) <= (2e-3 if shift == 0.0 else 2e-4), (shift, a, b)
+            assert 0.0 <= a <= 1.0
+    assert b < 0.9                                             # the last view really lost part of the surface
+
+
 def test_native_bundle_adjustment_follows_the_torch_graph_loop():
     """mapping.do_BA natively (pose Adam on the device inside mm3dgs_slam_map, gradient masking by covisibility inside the in-kernel map
     Adam) against the torch-graph Mapper.optimize_map with do_BA (slam/mapper.py:718-795,931-942): the same window (three keyframes +
