@@ -326,7 +326,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
-  if (tl && !tracking && bwd2_requested() == 2) return fail(-1, "internal: the second-generation backward compositor has no folded mapping loss");
+  if (tl && !tracking && (bwd2_requested() == 2 || bwd2_requested() == 4)) return fail(-1, "internal: the second-generation backward compositor has no folded mapping loss");
   // MM3DGS_BWD2=1 selects the 2-pixels-per-lane / MFMA-reduction backward compositor (composite_bwd2.hip).  Default off: it
   // executes 29 % fewer VALU instructions but, with half the waves per SIMD (2.3 instead of 4.7), cannot keep the VALU busy
   // (58 % active; 61 us against 49 us at SLAM size, and no better at 1200x680 -- profiles/r02_bwd2_experiment.md).  Kept as a
@@ -336,7 +336,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, bwd2);
     else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, bwd2 ? 1 : 0, slam_direct_bins(flags, cd, P, N_capacity).on); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, (bwd2 == 2 || bwd2 == 3) ? 1 : 0, slam_direct_bins(flags, cd, P, N_capacity).on); }
   return check_launch("slam_backward");
 }
 
@@ -466,7 +466,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       if (rc) return rc;
       // the gradient-image pass itself runs in the backward compositor's prologue (tl.dmaps set) unless the second-generation
       // compositor or MM3DGS_NO_FOLDED_LOSS asks for the separate launch
-      const bool fold_grad = bwd2_requested() != 2 && !env_flag("MM3DGS_NO_FOLDED_LOSS", 0);
+      const bool fold_grad = bwd2_requested() != 2 && bwd2_requested() != 4 && !env_flag("MM3DGS_NO_FOLDED_LOSS", 0);
       { ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
         launch_loss_after_forward_rows(lc, out_color, tl.gt, tl.ref, dmaps, sums, partial, fold_grad ? nullptr : dL_dout, (hipStream_t)stream); }
       if (loss4 && it == n_iter - 1) launch_loss_finish(lc, sums, partial, (hipStream_t)stream, loss4);

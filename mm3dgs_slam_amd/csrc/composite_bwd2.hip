@@ -249,6 +249,230 @@ composite_bwd2_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t 
   else run_chunks(std::false_type{});
 }
 
+// ---- fourth generation: two pixels per lane like the second, but the block's eight lanes are CONTIGUOUS (lane = 8 * block + 2 * row +
+// half), so the sum over a block is three DPP steps (quad_perm xor 1, xor 2, row_half_mirror) per value instead of a matrix-core
+// pass: 30 (mapping) / 21 (tracking) v_add_f32_dpp per wave step for EIGHT records, against ~34 per four records in the first
+// generation, and the y-moments are taken about the splat centre directly (dy is a per-lane constant of the step): the records
+// are the first generation's, no shift in the gather.
+template <int MODE>   // 1: mapping records [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy], 2: tracking [M0 Mx Mxx cz | My Mxy Myy]
+__global__ void __launch_bounds__(128)
+composite_bwd4_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
+                      float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
+  constexpr int C = 6;
+  constexpr int RECF = MODE == 2 ? REC_TRACK_F : REC_MAP_F;    // packed records (composite_common.h)
+  constexpr uint32_t CH = 16;                           // list entries staged per block and chunk
+  const int T = cam.gx * cam.gy;
+  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  if (tile >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int bq = lane >> 3, k = (lane >> 1) & 3, h = lane & 1;
+  const int L = 8 * wv + bq;                            // block list: 4 * (8x8 sub-tile) + block inside it (sort_tile.h)
+  const int sub = L >> 2, inb = L & 3;
+  const int bx = (sub & 1) * 2 + (inb & 1), by = (sub >> 1) * 2 + (inb >> 1);
+  const int px0 = (tile % cam.gx) * TILE + 4 * bx + 2 * h;
+  const int py = (tile / cam.gx) * TILE + 4 * by + k;
+  const bool in0 = px0 < cam.W && py < cam.H, in1 = px0 + 1 < cam.W && py < cam.H;
+  const float pxf0 = (float)px0, pxf1 = (float)(px0 + 1), pyf = (float)py;
+  uint32_t start, len_;
+  tile_span(iv, tile, N_cap, start, len_);
+  const uint32_t end = start + len_;
+  const uint32_t len = end - start;
+  const uint32_t count = len ? min(iv.subcount[NLIST * tile + L], len) : 0u;
+  const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
+
+  // [wave][buffer][field A|B|C][step * 8 + block]: lane-contiguous staging writes; a step's reads touch 8 consecutive 16-byte
+  // slots (the 8 blocks), each broadcast to its 8 lanes -- conflict free
+  __shared__ float4 stg[2][2][3][CH * 8];
+  __shared__ uint32_t srec[2][2][CH * 8];
+  __shared__ uint32_t s_todo[2][8];
+  __shared__ unsigned long long s_list[2][8];           // element offset of each block's list inside b.sublist
+
+  const size_t HW = (size_t)cam.H * cam.W;
+  const size_t pix0 = (size_t)py * cam.W + px0;
+  float Tf[2] = {in0 ? iv.final_T[pix0] : 0.f, in1 ? iv.final_T[pix0 + 1] : 0.f};
+  uint32_t lastc[2] = {in0 ? iv.n_contrib[pix0] : 0u, in1 ? iv.n_contrib[pix0 + 1] : 0u};
+  float dL[2][C];
+  bool dl_done = false;
+  if constexpr (MODE == 2) {
+    if (has_tl) {
+      // tracking loss folded in: dL/d(image) of these pixels from the finished sums (what loss_grad_kernel would have written)
+      const float l1s = tl.defer_scale ? tl.cfg.w_l1 / 3.f : loss_l1_scale(tl.cfg, tl.sums);   // deferred: 1/n applied to the pose gradient
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int ch = 0; ch < C; ch++) dL[p][ch] = 0.f;
+        if (p == 0 ? in0 : in1) {
+          const size_t pix = pix0 + p;
+          const float sil = tl.out[4 * HW + pix];
+          const bool smask = sil > tl.cfg.sil_thr;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) dL[p][ch] = loss_px_l1_grad(tl.cfg, tl.out[ch * HW + pix], tl.gt[ch * HW + pix], smask, l1s);
+          if (tl.cfg.w_pearson != 0.f) dL[p][3] = loss_px_pearson_grad(tl.cfg, sil, tl.out[3 * HW + pix], tl.ref[pix], tl.sums);
+        }
+      }
+      if (!tl.defer_scale && tile == 0 && tid == 0 && tl.loss4) loss_scalars(tl.cfg, tl.sums, HW, tl.loss4);
+      dl_done = true;
+    }
+  }
+  float Tf_bg[2] = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    float bg_dot = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C; ch++) {
+      if (!dl_done) dL[p][ch] = ((p == 0 ? in0 : in1) && ch < dl_planes) ? dL_dout[ch * HW + pix0 + p] : 0.f;
+      if (ch < 3) bg_dot += cam.bg[ch] * dL[p][ch];
+    }
+    Tf_bg[p] = Tf[p] * bg_dot;
+  }
+  float Tr[2] = {Tf[0], Tf[1]};
+  float behind[2] = {0.f, 0.f};      // (colour accumulated behind the current list position) . dL, per pixel
+
+  // nothing behind the deepest contributor of any pixel of the block matters: todo = max over the block's 16 pixels
+  // (2 in this lane, the other half one lane over, the other rows 16 / 32 lanes over)
+  uint32_t todo = max(lastc[0], lastc[1]);
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 1, 64));
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 2, 64));
+  todo = max(todo, (uint32_t)__shfl_xor((int)todo, 4, 64));
+  todo = min(todo, count);
+  uint32_t maxtodo = todo;
+  maxtodo = max(maxtodo, (uint32_t)__shfl_xor((int)maxtodo, 8, 64));
+  maxtodo = max(maxtodo, (uint32_t)__shfl_xor((int)maxtodo, 16, 64));
+  maxtodo = max(maxtodo, (uint32_t)__shfl_xor((int)maxtodo, 32, 64));
+  maxtodo = __builtin_amdgcn_readfirstlane(maxtodo);
+  if ((lane & 7) == 0) {
+    s_todo[wv][bq] = todo;
+    s_list[wv][bq] = (unsigned long long)NLIST * start + (unsigned long long)L * len;
+  }
+  // entries behind `todo` receive no gradient: their records are zero (8 lanes per block)
+  {
+    const uint32_t q8 = (uint32_t)(lane & 7);
+    for (uint32_t e = todo + q8; e < count; e += 8) {
+      zero_record<RECF>(dsub + (size_t)list[e].y * RECF);
+    }
+  }
+  __syncthreads();                   // s_todo / s_list visible (both waves take the same path up to here)
+  if (maxtodo == 0) return;          // wave-uniform
+
+  // staging: this lane loads the entries of slots `lane` and `lane + 64` of a chunk: slot = step * 8 + block
+  const int sb0 = lane & 7, ss0 = lane >> 3, ss1 = ss0 + 8;     // both slots belong to block sb0, steps ss0 and ss0 + 8
+  const uint32_t stodo = s_todo[wv][sb0];
+  const uint2* __restrict__ slist = b.sublist + s_list[wv][sb0];
+  auto entry_at = [&](uint32_t pos_from_back) -> uint2 {           // traversal position -> list entry (back to front)
+    return pos_from_back < stodo ? slist[stodo - 1u - pos_from_back] : make_uint2(0u, 0u);
+  };
+  {
+    const uint2 e0 = entry_at((uint32_t)ss0), e1 = entry_at((uint32_t)ss1);
+    const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)ss0 < stodo), r1 = load_rec<C>(g.splat, e1.x, (uint32_t)ss1 < stodo);
+    stg[wv][0][0][lane] = r0.A; stg[wv][0][1][lane] = r0.B; stg[wv][0][2][lane] = r0.C; srec[wv][0][lane] = e0.y;
+    stg[wv][0][0][lane + 64] = r1.A; stg[wv][0][1][lane + 64] = r1.B; stg[wv][0][2][lane + 64] = r1.C; srec[wv][0][lane + 64] = e1.y;
+  }
+  uint2 en0 = entry_at(CH + (uint32_t)ss0), en1 = entry_at(CH + (uint32_t)ss1);
+  int cur = 0;
+
+  // The SLAM losses leave the silhouette and depth^2 channels without gradient (dL[4] = dL[5] = 0): a wave that sees only
+  // zeros there runs a loop instance with those terms removed (exact: they would multiply by zero).
+  const bool z45_wave = __ballot(dL[0][4] != 0.f || dL[0][5] != 0.f || dL[1][4] != 0.f || dL[1][5] != 0.f) == 0ull;
+  auto run_chunks = [&](auto z45_tag) {
+    constexpr bool Z45 = decltype(z45_tag)::value;
+    for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
+      // gathers for the following chunks are issued before this one is touched; they land while it is processed
+      const SplatRec rn0 = load_rec<C>(g.splat, en0.x, base + CH + (uint32_t)ss0 < stodo);
+      const SplatRec rn1 = load_rec<C>(g.splat, en1.x, base + CH + (uint32_t)ss1 < stodo);
+      const uint2 enn0 = entry_at(base + 2 * CH + (uint32_t)ss0), enn1 = entry_at(base + 2 * CH + (uint32_t)ss1);
+      const float4 (*wS)[CH * 8] = stg[wv][cur];
+      const uint32_t* wR = srec[wv][cur];
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
+      auto step = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t rec, const int s) {
+        const bool blk_on = base + (uint32_t)s < todo;                 // this block still has an entry at this step
+        const uint32_t pos = todo - 1u - (base + (uint32_t)s);          // 0-based index in the block's list (garbage when !blk_on)
+        const float dy = A.y - pyf;
+        float u_[2], udx_[2], udxx_[2], w_[2];
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, cz = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          const float dx = A.x - (p == 0 ? pxf0 : pxf1);
+          const float power = splat_power(dx, dy, A.z, A.w, B.x);
+          const float G = __expf(power);
+          const float alpha = fminf(0.99f, B.y * G);
+          const bool valid = blk_on && (pos < lastc[p]) && !(power > 0.f) && !(alpha < ALPHA_MIN);
+          const float a_eff = valid ? alpha : 0.f;
+          const float G_eff = valid ? G : 0.f;
+          const float r = __builtin_amdgcn_rcpf(1.f - a_eff);
+          Tr[p] *= r;                                                   // transmittance in front of this splat
+          const float w = a_eff * Tr[p];
+          // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: the dL-weighted colour behind is ONE running scalar
+          float qd = B.z * dL[p][0];
+          qd = fmaf(B.w, dL[p][1], qd); qd = fmaf(Cc.x, dL[p][2], qd); qd = fmaf(Cc.y, dL[p][3], qd);
+          if (!Z45) { qd = fmaf(Cc.z, dL[p][4], qd); qd = fmaf(Cc.w, dL[p][5], qd); }
+          const float diff = qd - behind[p];
+          behind[p] = fmaf(a_eff, diff, behind[p]);
+          const float dLa = diff * Tr[p] - Tf_bg[p] * r;
+          const float u = B.y * dLa * G_eff;                           // dL/dG * G: its moments give d/dxy and d/dconic
+          u_[p] = u; udx_[p] = u * dx; udxx_[p] = udx_[p] * dx; w_[p] = w;
+          if (MODE == 1) { p0 = fmaf(w, dL[p][0], p0); p1 = fmaf(w, dL[p][1], p1); p2 = fmaf(w, dL[p][2], p2); }
+          cz = fmaf(w, Z45 ? dL[p][3] : fmaf(2.f * Cc.y, dL[p][5], dL[p][3]), cz);   // d/dz of the [z, 1, z^2] bundle, chained here
+        }
+        const float U0 = u_[0] + u_[1], U1 = udx_[0] + udx_[1], U2 = udxx_[0] + udxx_[1];
+        // y-moments about the splat centre: dy is this lane's constant of the step
+        float vals[MODE == 1 ? 10 : 7];
+        if constexpr (MODE == 1) {
+          vals[0] = U0; vals[1] = U1; vals[2] = U2; vals[3] = p0; vals[4] = p1; vals[5] = p2; vals[6] = cz;
+          vals[7] = U0 * dy; vals[8] = U1 * dy; vals[9] = vals[7] * dy;
+        } else {
+          vals[0] = U0; vals[1] = U1; vals[2] = U2; vals[3] = cz; vals[4] = U0 * dy; vals[5] = U1 * dy; vals[6] = vals[4] * dy;
+        }
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+          for (int q = 0; q < (MODE == 1 ? 10 : 7); q++) {
+            float v = vals[q];
+            v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+            v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+            v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+            vals[q] = v;
+          }
+        }
+        // every lane of the block holds the record: its first lane stores it (the only writer of the (block, splat) record)
+        if (blk_on && (lane & 7) == 0) {
+          float* r = dsub + (size_t)rec * RECF;
+          const float4 R0 = make_float4(vals[0], vals[1], vals[2], vals[3]);
+          st_part(r, R0, 4);
+          if constexpr (MODE == 1) {
+            st_part(r + 4, make_float4(vals[4], vals[5], vals[6], vals[7]), 4);
+            st_part(r + 8, make_float4(vals[8], vals[9], 0.f, 0.f), 2);
+          } else {
+            st_part(r + 4, make_float4(vals[4], vals[5], vals[6], 0.f), 3);
+          }
+        }
+      };
+      // two register sets used alternately: the next step's LDS reads are in flight while the current one is evaluated
+      float4 A0 = wS[0][bq], B0 = wS[1][bq], C0 = wS[2][bq];
+      uint32_t t0 = wR[bq];
+      for (int s = 0; s < cnt; s += 2) {
+        const int s1 = s + 1 < cnt ? s + 1 : s;
+        const float4 A1 = wS[0][s1 * 8 + bq], B1 = wS[1][s1 * 8 + bq], C1 = wS[2][s1 * 8 + bq];
+        const uint32_t t1 = wR[s1 * 8 + bq];
+        step(A0, B0, C0, t0, s);
+        if (s + 1 < cnt) {
+          const int s2 = s + 2 < cnt ? s + 2 : s1;
+          A0 = wS[0][s2 * 8 + bq]; B0 = wS[1][s2 * 8 + bq]; C0 = wS[2][s2 * 8 + bq];
+          t0 = wR[s2 * 8 + bq];
+          step(A1, B1, C1, t1, s1);
+        }
+      }
+      stg[wv][cur ^ 1][0][lane] = rn0.A; stg[wv][cur ^ 1][1][lane] = rn0.B; stg[wv][cur ^ 1][2][lane] = rn0.C; srec[wv][cur ^ 1][lane] = en0.y;
+      stg[wv][cur ^ 1][0][lane + 64] = rn1.A; stg[wv][cur ^ 1][1][lane + 64] = rn1.B; stg[wv][cur ^ 1][2][lane + 64] = rn1.C;
+      srec[wv][cur ^ 1][lane + 64] = en1.y;
+      en0 = enn0; en1 = enn1;
+    }
+  };
+  if (z45_wave) run_chunks(std::true_type{});
+  else run_chunks(std::false_type{});
+}
+
+
 // ---- third generation: ONE pixel per lane (the first generation's 4800 waves at 640x480: 4.7 per SIMD cover the in-order
 // stalls that 2.3 could not), the matrix-core block reduction of the second.  A wave = an 8x8 sub-tile = four blocks; lane =
 // (k, b, x): k = lane / 16 the pixel row inside the block, b = (lane % 16) / 4 the block, x = lane % 4 the pixel column.  The MFMA
@@ -474,6 +698,13 @@ void launch_composite_bwd2_slam(const CamDev& cam, bool tracking, GeomView g, Im
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
+  if (gen == 4) {
+    if (tracking)
+      hipLaunchKernelGGL((composite_bwd4_kernel<2>), dim3(grid), dim3(128), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+    else
+      hipLaunchKernelGGL((composite_bwd4_kernel<1>), dim3(grid), dim3(128), 0, s, cam, g, iv, b, ncap, dL, dsub, 0, none, dl_planes);
+    return;
+  }
   if (gen == 3) {
     if (tracking)
       hipLaunchKernelGGL((composite_bwd3_kernel<2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);

@@ -644,7 +644,7 @@ def eng_grads(eng, g):
     return eng.grads
 
 
-@pytest.mark.parametrize("gen", ["2", "3"])
+@pytest.mark.parametrize("gen", ["2", "3", "4"])
 @pytest.mark.parametrize("mode", ["map", "track"])
 def test_second_generation_backward_compositor_matches_the_first(mode, gen, monkeypatch):
     """composite_bwd2_kernel (2 pixels per lane, MFMA block reduction, y-moments about the block centre shifted in the gather)
@@ -655,7 +655,7 @@ def test_second_generation_backward_compositor_matches_the_first(mode, gen, monk
         with torch.no_grad():
             g._scaling += scale_up
         res = []
-        for flag in ("0", gen):      # MM3DGS_BWD2: 0 first generation, 2 / 3 the MFMA-reduction kernels (2 px / 1 px per lane)
+        for flag in ("0", gen):      # MM3DGS_BWD2: 0 first generation, 2 / 3 the MFMA-reduction kernels (2 px / 1 px per lane), 4 two px per lane + DPP
             monkeypatch.setenv("MM3DGS_BWD2", flag)
             eng = FusedEngine(R)
             si = eng.forward(pose, g, need_grads=True)
