@@ -293,6 +293,8 @@ int mm3dgs_covisibility_ratio(int H, int W, const float* depth /*[H,W]*/, const 
 #define MM3DGS_PROF_KERNELS 10
 void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 16th launch of the forward (sort +) compositor and of the backward compositors only */
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
+/* what the event pair adds to an interval it brackets (measured on empty kernels: 2 T(1 launch) - T(2 launches)); synchronises the stream */
+double mm3dgs_profile_event_overhead_ms(void* stream);
 
 const char* mm3dgs_last_error(void);
 int mm3dgs_version(void);   /* 100: round 1; 200: this header */

@@ -55,9 +55,33 @@ struct ProfScope {
   ~ProfScope() { if (on) (void)hipEventRecord(e1, s); }
 };
 
+__global__ void profile_null_kernel() {}
+
 extern "C" {
 
 void mm3dgs_profile_enable(int on) { g_prof_on = on; }
+// What an event pair adds to the interval it brackets: T1 = (event, kernel, event), T2 = (event, kernel, kernel, event) with an empty
+// kernel; T2 - T1 is what one more launch costs, so 2 T1 - T2 is the part of T1 that is not the launch.  Synchronises the stream.
+double mm3dgs_profile_event_overhead_ms(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.0;
+  double t[2] = {0.0, 0.0};
+  const int reps = 32;
+  for (int n = 1; n <= 2; n++) {
+    for (int r = 0; r < reps + 4; r++) {
+      (void)hipEventRecord(a, s);
+      for (int q = 0; q < n; q++) hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, s);
+      (void)hipEventRecord(b, s);
+      (void)hipEventSynchronize(b);
+      float ms = 0.f;
+      if (r >= 4 && hipEventElapsedTime(&ms, a, b) == hipSuccess) t[n - 1] += ms;
+    }
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  const double o = (2.0 * t[0] - t[1]) / reps;
+  return o > 0.0 ? o : 0.0;
+}
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
   if (kernel < 0 || kernel >= MM3DGS_PROF_KERNELS) return fail(-1, "bad kernel id %d", kernel);
   std::lock_guard<std::mutex> lk(g_prof_mu);
