@@ -150,53 +150,80 @@ def test_fused_tracker_and_mapper_follow_the_torch_graph_loops():
     assert b[3][1] < 0.01 and b[3][2] < 0.01, b[3]
 
 
-def test_fused_path_matches_float64_oracle():
-    """The fused kernels (pose transform, activations, depth bundle, chain rules) against the float64 CPU oracle driven
-    through the torch-graph Renderer: the strongest statement of parity for the SLAM path."""
+def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False):
+    """rel-L2 errors of the native SLAM path (pose transform, activations, depth bundle, compositors, chain rules: one fused forward +
+    backward with a random gradient image) against the float64 CPU oracle driven through the torch-graph Renderer.  direct: second
+    render of the engine (direct bins) instead of its first (packed bins).  floor: also the errors of the ORACLE evaluated in float32
+    against itself in float64 on the same scene (what float32 arithmetic costs there, whatever the implementation), as "f32:" keys."""
     import copy
-    import mm3dgs_slam_amd.pose_utils as P
+    import mm3dgs_slam_amd.pose_utils as P_
     import mm3dgs_slam_amd.renderer as rmod
     from mm3dgs_slam_amd.fused import FusedEngine
     from mm3dgs_slam_amd.renderer import Renderer
     from oracle.raster_ref import RefRasterizer
-    cfg, g, R, pose, color, depth = _setup(P=3000, H=120, W=160)
+    cfg, g, R, pose, color, depth = _setup(P=P, H=H, W=W, seed=seed)
     eng = FusedEngine(R)
     si = eng.forward(pose, g, need_grads=True)
     assert eng.check_capacity()
+    if direct:
+        si = eng.forward(pose, g, need_grads=True)
+        assert eng.direct
     w = torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     eng.dL.copy_(w)
     eng.backward(si, grads=eng.grads, dpose=eng.dpose)
-
-    class PC:
-        active_sh_degree = 0
-        max_sh_degree = 0
-    pc = PC()
+    assert eng.check_capacity()
     keys = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
-    leaf = {k: getattr(g, k).detach().double().cpu().requires_grad_(True) for k in keys}
-    pc._xyz, pc._scaling, pc._rotation = leaf["_xyz"], leaf["_scaling"], leaf["_rotation"]
-    pc.get_xyz, pc.get_opacity, pc.get_scaling = leaf["_xyz"], torch.sigmoid(leaf["_opacity"]), torch.exp(leaf["_scaling"])
-    pc.get_rotation, pc.get_features = torch.nn.functional.normalize(leaf["_rotation"]), leaf["_features_dc"]
     ccfg = copy.deepcopy(cfg)
     ccfg["device"] = "cpu"
-    Rc = Renderer(ccfg, rasterizer_cls=RefRasterizer)
-    Rc.projection_matrix, Rc.background, Rc._eye = Rc.projection_matrix.double(), Rc.background.double(), Rc._eye.double()
-    orig = rmod.get_camera_from_tensor
 
-    def cam64(t):     # the float64 twin of get_camera_from_tensor (which casts to float32 like the reference does)
-        return torch.cat([torch.cat([P.quad2rotation(t[None, :4])[0], t[4:7, None]], 1),
-                          torch.tensor([[0.0, 0, 0, 1]], dtype=t.dtype)], 0)
-    rmod.get_camera_from_tensor = cam64
-    try:
-        p64 = pose.detach().double().cpu().requires_grad_(True)
-        r64 = Rc.render(pc, p64)
-        ref = torch.cat([r64["render"], r64["depth"]], 0)
-        (ref * w.double().cpu()).sum().backward()
-    finally:
-        rmod.get_camera_from_tensor = orig
-    assert pu.rel_l2(eng.out, ref) <= pu.IMG_TOL
-    assert pu.rel_l2(eng.dpose, p64.grad) <= 1e-5          # north_star: pose gradients <= 1e-5
-    for name, key in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation")):
-        assert pu.rel_l2(eng.grads[name], leaf[key].grad) <= pu.GRAD_TOL, name
+    def oracle(dt):
+        class PC:
+            active_sh_degree = 0
+            max_sh_degree = 0
+        pc = PC()
+        leaf = {k: getattr(g, k).detach().to(dt).cpu().requires_grad_(True) for k in keys}
+        pc._xyz, pc._scaling, pc._rotation = leaf["_xyz"], leaf["_scaling"], leaf["_rotation"]
+        pc.get_xyz, pc.get_opacity, pc.get_scaling = leaf["_xyz"], torch.sigmoid(leaf["_opacity"]), torch.exp(leaf["_scaling"])
+        pc.get_rotation, pc.get_features = torch.nn.functional.normalize(leaf["_rotation"]), leaf["_features_dc"]
+        Rc = Renderer(ccfg, rasterizer_cls=RefRasterizer)
+        Rc.projection_matrix, Rc.background, Rc._eye = Rc.projection_matrix.to(dt), Rc.background.to(dt), Rc._eye.to(dt)
+        orig = rmod.get_camera_from_tensor
+
+        def cam(t):     # the dtype-preserving twin of get_camera_from_tensor (which casts to float32 like the reference does)
+            return torch.cat([torch.cat([P_.quad2rotation(t[None, :4])[0], t[4:7, None]], 1),
+                              torch.tensor([[0.0, 0, 0, 1]], dtype=t.dtype)], 0)
+        rmod.get_camera_from_tensor = cam
+        try:
+            p_ = pose.detach().to(dt).cpu().requires_grad_(True)
+            r_ = Rc.render(pc, p_)
+            ref_ = torch.cat([r_["render"], r_["depth"]], 0)
+            (ref_ * w.to(dt).cpu()).sum().backward()
+        finally:
+            rmod.get_camera_from_tensor = orig
+        return ref_.detach(), p_.grad, {k: leaf[k].grad for k in keys}
+
+    ref, dp, lg = oracle(torch.float64)
+    names = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation"))
+    m = {"img": pu.rel_l2(eng.out, ref), "d_pose": pu.rel_l2(eng.dpose, dp)}
+    for name, key in names:
+        m["d_" + name] = pu.rel_l2(eng.grads[name], lg[key])
+    if floor:
+        ref32, dp32, lg32 = oracle(torch.float32)
+        m["f32:img"], m["f32:d_pose"] = pu.rel_l2(ref32, ref), pu.rel_l2(dp32, dp)
+        for name, key in names:
+            m["f32:d_" + name] = pu.rel_l2(lg32[key], lg[key])
+    return m
+
+
+@pytest.mark.parametrize("seed,direct", [(0, False), (0, True), (3, True)])
+def test_fused_path_matches_float64_oracle(seed, direct):
+    """The fused kernels against the float64 CPU oracle: the strongest statement of parity for the SLAM path (packed and direct bins)."""
+    m = native_vs_oracle(seed, direct)
+    assert m["img"] <= pu.IMG_TOL, m
+    assert m["d_pose"] <= 1e-5, m          # north_star: pose gradients <= 1e-5
+    for k, v in m.items():
+        if k.startswith("d_") and k != "d_pose":
+            assert v <= pu.GRAD_TOL, (k, m)
 
 
 def _window_worker(rank, world, port, out):
