@@ -223,17 +223,27 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
                     float* loss4, void* backward_scratch, const Mm3dgsSlamGrads* grads_stats, const Mm3dgsMapAdam* map_adam,
                     void* stream);
 
-/* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:856-873,
+/* Image losses with the gradient image as output (slam/tracker.py:104-155, slam/mapper.py:836-873,
  * utils/loss_utils.py): w_l1 * mean|rgb-gt| (optionally over silhouette > sil_thr) + w_ssim * (1 - SSIM 11x11)
- * + w_pearson * (1 - rho(depth, ref)).  loss[4] = {total, l1, 1-ssim, 1-rho}.  work: mm3dgs_loss_work_bytes(). */
+ * + w_pearson * (1 - rho(depth, ref)).  loss[4] = {total, l1, 1-ssim, 1-rho}.  work: mm3dgs_loss_work_bytes().
+ * The `method: splatam` losses (slam/tracker.py:110-126, slam/mapper.py:836-855) add a depth term and masked sums:
+ *   + w_depth_l1 * mean|ref - depth| over depth_l1_mask;  l1_sum = 1 turns both L1 means into sums over their masks
+ * (tracking: l1_mask = depth_l1_mask = 3, l1_sum = 1, w_l1 = 0.5, w_depth_l1 = 1;  mapping: depth_l1_mask = 2, w_depth_l1 = 1,
+ * w_l1 = 0.5 (1 - lambda), w_ssim = 0.5 lambda).  The depth-L1 and Pearson terms are exclusive (they share the partial-sum
+ * columns); with w_depth_l1 != 0, loss[3] is the depth term.  The reference's NaN masks are not modelled: this renderer
+ * produces no NaN.  Configurations that use the three splatam fields run the loss as its own launches (not folded into the
+ * compositors). */
 typedef struct Mm3dgsLossConfig {
   int32_t H, W;
   float w_l1, w_ssim, w_pearson;
-  int32_t l1_mask;        /* 0 all pixels, 1 silhouette > sil_thr                                        */
+  int32_t l1_mask;        /* bit0 silhouette > sil_thr, bit1 ref > 0 (0: all pixels)                     */
   int32_t pearson_mask;   /* bit0 silhouette > sil_thr, bit1 ref > 0                                     */
   int32_t pearson_invert; /* 1: min over targets -ref and 1/(ref+200) (utils/loss_utils.py:53-57)        */
   float sil_thr;
   float window[11];       /* normalised 1-D Gaussian window (sigma 1.5), as utils/loss_utils.py:95-112    */
+  float w_depth_l1;       /* weight of the depth-L1 term (0: none)                                       */
+  int32_t depth_l1_mask;  /* bit0 silhouette > sil_thr, bit1 ref > 0                                     */
+  int32_t l1_sum;         /* 1: the colour and depth L1 terms are sums over their masks, not means       */
 } Mm3dgsLossConfig;
 size_t mm3dgs_loss_work_bytes(int H, int W);
 int mm3dgs_loss(const Mm3dgsLossConfig* cfg, const float* out6, const float* gt_color, const float* ref_depth_or_null,
@@ -297,7 +307,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 double mm3dgs_profile_event_overhead_ms(void* stream);
 
 const char* mm3dgs_last_error(void);
-int mm3dgs_version(void);   /* 100: round 1; 200: this header */
+int mm3dgs_version(void);   /* 100: round 1; 200: direct bins; 201: this header (Mm3dgsLossConfig grew by three fields) */
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ class Mm3dgsMapView(C.Structure):
 class Mm3dgsLossConfig(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_pearson", C.c_float),
                 ("l1_mask", C.c_int32), ("pearson_mask", C.c_int32), ("pearson_invert", C.c_int32), ("sil_thr", C.c_float),
-                ("window", C.c_float * 11)]
+                ("window", C.c_float * 11), ("w_depth_l1", C.c_float), ("depth_l1_mask", C.c_int32), ("l1_sum", C.c_int32)]
 
 
 class Mm3dgsAdamGroup(C.Structure):

@@ -101,7 +101,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
 }
 
 const char* mm3dgs_last_error(void) { return g_err; }
-int mm3dgs_version(void) { return 200; }   // 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points
+int mm3dgs_version(void) { return 201; }   // 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields
 
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
@@ -378,7 +378,17 @@ static LossCfg loss_cfg_dev(const Mm3dgsLossConfig* c) {
   lc.H = c->H; lc.W = c->W; lc.w_l1 = c->w_l1; lc.w_ssim = c->w_ssim; lc.w_pearson = c->w_pearson; lc.l1_mask = c->l1_mask;
   lc.pearson_mask = c->pearson_mask; lc.pearson_invert = c->pearson_invert; lc.sil_thr = c->sil_thr;
   for (int i = 0; i < 11; i++) lc.window[i] = c->window[i];
+  lc.w_depth = c->w_depth_l1; lc.depth_mask = c->depth_l1_mask; lc.l1_sum = c->l1_sum;
   return lc;
+}
+// the splatam forms of the losses (depth-L1 term, colour L1 over { ref > 0 }, sums instead of means) exist in the standalone loss
+// kernels only: a configuration that uses them is never folded into the compositors
+static bool loss_is_variant(const Mm3dgsLossConfig* c) { return c->w_depth_l1 != 0.f || c->l1_sum != 0 || (c->l1_mask & 2) != 0; }
+static int loss_cfg_check(const Mm3dgsLossConfig* c, const float* ref) {
+  if (c->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
+  if ((c->w_depth_l1 != 0.f || (c->l1_mask & 2)) && !ref) return fail(-2, "depth-L1 term / { ref > 0 } mask needs a reference depth");
+  if (c->w_depth_l1 != 0.f && c->w_pearson != 0.f) return fail(-2, "the depth-L1 and Pearson terms are exclusive");
+  return 0;
 }
 size_t mm3dgs_loss_work_bytes(int H, int W) {
   return 256 + align_up((size_t)9 * H * W * 4, 256) + align_up(loss_rows(H, W) * 12 * 8, 256);
@@ -389,7 +399,7 @@ int mm3dgs_loss(const Mm3dgsLossConfig* c, const float* out6, const float* gt_co
   if (!c || !out6 || !gt_color || !work || !dL) return fail(-1, "NULL argument");
   if (c->H <= 0 || c->W <= 0) return fail(-1, "bad image size");
   if ((double)c->H * c->W * 36.0 >= 4294967296.0) return fail(-1, "image too large for the loss kernels' 32-bit offsets");
-  if (c->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
+  if (int rc = loss_cfg_check(c, ref)) return rc;
   LossCfg lc = loss_cfg_dev(c);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MM3DGS_PROF_LOSS, s);
@@ -408,11 +418,11 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   Mm3dgsSlamGrads none;
   memset(&none, 0, sizeof(none));
   if (!loss_cfg || !gt_color || !loss_work || !dL_dout) return fail(-1, "NULL argument");
-  if (loss_cfg->w_pearson != 0.f && !ref) return fail(-2, "Pearson term needs a reference depth");
+  if (int rc = loss_cfg_check(loss_cfg, ref)) return rc;
   // without SSIM every loss term is per pixel: fold the loss into the compositors (two launches and the gradient image
   // round trip less per iteration); needs the sort + forward-composite kernel (its workgroup = one 16x16 loss tile)
   const int no_fold = env_flag("MM3DGS_NO_FOLDED_LOSS", 0);   // read per call: tests compare both paths in one process
-  const bool fold = !no_fold && loss_cfg->w_ssim == 0.f && slam_fused_sort(fwd_flags) && cam->image_height > 0 && cam->image_width > 0;
+  const bool fold = !no_fold && !loss_is_variant(loss_cfg) && loss_cfg->w_ssim == 0.f && slam_fused_sort(fwd_flags) && cam->image_height > 0 && cam->image_width > 0;
   TrackLoss tl = {};
   if (fold) {
     tl.cfg = loss_cfg_dev(loss_cfg);
@@ -467,7 +477,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   // Pearson rows, the SSIM kernel's extra workgroup reduces them, and the gradient image has four planes: two launches per
   // iteration for the loss instead of three (no finishing launch), the loss values only once, at the end of the run
   const int no_rows = env_flag("MM3DGS_NO_FORWARD_ROWS", 0);   // read per call: tests compare both paths in one process
-  const bool rows = n_iter > 0 && !no_rows && loss_cfg->w_ssim != 0.f && slam_fused_sort(fwd_flags) && loss_cfg->H == cam->image_height &&
+  const bool rows = n_iter > 0 && !no_rows && !loss_is_variant(loss_cfg) && loss_cfg->w_ssim != 0.f && slam_fused_sort(fwd_flags) && loss_cfg->H == cam->image_height &&
                     loss_cfg->W == cam->image_width;
   TrackLoss tl = {};
   LossCfg lc = {};
@@ -482,6 +492,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
     if (loss_cfg->w_pearson != 0.f && !views[it].ref_depth_or_null) return fail(-2, "view %d: Pearson term needs a reference depth", it);
+    if ((loss_cfg->w_depth_l1 != 0.f || (loss_cfg->l1_mask & 2)) && !views[it].ref_depth_or_null) return fail(-2, "view %d: depth-L1 term needs a reference depth", it);
     si.pose = views[it].pose;
     int rc;
     if (rows) {

@@ -22,6 +22,10 @@ struct LossCfg {
   int l1_mask, pearson_mask, pearson_invert;
   float sil_thr;
   float window[11];
+  // `method: splatam` forms (standalone loss kernels only; api.hip never folds such a configuration into the compositors):
+  float w_depth;       // weight of the depth-L1 term |ref - depth| over depth_mask (bit0 silhouette > sil_thr, bit1 ref > 0)
+  int depth_mask;
+  int l1_sum;          // the L1 terms are sums over their masks instead of means;  l1_mask bit1: ref > 0
 };
 
 // A tracking iteration without SSIM folds the per-pixel loss into the compositors (mm3dgs_slam_track): the forward epilogue

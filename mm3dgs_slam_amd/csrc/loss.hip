@@ -73,6 +73,34 @@ __device__ __forceinline__ void pearson_scalars(const double* tot, int pearson_o
   sums[16] = valid; sums[17] = use2; sums[18] = rho; sums[19] = k1; sums[20] = k2; sums[21] = mx; sums[22] = mt; sums[23] = loss_p;
 }
 
+// ---- `method: splatam` forms of the per-pixel terms (slam/tracker.py:110-126, slam/mapper.py:836-855) ----------------------------
+// colour L1 over { silhouette > thr } and / or { ref > 0 }, a depth-L1 term |ref - depth| over its own mask, both as means or as
+// sums.  Row columns: [0] colour L1 sum, [1] its pixel count, [3] depth pixel count, [4] depth L1 sum -- the first two Pearson
+// columns, which is why the API refuses the two terms together.  Only the standalone kernels of this file know these forms.
+__device__ __forceinline__ bool loss_variant(const LossCfg& cfg) { return cfg.w_depth != 0.f || cfg.l1_sum != 0 || (cfg.l1_mask & 2) != 0; }
+__device__ __forceinline__ unsigned loss_double_cols(const LossCfg& cfg) { return pearson_double_cols(cfg) | (cfg.w_depth != 0.f ? 0x10u : 0u); }
+__device__ __forceinline__ void variant_px_sums(const LossCfg& cfg, float l1, float sil, float depth, float refv, double (&acc)[12]) {
+  const bool smask = sil > cfg.sil_thr;
+  const bool on = loss_mask_on(cfg.l1_mask, smask, refv);
+  acc[0] = on ? (double)l1 : 0.0;
+  acc[1] = on ? 1.0 : 0.0;
+  if (cfg.w_depth != 0.f) {
+    const bool don = loss_mask_on(cfg.depth_mask, smask, refv);
+    acc[3] = don ? 1.0 : 0.0;
+    acc[4] = don ? fabs((double)refv - (double)depth) : 0.0;
+  }
+}
+// {total, colour l1, 1-ssim, depth term (or 1-rho)} of a configuration with these forms
+__device__ __forceinline__ void variant_scalars(const LossCfg& cfg, const double* sums, size_t HW, float* loss) {
+  const double n_l1 = sums[1], n_d = sums[3];
+  const double l1 = cfg.l1_sum ? sums[0] : (n_l1 > 0.0 ? sums[0] / (3.0 * n_l1) : 0.0);
+  const double ss = cfg.w_ssim != 0.f ? 1.0 - sums[2] / (3.0 * (double)HW) : 0.0;
+  const double loss_p = (cfg.w_pearson != 0.f && sums[16] != 0.0) ? sums[23] : 0.0;
+  const double dl = cfg.w_depth != 0.f ? (cfg.l1_sum ? sums[4] : (n_d > 0.0 ? sums[4] / n_d : 0.0)) : 0.0;
+  loss[1] = (float)l1; loss[2] = (float)ss; loss[3] = (float)(cfg.w_depth != 0.f ? dl : loss_p);
+  loss[0] = (float)(cfg.w_l1 * l1 + cfg.w_ssim * ss + cfg.w_pearson * loss_p + cfg.w_depth * dl);
+}
+
 // ---- SSIM moments and derivative maps ---------------------------------------------------------------------------------------
 template <bool ROWS>
 __global__ void __launch_bounds__(256, 5)   // >= 5 waves per SIMD: the whole 1200-workgroup grid of a 640x480 image in one round
@@ -193,10 +221,13 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
       // (the L1 sum was taken from the staged channels; loss_px_sums only needs it and the depth / silhouette / reference)
       const float sil = out[4 * HW + pix];
       const float rgb[3] = {l1, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
-      loss_px_sums(cfg, rgb, sil, cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
+      const bool var = loss_variant(cfg), need = cfg.w_pearson != 0.f || var;
+      const float depth = need ? out[3 * HW + pix] : 0.f, refv = (need && ref) ? ref[pix] : 0.f;
+      loss_px_sums(cfg, rgb, sil, depth, g3, refv, acc);
+      if (var) variant_px_sums(cfg, l1, sil, depth, refv, acc);
     }
     acc[2] = (double)ssim_sum;
-    block_sums<12>(acc, red, pearson_double_cols(cfg));
+    block_sums<12>(acc, red, loss_double_cols(cfg));
     if (tid == 0) {
       double* row = partial + (size_t)tile * 12;
 #pragma unroll
@@ -227,9 +258,12 @@ loss_rows_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
   if (inside) {
     const float rgb[3] = {out[pix], out[HW + pix], out[2 * HW + pix]}, g3[3] = {gt[pix], gt[HW + pix], gt[2 * HW + pix]};
-    loss_px_sums(cfg, rgb, out[4 * HW + pix], cfg.w_pearson != 0.f ? out[3 * HW + pix] : 0.f, g3, cfg.w_pearson != 0.f ? ref[pix] : 0.f, acc);
+    const bool var = loss_variant(cfg), need = cfg.w_pearson != 0.f || var;
+    const float sil = out[4 * HW + pix], depth = need ? out[3 * HW + pix] : 0.f, refv = (need && ref) ? ref[pix] : 0.f;
+    loss_px_sums(cfg, rgb, sil, depth, g3, refv, acc);
+    if (var) variant_px_sums(cfg, fabsf(rgb[0] - g3[0]) + fabsf(rgb[1] - g3[1]) + fabsf(rgb[2] - g3[2]), sil, depth, refv, acc);
   }
-  block_sums<12>(acc, red, pearson_double_cols(cfg));
+  block_sums<12>(acc, red, loss_double_cols(cfg));
   if (threadIdx.x == 0) {
     double* row = partial + (size_t)tile * 12;
 #pragma unroll
@@ -272,20 +306,24 @@ __global__ void __launch_bounds__(1024) loss_finish_kernel(LossCfg cfg, const do
   __syncthreads();
   if (threadIdx.x == 0) {
     pearson_scalars(tot, cfg.w_pearson != 0.f ? 1 : 0, cfg.pearson_invert, sums);
-    if (loss4) loss_scalars(cfg, sums, (size_t)cfg.H * cfg.W, loss4);
+    if (loss4) {
+      if (loss_variant(cfg)) variant_scalars(cfg, sums, (size_t)cfg.H * cfg.W, loss4);
+      else loss_scalars(cfg, sums, (size_t)cfg.H * cfg.W, loss4);
+    }
   }
 }
 
 // ---- gradient image ------------------------------------------------------------------------------------------------------------
 // write6: also store zeros to the silhouette / depth^2 planes (no loss term reaches them).  (In the mapping loop this whole pass
 // runs inside the backward compositor's prologue instead: loss_tile.h, composite.hip.)
+template <bool VAR>
 __global__ void __launch_bounds__(256)
 loss_grad_kernel(LossCfg cfg, const float* __restrict__ out, const float* __restrict__ gt, const float* __restrict__ ref,
                  const float* __restrict__ dmaps, const double* __restrict__ sums, float* __restrict__ dL, int tiles_x, int write6) {
   __shared__ __align__(16) LossGradSmem sm;
   float g4[4];
   bool inside;
-  loss_grad_tile(cfg, out, gt, ref, dmaps, sums, blockIdx.x, tiles_x, sm, g4, inside);
+  loss_grad_tile<VAR>(cfg, out, gt, ref, dmaps, sums, blockIdx.x, tiles_x, sm, g4, inside);
   if (inside) {
     const int px = (blockIdx.x % tiles_x) * LT + (threadIdx.x & 15), py = (blockIdx.x / tiles_x) * LT + (threadIdx.x >> 4);
     const size_t HW = (size_t)cfg.H * cfg.W, pix = (size_t)py * cfg.W + px;
@@ -311,7 +349,8 @@ void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const fl
   else
     hipLaunchKernelGGL(loss_rows_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, partial, tx);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, cfg, partial, T, sums, loss);
-  hipLaunchKernelGGL(loss_grad_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 1);
+  const bool var = cfg.w_depth != 0.f || cfg.l1_sum != 0 || (cfg.l1_mask & 2) != 0;     // the `method: splatam` forms
+  hipLaunchKernelGGL(var ? loss_grad_kernel<true> : loss_grad_kernel<false>, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 1);
 }
 
 // mapping-loop form (mm3dgs_slam_map): the forward compositor's epilogue already wrote the L1 / Pearson rows of this render.
@@ -322,5 +361,5 @@ void launch_loss_after_forward_rows(const LossCfg& cfg, const float* out, const 
   const int T = loss_tiles(cfg), tx = loss_tiles_x(cfg);
   hipLaunchKernelGGL(ssim_maps_kernel<false>, dim3(T + 1), dim3(256), 0, s, cfg, out, gt, ref, dmaps, partial, sums, tx, T);
   if (dL)   // NULL: the caller runs the gradient pass inside the backward compositor (composite.hip)
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 0);
+    hipLaunchKernelGGL(loss_grad_kernel<false>, dim3(T), dim3(256), 0, s, cfg, out, gt, ref, dmaps, sums, dL, tx, 0);
 }

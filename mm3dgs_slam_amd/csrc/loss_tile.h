@@ -41,7 +41,11 @@ __device__ __forceinline__ HaloIdx halo_index(const LossCfg& cfg, int x0, int y0
 // adjoint 11x11 convolution of the SSIM derivative maps (one colour channel at a time through `sD` / `hD`: two-output strips
 // horizontally, one output per lane vertically), L1 sign, Pearson gradient.  Every lane of the 256-lane workgroup must call it
 // (barriers inside).  Used by loss_grad_kernel and, folded into its prologue, by the mapping-mode backward compositor.
+// <VAR>: the `method: splatam` forms of the per-pixel terms (LossCfg: colour L1 over { ref > 0 } too, sums instead of means, depth-L1
+// term); only loss_grad_kernel instantiates it -- the compositor's prologue is never given such a configuration (api.hip).
 struct LossGradSmem { float sD[3][LW][SW]; float hD[3][LW][HW_]; };
+__device__ __forceinline__ bool loss_mask_on(int bits, bool smask, float refv) { return (!(bits & 1) || smask) && (!(bits & 2) || refv > 0.f); }
+template <bool VAR = false>
 __device__ __forceinline__ void loss_grad_tile(const LossCfg& cfg, const float* __restrict__ out, const float* __restrict__ gt,
                                                const float* __restrict__ ref, const float* __restrict__ dmaps, const double* __restrict__ sums,
                                                int tile, int tiles_x, LossGradSmem& sm, float (&g4)[4], bool& inside_out) {
@@ -118,9 +122,27 @@ __device__ __forceinline__ void loss_grad_tile(const LossCfg& cfg, const float* 
   inside_out = inside;
   if (inside) {
     const bool smask = sil > cfg.sil_thr;
+    if constexpr (VAR) {
+      const float refv = ref ? ref[pix] : 0.f, depth = out[3 * HW + pix];
+      const bool on = loss_mask_on(cfg.l1_mask, smask, refv);
+      const float sc = cfg.l1_sum ? cfg.w_l1 : l1_scale;          // d/dx of w sum|x - g|  or of  w mean|x - g| (3 n elements)
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) g4[ch] = gch[ch] + loss_px_l1_grad(cfg, oc[ch], gc[ch], smask, l1_scale);
-    // depth channel: Pearson; silhouette and depth^2 carry no loss
-    g4[3] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + pix], ref[pix], sums) : 0.f;
+      for (int ch = 0; ch < 3; ch++) {
+        const float d = oc[ch] - gc[ch];
+        g4[ch] = gch[ch] + (on ? sc * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 0.f);
+      }
+      g4[3] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, depth, refv, sums) : 0.f;
+      if (cfg.w_depth != 0.f && loss_mask_on(cfg.depth_mask, smask, refv)) {
+        // sums[3] = pixels of the depth mask, sums[4] = sum |ref - depth| (the Pearson columns: the two terms are exclusive)
+        const float dsc = cfg.l1_sum ? cfg.w_depth : (sums[3] > 0.0 ? cfg.w_depth / (float)sums[3] : 0.f);
+        const float d = depth - refv;
+        g4[3] += dsc * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) g4[ch] = gch[ch] + loss_px_l1_grad(cfg, oc[ch], gc[ch], smask, l1_scale);
+      // depth channel: Pearson; silhouette and depth^2 carry no loss
+      g4[3] = cfg.w_pearson != 0.f ? loss_px_pearson_grad(cfg, sil, out[3 * HW + pix], ref[pix], sums) : 0.f;
+    }
   }
 }

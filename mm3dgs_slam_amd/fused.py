@@ -5,9 +5,10 @@ collapsed into a handful of C-ABI calls with no host synchronisation inside the 
     mm3dgs_slam_forward  ->  mm3dgs_loss  ->  mm3dgs_slam_backward ( -> pose Adam on device | mm3dgs_adam )
 
 ``FusedTracker`` / ``FusedMapper`` subclass the torch-graph ``Tracker`` / ``Mapper`` and take over ``optimize_cam`` /
-``optimize_map`` when the configuration is the one both shipped configs use (``transform_means_python``, SH degree 0,
-no python SH / cov3D, method != splatam, no IMU loss term, no BA); anything else falls back to the torch-graph loop,
-which stays the parity reference for these kernels (tests/test_gpu_fused.py).
+``optimize_map`` when the pipeline is the one both shipped configs use (``transform_means_python``, SH degree 0 -- the
+reference never raises it --, no python SH / cov3D); the IMU residual, bundle adjustment and the ``method: splatam`` losses
+and pruning schedule run natively too.  Anything else (``keep_best_candidate``, BA with a sharded window) falls back to the
+torch-graph loop, which stays the parity reference for these kernels (tests/test_gpu_fused.py).
 """
 from __future__ import annotations
 
@@ -69,7 +70,7 @@ class FusedEngine:
     def eligible(cfg, gaussians):
         pipe = cfg["pipeline"]
         return (pipe["transform_means_python"] and not pipe["convert_SHs_python"] and not pipe["compute_cov3D_python"]
-                and gaussians.max_sh_degree == 0 and cfg["method"].lower() != "splatam" and str(cfg["device"]).startswith("cuda"))
+                and gaussians.max_sh_degree == 0 and str(cfg["device"]).startswith("cuda"))
 
     def _ensure(self, P, need_grads):
         if P != self.P:
@@ -212,10 +213,11 @@ class FusedEngine:
                                                  C.byref(map_adam) if map_adam is not None else None, self._flags(), _stream()))
 
 
-def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr):
+def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr, w_depth_l1=0.0, depth_l1_mask=0, l1_sum=0):
     c = _lib.Mm3dgsLossConfig()
     c.H, c.W, c.w_l1, c.w_ssim, c.w_pearson = H, W, w_l1, w_ssim, w_pearson
     c.l1_mask, c.pearson_mask, c.pearson_invert, c.sil_thr = l1_mask, pearson_mask, invert, sil_thr
+    c.w_depth_l1, c.depth_l1_mask, c.l1_sum = w_depth_l1, depth_l1_mask, l1_sum      # the `method: splatam` forms (include/mm3dgs.h)
     for i, v in enumerate(_WINDOW):
         c.window[i] = v
     return c
@@ -242,6 +244,10 @@ class FusedTracker(Tracker):
                 w_p = float(trk["pearson_weight"])
                 pmask, ref = (1, est_depth) if not self.cfg["use_gt_depth"] else (3, gt_depth)
             lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, w_p, 1, pmask, 1, 0.99)
+            if self.cfg["method"].lower() == "splatam":
+                # slam/tracker.py:110-126: sum |gt_depth - depth| + 0.5 sum |gt - image| over { gt_depth > 0, silhouette > 0.99 }
+                lcfg = _loss_cfg(eng.H, eng.W, 0.5, 0.0, 0.0, 3, 0, 0, 0.99, w_depth_l1=1.0, depth_l1_mask=3, l1_sum=1)
+                ref = gt_depth
             gt_color = gt_color.contiguous()
             ref = None if ref is None else ref.contiguous()
             g = self.gaussians
@@ -255,7 +261,7 @@ class FusedTracker(Tracker):
                 ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
                 ad.lr_q, ad.lr_t = float(trk["rotation_lr"]), float(trk["position_lr"])
                 ad.beta1, ad.beta2, ad.eps = 0.9, 0.999, 1e-8
-                if trk["use_imu_loss"]:      # rel_pose_loss against the pose the optimisation starts from (slam/tracker.py:87,146-155)
+                if trk["use_imu_loss"] and self.cfg["method"].lower() != "splatam":      # rel_pose_loss against the pose the optimisation starts from (slam/tracker.py:87,146-155; not in the splatam branch)
                     ad.prior_pose, ad.prior_w_t, ad.prior_w_q = pose0.data_ptr(), float(trk["imu_T_weight"]), float(trk["imu_q_weight"])
                 eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
                 if eng.check_capacity():
@@ -325,8 +331,14 @@ class FusedMapper(Mapper):
             else:
                 rdepth, sil = self._render_depth_sil(camera_pose)
                 err = (depth - rdepth).abs() * (depth > 0)
-                non_presence = ((sil < 0.5) | (err > 10 * err.median())).reshape(-1)
+                if self.cfg["method"].lower() == "splatam":     # slam/mapper.py:520-526: only surfaces IN FRONT of the map, 50 x median
+                    far = (rdepth > depth) & (err > 50 * err.median())
+                else:
+                    far = err > 10 * err.median()
+                non_presence = ((sil < 0.5) | far).reshape(-1)
             non_presence = non_presence & (depth > 0).reshape(-1)
+            if self.cfg["method"].lower() == "splatam" and not bool(non_presence.any()):
+                return None, non_presence.reshape(depth.shape)          # (slam/mapper.py:532,590-591)
             frac = float(self.cfg["mapping"].get("seed_fraction", 1.0))
             if frac < 1.0:     # workload knob (not in the reference): seed only a fixed pseudo-random subset of the pixels
                 gen = torch.Generator(device="cpu").manual_seed(1234 + idx)
@@ -354,6 +366,11 @@ class FusedMapper(Mapper):
             w_p = float(m["pearson_weight"])
             pmask = 0 if not self.cfg["use_gt_depth"] else 2
         lcfg = _loss_cfg(eng.H, eng.W, 1.0 - lam, lam, w_p, 0, pmask, 0, 0.5)
+        splatam = self.cfg["method"].lower() == "splatam"
+        if splatam:
+            # slam/mapper.py:836-855: mean |gt_depth - depth| over { gt_depth > 0 } + 0.5 ((1-l) L1 + l (1 - SSIM)); no Pearson term
+            w_p = 0.0
+            lcfg = _loss_cfg(eng.H, eng.W, 0.5 * (1.0 - lam), 0.5 * lam, 0.0, 0, 0, 0, 0.5, w_depth_l1=1.0, depth_l1_mask=2)
         stack = None
 
         def pop():
@@ -382,6 +399,8 @@ class FusedMapper(Mapper):
             ref = None
             if w_p:
                 ref = (est_depth if not self.cfg["use_gt_depth"] else gt_depth).contiguous()
+            if splatam:
+                ref = gt_depth.contiguous()
             buf = pose.detach().float().contiguous()
             # Reference quirk kept by default: slam/mapper.py:752-760 puts `keyframes[k].pose[:4].requires_grad_()` views into the pose
             # optimiser, but the loop renders from FRESH views `keyframe.pose[:4]` (:817-819) that do not require grad -- so the
@@ -401,6 +420,8 @@ class FusedMapper(Mapper):
             return buf, gt_color.contiguous(), ref, ad
 
         def prune_at(it):
+            if splatam:      # "Splatam does not densify -- only prunes" (slam/mapper.py:879-884): iterations 0 and 20, no size threshold
+                return it <= 20 and it % 20 == 0
             return it <= m["densify_until_iter"] and it >= m["densify_from_iter"] and it % m["pruning_interval"] == 0
 
         import random as _random
@@ -445,16 +466,21 @@ class FusedMapper(Mapper):
         self.mapping_iter_count += num_iter
 
     def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
+        splatam = self.cfg["method"].lower() == "splatam"       # prunes (prune_at), never collects densification statistics
+
+        def dens(it):
+            return (not splatam) and it <= m["densify_until_iter"]
+
         with torch.no_grad():
             iteration = 0
             while iteration < num_iter:
-                densify = iteration <= m["densify_until_iter"]
+                densify = dens(iteration)
                 if not multi and not prune_at(iteration):
                     # single GPU: the run of iterations up to the next pruning step (or the end of the densification phase)
                     # is enqueued by ONE C call -- no Python between the ~9 launches of an iteration
                     n = 1
                     while (iteration + n < num_iter and not prune_at(iteration + n)
-                           and (iteration + n <= m["densify_until_iter"]) == densify):
+                           and dens(iteration + n) == densify):
                         n += 1
                     views = [view_of(pop()) for _ in range(n)]
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
@@ -498,7 +524,7 @@ class FusedMapper(Mapper):
                 if prune_now:
                     # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
                     # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py)
-                    pruned = g.prune(m["min_opacity"], self.camera_extent, m["size_threshold"])
+                    pruned = g.prune(m["min_opacity"], self.camera_extent, None if splatam else m["size_threshold"])
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
                         self._opt_mask = self._opt_mask[~pruned].contiguous()
                 iteration += 1

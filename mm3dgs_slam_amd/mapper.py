@@ -213,8 +213,14 @@ class Mapper:
             result = self.renderer.render(self.gaussians, camera_pose=camera_pose)
             sil, rdepth = result["depth"][1], result["depth"][0]
             err = (depth - rdepth).abs() * (depth > 0)
-            non_presence = ((sil < 0.5) | (err > 10 * err.median())).reshape(-1)
+            if self.cfg["method"].lower() == "splatam":     # slam/mapper.py:520-526: only surfaces IN FRONT of the map, 50 x median
+                far = (rdepth > depth) & (err > 50 * err.median())
+            else:
+                far = err > 10 * err.median()
+            non_presence = ((sil < 0.5) | far).reshape(-1)
         non_presence = non_presence & (depth > 0).reshape(-1)
+        if self.cfg["method"].lower() == "splatam" and not bool(non_presence.any()):
+            return None, non_presence.reshape(depth.shape)          # (slam/mapper.py:532,590-591)
         frac = float(self.cfg["mapping"].get("seed_fraction", 1.0))
         if frac < 1.0:     # workload knob (not in the reference): seed only a fixed pseudo-random subset of the pixels
             gen = torch.Generator(device="cpu").manual_seed(1234 + idx)
