@@ -139,8 +139,9 @@ def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeyp
             self.calls.append(("check",))
             return True
 
-    for (d_from, d_until, interval, iters) in ((0, 50, 50, 150), (10, 30, 10, 45), (0, 0, 50, 7), (5, 100, 4, 12)):
-        cfg = default_config(device="cpu", height=24, width=32,
+    for (d_from, d_until, interval, iters, method) in ((0, 50, 50, 150, "vigs"), (10, 30, 10, 45, "vigs"), (0, 0, 50, 7, "vigs"), (5, 100, 4, 12, "vigs"),
+                                                       (0, 50, 50, 45, "splatam"), (0, 50, 50, 150, "splatam")):
+        cfg = default_config(device="cpu", height=24, width=32, method=method,
                              mapping={"iters": iters, "densify_from_iter": d_from, "densify_until_iter": d_until, "pruning_interval": interval})
         g = GaussianModel(cfg); g.training_setup()
         n = 50
@@ -156,15 +157,19 @@ def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeyp
         mp.optimize_map(3, iters, [-1], None, pose, torch.rand(3, 24, 32), torch.rand(24, 32), torch.rand(24, 32))
         # expected sequence from the per-iteration rule
         prune = lambda it: it <= d_until and it >= d_from and it % interval == 0
+        dens = lambda it: it <= d_until
+        if method == "splatam":     # slam/mapper.py:879-884: prunes at iterations 0 and 20, never collects densification statistics
+            prune = lambda it: it <= 20 and it % 20 == 0
+            dens = lambda it: False
         want, it, step = [], 0, 1
         while it < iters:
-            densify = it <= d_until
+            densify = dens(it)
             if prune(it):
                 want.append(("map_loop", 1, densify, None, True))     # gradients + statistics only: the Adam step is a no-op
                 it += 1
                 continue
             m = 1
-            while it + m < iters and not prune(it + m) and ((it + m) <= d_until) == densify:
+            while it + m < iters and not prune(it + m) and dens(it + m) == densify:
                 m += 1
             want.append(("map_loop", m, densify, step, False))
             step += m
