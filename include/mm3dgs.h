@@ -69,6 +69,8 @@ typedef struct Mm3dgsHeader {
                                  backward scratch, a workgroup that needs more sets `overflow` */
 } Mm3dgsHeader;
 
+struct Mm3dgsLossConfig;   /* defined with mm3dgs_loss below; the SLAM loop entry points take a pointer to it */
+
 /* ---- buffer sizing (pure host arithmetic) ------------------------------------------------------------- */
 size_t mm3dgs_geom_bytes(int P);                       /* per-Gaussian screen-space state               */
 size_t mm3dgs_image_bytes(int H, int W);               /* header + per-tile counters/ranges + per-pixel */

@@ -46,3 +46,30 @@ def test_drop_in_module_name():
     import diff_gaussian_rasterization as d
     assert d.GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier",
                                                        "viewmatrix", "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+
+
+def test_struct_layouts_of_the_binding_match_the_header(tmp_path):
+    """Every ctypes.Structure of the binding has the size and the field offsets the C compiler gives the struct of the same name in
+    include/mm3dgs.h (gcc on a generated probe; the header is plain C)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {n: c for n, c in vars(_lib).items() if isinstance(c, type) and issubclass(c, C.Structure) and n.startswith("Mm3dgs")}
+    assert len(structs) >= 10
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mm3dgs.h"', 'int main(void) {']
+    for n, c in sorted(structs.items()):
+        lines.append(f'  printf("{n} %zu\\n", sizeof({n}));')
+        for f in c._fields_:
+            lines.append(f'  printf("{n}.{f[0]} %zu\\n", offsetof({n}, {f[0]}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])     # (the header must be clean C)
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, c in structs.items():
+        assert int(got[n]) == C.sizeof(c), (n, got[n], C.sizeof(c))
+        for f in c._fields_:
+            assert int(got[f"{n}.{f[0]}"]) == getattr(c, f[0]).offset, (n, f[0])
