@@ -283,3 +283,71 @@ def test_splatam_window_ranks_keyframes_by_projected_overlap():
     assert sel[-1] == len(poses) - 1 and times == [10 * k for k in sel]
     assert len(sel) == 3                                           # kf_window_size - 2 overlapping ones + the last keyframe
     assert set(sel[:-1]) <= {0, 2, 4}                              # never the two that see nothing
+
+
+def test_native_loops_hand_the_reference_loss_of_each_method_to_the_c_loops(monkeypatch):
+    """FusedTracker / FusedMapper translate the loss branches of slam/tracker.py:104-155 and slam/mapper.py:836-873 into one
+    Mm3dgsLossConfig per loop: the shipped methods (masked mean-L1 [+ Pearson]; (1-l) L1 + l (1-SSIM) + Pearson) and `splatam`
+    (masked sums of depth-L1 + 0.5 colour-L1; mean depth-L1 over { gt_depth > 0 } + 0.5 photometric).  Control flow only: a recording
+    fake engine stands in for the kernels (which tests/test_gpu_fused.py checks against the torch losses)."""
+    import torch
+    from mm3dgs_slam_amd import fused
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+
+    class FakeEngine:
+        H, W = 24, 32
+        dev = "cpu"
+        def __init__(self):
+            self.track, self.maps, self.grads = [], [], {}
+            self.loss, self.out = torch.zeros(4), torch.zeros(6, 24, 32)
+        def track_loop(self, n, pose, g, lcfg, gt_color, ref, ad):
+            self.track.append((n, lcfg, ref, bool(ad.prior_pose)))
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+            self.maps.append((len(views), lcfg, [v[2] for v in views], stats is not None))
+        def _ensure(self, P, need_grads):
+            pass
+        def check_capacity(self):
+            return True
+
+    fields = ("w_l1", "w_ssim", "w_pearson", "l1_mask", "pearson_mask", "pearson_invert", "sil_thr", "w_depth_l1", "depth_l1_mask", "l1_sum")
+    as_dict = lambda c: {k: round(float(getattr(c, k)), 6) for k in fields}
+    gt_color, gt_depth = torch.rand(3, 24, 32), torch.rand(24, 32) + 0.5
+    for method in ("vigs", "splatam"):
+        cfg = default_config(device="cpu", height=24, width=32, method=method, tracking={"iters": 7, "use_depth_estimate_loss": True, "use_imu_loss": True,
+                                                                                        "imu_T_weight": 1.0, "imu_q_weight": 0.1},
+                             mapping={"iters": 9})
+        g = GaussianModel(cfg); g.training_setup()
+        n = 30
+        g.densification_postfix(torch.randn(n, 3), torch.randn(n, 1, 3), torch.zeros(n, 0, 3), torch.zeros(n, 1), torch.full((n, 3), -3.0),
+                                torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1), torch.rand(n, 3))
+        eng = FakeEngine()
+        monkeypatch.setattr(fused.FusedEngine, "eligible", staticmethod(lambda cfg, gaussians: True))
+        monkeypatch.setattr(fused, "_engine", lambda renderer: eng)
+        monkeypatch.setattr(GaussianModel, "_native", lambda self: False)
+        tr = fused.FusedTracker(cfg, g, renderer=None, estimate_pose_list=[None])
+        q, T = torch.tensor([1.0, 0, 0, 0]), torch.zeros(3)
+        tr.optimize_cam(1, 7, None, q, T, gt_color, gt_depth, None)
+        mp = fused.FusedMapper(cfg, g, renderer=None, estimate_pose_list=[None])
+        mp.camera_extent = 10.0
+        mp.optimize_map(3, 9, [-1], None, torch.tensor([1.0, 0, 0, 0, 0, 0, 0]), gt_color, gt_depth, None)
+        (n_it, lc, ref, prior), = eng.track
+        assert n_it == 7 and ref is not None and torch.equal(ref, gt_depth)
+        if method == "splatam":
+            assert as_dict(lc) == dict(w_l1=0.5, w_ssim=0.0, w_pearson=0.0, l1_mask=3.0, pearson_mask=0.0, pearson_invert=0.0, sil_thr=0.99,
+                                       w_depth_l1=1.0, depth_l1_mask=3.0, l1_sum=1.0)
+            assert not prior                                  # the IMU residual is not part of the splatam branch
+        else:
+            assert as_dict(lc) == dict(w_l1=1.0, w_ssim=0.0, w_pearson=0.05, l1_mask=1.0, pearson_mask=3.0, pearson_invert=1.0, sil_thr=0.99,
+                                       w_depth_l1=0.0, depth_l1_mask=0.0, l1_sum=0.0)
+            assert prior
+        assert sum(m[0] for m in eng.maps) == 9
+        for _, lc, refs, with_stats in eng.maps:
+            assert all(r is not None and torch.equal(r, gt_depth) for r in refs)
+            if method == "splatam":
+                assert as_dict(lc) == dict(w_l1=0.4, w_ssim=0.1, w_pearson=0.0, l1_mask=0.0, pearson_mask=0.0, pearson_invert=0.0, sil_thr=0.5,
+                                           w_depth_l1=1.0, depth_l1_mask=2.0, l1_sum=0.0)
+                assert not with_stats                         # splatam never collects densification statistics
+            else:
+                assert as_dict(lc) == dict(w_l1=0.8, w_ssim=0.2, w_pearson=0.05, l1_mask=0.0, pearson_mask=2.0, pearson_invert=0.0, sil_thr=0.5,
+                                           w_depth_l1=0.0, depth_l1_mask=0.0, l1_sum=0.0)
