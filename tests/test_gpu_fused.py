@@ -162,9 +162,10 @@ def test_fused_tracker_and_mapper_follow_the_torch_graph_loops(method):
     # two float32 pipelines + Adam: same trajectory, not the same bits (the torch graph's MIOpen convolutions are not even
     # run-to-run deterministic)
     assert (a[0] - b[0]).abs().max() < 4e-3, (a[0], b[0])
-    if method == "splatam" and a[1].shape != b[1].shape:
+    if method == "splatam":
         # splatam prunes by opacity inside the loop (iterations 0 and 20): a Gaussian within rounding of the 0.005 threshold may
-        # go either way, after which the two maps are no longer row-aligned -- compare the populations
+        # go either way (measured: 77169 against 77171 rows), after which the two maps are no longer row-aligned -- compare the
+        # populations
         na, nb = a[1].shape[0], b[1].shape[0]
         assert abs(na - nb) <= 1e-3 * na, (na, nb)
         qs = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95])
