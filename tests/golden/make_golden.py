@@ -21,6 +21,9 @@ G8 losses            utils/loss_utils.py: l1_loss (:64-68, with and without mask
                      textbook definition torchmetrics.functional.regression.pearson_corrcoef computes), so the
                      Pearson rows pin the reference's masking / min-of-two-targets logic, not torchmetrics' arithmetic.
 
+G9 (end-to-end runs of the reference's Tracker / Mapper / GaussianModel / Renderer classes) has its own generator:
+tests/golden/make_golden_slam.py.
+
     python tests/golden/make_golden.py            # everything
     python tests/golden/make_golden.py g8         # only the named fixture(s)
 """
