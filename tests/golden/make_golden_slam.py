@@ -14,7 +14,7 @@ keyframe picks, `np.random.permutation` window subsets), keyframe decisions and 
 the densification statistics, the pruning schedule and its interaction with Adam, both optimisers, pose propagation.
 
 Stored: the input frames and ground-truth poses (g9_frames.npz) and, per variant (g9_<variant>.npz: the shipped method, `method:
-splatam`, bundle adjustment, the UTMM-style IMU configuration), the configuration overrides and per frame the estimated pose, the keyframe indices, the number of
+splatam`, bundle adjustment, no sensor depth, the UTMM-style IMU configuration), the configuration overrides and per frame the estimated pose, the keyframe indices, the number of
 Gaussians and a few moments of the parameters; the final parameters, keyframe poses and covisibility graph in full."""
 import os
 import random
@@ -44,6 +44,10 @@ VARIANTS = {
     "ba": dict(tracking={"iters": 10}, mapping=dict(_MAP, do_BA=True)),
     # configs/UTMM.yml's hot-path settings: IMU dead-reckoning for the pose prediction (utils/pose_utils.py:148-200 inside
     # Tracker.run_frame), Pearson depth term in the tracking loss, isotropic Gaussians, 0.002 pose learning rates
+    # no sensor depth (use_gt_depth: false): the monocular estimate (here: a synthetic inverse-depth map) feeds the tracking Pearson term
+    # with its min-of-two-targets form (utils/loss_utils.py:43-61), its rescaled version (slam/SLAM.py:413-450 computes it; here
+    # given) seeds new Gaussians and feeds the mapping Pearson term
+    "estdepth": dict(use_gt_depth=False, tracking={"iters": 10, "use_depth_estimate_loss": True}, mapping=dict(_MAP)),
     "imu": dict(pipeline={"force_isotropic": True},
                 tracking={"iters": 10, "dynamics_model": "imu", "use_depth_estimate_loss": True, "pearson_weight": 0.001, "position_lr": 0.002,
                           "rotation_lr": 0.002},
@@ -70,13 +74,18 @@ def make_frames():
     frames = [(c.clone(), d.clone()) for c, d in seq.frames]
     gt_poses = torch.stack([p.clone() for p in seq.poses])
     imu = torch.stack([seq.imu(i) if i else torch.zeros_like(seq.imu(1)) for i in range(N_FRAMES)])     # synthetic 100 Hz rows per frame interval
+    # stand-ins for the monocular network's output (inverse-depth-like, arbitrary scale) and for its rescaled version
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    est = [1000.0 / (d + 0.5 + 0.05 * torch.sin(xx / 5.0 + i)) for i, (_, d) in enumerate(frames)]
+    est_scaled = [torch.where(d > 0, d * (1.0 + 0.03 * torch.sin(xx / 9.0 + 0.3 * i) * torch.cos(yy / 7.0)), torch.full_like(d, 2.0)) for i, (_, d) in enumerate(frames)]
     np.savez_compressed(os.path.join(HERE, "g9_frames.npz"), H=H, W=W, color=np.stack([mg.t2n(c) for c, _ in frames]),
                         depth=np.stack([mg.t2n(d) for _, d in frames]), gt_poses=mg.t2n(gt_poses), imu=mg.t2n(imu),
-                        tstamps=np.array(seq.tstamps, dtype=np.float64))
-    return frames, gt_poses, imu, list(seq.tstamps)
+                        tstamps=np.array(seq.tstamps, dtype=np.float64), est=np.stack([mg.t2n(e) for e in est]),
+                        est_scaled=np.stack([mg.t2n(e) for e in est_scaled]))
+    return frames, gt_poses, imu, list(seq.tstamps), est, est_scaled
 
 
-def run_reference(name, overrides, frames, gt_poses, imu, tstamps):
+def run_reference(name, overrides, frames, gt_poses, imu, tstamps, mono, mono_scaled):
     from oracle.raster_ref import RefRasterizer, RefSettings
     from mm3dgs_slam_amd.config import default_config
     with mg._CpuMode():
@@ -96,14 +105,15 @@ def run_reference(name, overrides, frames, gt_poses, imu, tstamps):
         per_frame, kf_lists, kf_poses = [], [], None
         for idx in range(N_FRAMES):
             gt_color, gt_depth = frames[idx]
+            e_raw, e_scaled = (None, None) if rcfg["use_gt_depth"] else (mono[idx], mono_scaled[idx])       # slam/SLAM.py:390-394,413-450
             gt_w2c = pose_utils.get_camera_from_tensor(gt_poses[idx])
             if idx == 0:
                 est[idx] = pose_utils.get_tensor_from_camera(gt_w2c)
             else:
-                tracker.run_frame(idx, gt_color, gt_depth, None, imu[idx].clone() if use_imu else None)
-            if idx == 0:
-                mapper.camera_extent = torch.max(gt_depth) / rcfg["scene_radius_depth_ratio"]
-            mapper.run_frame(idx, gt_color, gt_depth, None, None)
+                tracker.run_frame(idx, gt_color, gt_depth, e_raw, imu[idx].clone() if use_imu else None)
+            if idx == 0:        # slam/SLAM.py:456-463
+                mapper.camera_extent = torch.max(gt_depth if rcfg["use_gt_depth"] else e_scaled) / rcfg["scene_radius_depth_ratio"]
+            mapper.run_frame(idx, gt_color, gt_depth, e_scaled, None)
             per_frame.append(summary(ns.gaussians))
             kf_lists.append([kf.idx for kf in mapper.keyframes])
             print(f"{name} frame {idx}: P={ns.gaussians._xyz.shape[0]} keyframes={kf_lists[-1]}", flush=True)
@@ -128,9 +138,9 @@ def main():
         x, y = preds - preds.mean(), target - target.mean()
         return (x * y).sum() / torch.sqrt((x * x).sum() * (y * y).sum())
     sys.modules["torchmetrics.functional.regression"].pearson_corrcoef = pearson_corrcoef
-    frames, gt_poses, imu, tstamps = make_frames()
+    frames, gt_poses, imu, tstamps, est, est_scaled = make_frames()
     for name in (sys.argv[1:] or list(VARIANTS)):
-        run_reference(name, VARIANTS[name], frames, gt_poses, imu, tstamps)
+        run_reference(name, VARIANTS[name], frames, gt_poses, imu, tstamps, est, est_scaled)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """G9: this repository's torch-graph Tracker / Mapper / GaussianModel / Renderer against an end-to-end run of the REFERENCE's own
 classes (tests/golden/make_golden_slam.py: slam/tracker.py, slam/mapper.py, slam/gaussian_model.py, slam/renderer.py driven like
 slam/SLAM.py:375-493 on CPU, with the CPU oracle standing in for the absent CUDA extension on both sides), in four configurations:
-the shipped method, `method: splatam`, bundle adjustment, and the UTMM-style IMU configuration.  Pins the harness rows of
+the shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU configuration, and a run without sensor depth.  Pins the harness rows of
 SURVEY.md 8f: RNG consumption order (keyframe picks, window subsets), keyframe decisions and covisibility graph, seeding masks and
 order, densification statistics, the pruning schedule and its interplay with Adam, both optimisers, pose propagation."""
 import os
@@ -33,7 +33,7 @@ class _Frames:
         return self.frames[i][0], self.frames[i][1], self.poses[i]
 
 
-@pytest.mark.parametrize("variant", ["vigs", "splatam", "ba", "imu"])
+@pytest.mark.parametrize("variant", ["vigs", "splatam", "ba", "imu", "estdepth"])
 def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.slam import SLAM
@@ -52,14 +52,16 @@ def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     #  is weakly constrained at 64x48 and its rounding noise grows ~10x per frame: 3e-7, 2e-5, 2e-4 -- hence the wider pose bar there)
     for idx in range(len(seq)):
         color, depth, gt_pose = seq[idx]
-        # the call sequence of slam/SLAM.py:375-493 with ground-truth depth: no depth estimate is passed on
+        # the call sequence of slam/SLAM.py:375-493; with sensor depth no depth estimate is passed on, without it the tracker gets the raw
+        # monocular estimate and the mapper its rescaled version (both stored in the fixture)
+        e_raw, e_scaled = (None, None) if cfg["use_gt_depth"] else (torch.from_numpy(F["est"][idx]), torch.from_numpy(F["est_scaled"][idx]))
         if idx == 0:
             slam.estimate_pose_list[idx] = gt_pose.clone()
         else:
-            slam.tracker.run_frame(idx, color, depth, None, imu_meas=seq.imu_rows[idx].clone() if use_imu else None)
+            slam.tracker.run_frame(idx, color, depth, e_raw, imu_meas=seq.imu_rows[idx].clone() if use_imu else None)
         if idx == 0:
-            slam.mapper.camera_extent = float(depth.max()) / cfg["scene_radius_depth_ratio"]
-        slam.mapper.run_frame(idx, color, depth, None)
+            slam.mapper.camera_extent = float((depth if cfg["use_gt_depth"] else e_scaled).max()) / cfg["scene_radius_depth_ratio"]
+        slam.mapper.run_frame(idx, color, depth, e_scaled)
         g = slam.gaussians
         # discrete decisions: identical keyframes; the map size up to the Gaussians (or seeded pixels) that sit within rounding of a
         # threshold -- two float32 programs order a few sums differently.  Measured: shipped method, frames 0-1 identical, then 1-4 of
