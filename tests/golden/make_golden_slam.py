@@ -32,6 +32,7 @@ sys.path.insert(1, ROOT)
 import make_golden as mg          # noqa: E402  (puts /root/reference first on sys.path, stubs the absent third-party modules)
 
 H, W, N_FRAMES, N_SEED = 48, 64, 5, 2500
+SHORT = {"no_transform": 3, "sh2_python": 3, "white_bg": 3}          # frames of the short variants
 _MAP = {"iters": 14, "kf_every": 2, "min_covisibility": 0.999, "densify_until_iter": 9, "pruning_interval": 4, "min_opacity": 0.4625,
         "size_threshold": 20}
 VARIANTS = {
@@ -48,6 +49,13 @@ VARIANTS = {
     # with its min-of-two-targets form (utils/loss_utils.py:43-61), its rescaled version (slam/SLAM.py:413-450 computes it; here
     # given) seeds new Gaussians and feeds the mapping Pearson term
     "estdepth": dict(use_gt_depth=False, tracking={"iters": 10, "use_depth_estimate_loss": True}, mapping=dict(_MAP)),
+    # renderer branches outside the shipped configs (3 frames each): world-frame means with the full view matrix -- including the
+    # transposed matrix slam/renderer.py:207-214 hands to get_depth_and_silhouette in that mode --, SH evaluated in Python with
+    # max_sh_degree 2 (f_rest rows through seeding, pruning and the optimiser groups), white background (composited under the depth
+    # bundle too, so the silhouette is 1 everywhere)
+    "no_transform": dict(pipeline={"transform_means_python": False}, tracking={"iters": 8}, mapping=dict(_MAP, iters=12)),
+    "sh2_python": dict(pipeline={"convert_SHs_python": True}, tracking={"iters": 8}, mapping=dict(_MAP, iters=12, sh_degree=2)),
+    "white_bg": dict(white_background=True, tracking={"iters": 8}, mapping=dict(_MAP, iters=12)),
     "imu": dict(pipeline={"force_isotropic": True},
                 tracking={"iters": 10, "dynamics_model": "imu", "use_depth_estimate_loss": True, "pearson_weight": 0.001, "position_lr": 0.002,
                           "rotation_lr": 0.002},
@@ -95,15 +103,16 @@ def run_reference(name, overrides, frames, gt_poses, imu, tstamps, mono, mono_sc
         ref_renderer.GaussianRasterizationSettings = RefSettings
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         rcfg = default_config(device="cpu", height=H, width=W, **overrides)   # (the TUM.yml schema as a dict: configuration, not code)
-        est = torch.zeros(N_FRAMES, 7)
+        n_frames = SHORT.get(name, N_FRAMES)
+        est = torch.zeros(n_frames, 7)
         use_imu = rcfg["tracking"]["dynamics_model"].lower() == "imu"                      # (slam/SLAM.py:44)
-        ns = types.SimpleNamespace(cfg=rcfg, gaussians=ref_gm.GaussianModel(rcfg), n_img=N_FRAMES, estimate_pose_list=est,
-                                   gt_pose_list=torch.zeros(N_FRAMES, 7), use_imu=use_imu, tf={"c2i": torch.eye(4)}, tstamps=tstamps)
+        ns = types.SimpleNamespace(cfg=rcfg, gaussians=ref_gm.GaussianModel(rcfg), n_img=n_frames, estimate_pose_list=est,
+                                   gt_pose_list=torch.zeros(n_frames, 7), use_imu=use_imu, tf={"c2i": torch.eye(4)}, tstamps=tstamps)
         ns.gaussians.training_setup()
         ns.renderer = ref_renderer.Renderer(rcfg)
         mapper, tracker = ref_mapper.Mapper(ns), ref_tracker.Tracker(ns)
         per_frame, kf_lists, kf_poses = [], [], None
-        for idx in range(N_FRAMES):
+        for idx in range(n_frames):
             gt_color, gt_depth = frames[idx]
             e_raw, e_scaled = (None, None) if rcfg["use_gt_depth"] else (mono[idx], mono_scaled[idx])       # slam/SLAM.py:390-394,413-450
             gt_w2c = pose_utils.get_camera_from_tensor(gt_poses[idx])

@@ -1,7 +1,8 @@
 """G9: this repository's torch-graph Tracker / Mapper / GaussianModel / Renderer against an end-to-end run of the REFERENCE's own
 classes (tests/golden/make_golden_slam.py: slam/tracker.py, slam/mapper.py, slam/gaussian_model.py, slam/renderer.py driven like
 slam/SLAM.py:375-493 on CPU, with the CPU oracle standing in for the absent CUDA extension on both sides), in four configurations:
-the shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU configuration, and a run without sensor depth.  Pins the harness rows of
+the shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU configuration, a run without sensor depth, and three
+renderer branches outside the shipped configs (world-frame means, Python SH with max_sh_degree 2, white background).  Pins the harness rows of
 SURVEY.md 8f: RNG consumption order (keyframe picks, window subsets), keyframe decisions and covisibility graph, seeding masks and
 order, densification statistics, the pruning schedule and its interplay with Adam, both optimisers, pose propagation."""
 import os
@@ -33,7 +34,7 @@ class _Frames:
         return self.frames[i][0], self.frames[i][1], self.poses[i]
 
 
-@pytest.mark.parametrize("variant", ["vigs", "splatam", "ba", "imu", "estdepth"])
+@pytest.mark.parametrize("variant", ["vigs", "splatam", "ba", "imu", "estdepth", "no_transform", "sh2_python", "white_bg"])
 def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.slam import SLAM
@@ -41,7 +42,8 @@ def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
     overrides = eval(str(G["overrides"]), {"__builtins__": {}})          # a dict literal written by the generator
     cfg = default_config(device="cpu", height=int(F["H"]), width=int(F["W"]), **overrides)
-    seq = _Frames(F["color"], F["depth"], F["gt_poses"], F["imu"], F["tstamps"])
+    n = G["est_poses"].shape[0]                                            # (the renderer-branch variants run 3 of the 5 frames)
+    seq = _Frames(F["color"][:n], F["depth"][:n], F["gt_poses"][:n], F["imu"][:n], F["tstamps"][:n])
     use_imu = cfg["tracking"]["dynamics_model"].lower() == "imu"
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer, render_mode="reference", native_loops=False)
