@@ -58,7 +58,32 @@ def _adam(p, g, m, v, t, lr, b1, b2, eps):
     p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))
 
 
+class _CpuLib:
+    """The one library entry point fused.py calls directly on the engine's handle: mm3dgs_adam (multi-GPU window: the all-reduced
+    gradients are stepped by a separate launch)."""
+
+    @staticmethod
+    def mm3dgs_adam(table, n_groups, step, beta1, beta2, eps, stream):
+        with torch.no_grad():
+            for i in range(n_groups):
+                e = table[i]
+                p, g, m, v = (_view(ptr, e.n) for ptr in (e.param, e.grad, e.exp_avg, e.exp_avg_sq))
+                _adam(p, g, m, v, int(step), e.lr, beta1, beta2, eps)
+        return 0
+
+
+def install(fused_module, registry=None):
+    """Route mm3dgs_slam_amd.fused to CPU engines (call under monkeypatch, or in a spawned worker): the product's eligibility rule
+    minus "the device is a GPU", one CpuEngine per renderer, no HIP stream."""
+    registry = {} if registry is None else registry
+    real = fused_module.FusedEngine.__dict__["eligible"].__func__
+    return dict(eligible=staticmethod(lambda c, g: real(dict(c, device="cuda:0"), g)),
+                _engine=lambda renderer: registry.setdefault(id(renderer), CpuEngine(renderer)), _stream=lambda: None), registry
+
+
 class CpuEngine:
+    lib = _CpuLib()
+
     def __init__(self, renderer):
         self.r = renderer
         self.cfg = renderer.cfg
@@ -80,6 +105,8 @@ class CpuEngine:
             o = [0, 3 * P, 6 * P, 7 * P, 10 * P, 14 * P, 15 * P, 16 * P]
             v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
             self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))
+            self.acc = torch.zeros(14 * P)                                         # window-batch mode: sum of the local views' gradients
+            self.stat_delta = (torch.zeros(P), v(5, (P, 1)), v(6, (P, 1)))         # max radii | accum | denom of one optimiser step
 
     def check_capacity(self):
         return True

@@ -14,7 +14,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _build(window):
+def _build(window, native=False):
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.renderer import Renderer
     from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
@@ -22,7 +22,18 @@ def _build(window):
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 2}, mapping={"iters": 3, "kf_every": 1})
     seq = SyntheticSequence(cfg, 3, 500, seed=5, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
-    return SLAM(cfg, seq, rasterizer_cls=RefRasterizer, window=window)
+    return SLAM(cfg, seq, rasterizer_cls=RefRasterizer, render_mode="reference" if native else "fused", window=window, native_loops=native)
+
+
+def _install_cpu_engine(setattr_fn=None):
+    """The native loops' host side (fused.py) over tests/cpu_engine.py: the C-ABI loop semantics on CPU."""
+    from mm3dgs_slam_amd import fused
+    from tests import cpu_engine
+    patches, registry = cpu_engine.install(fused)
+    for name, value in patches.items():
+        target = fused.FusedEngine if name == "eligible" else fused
+        (setattr_fn or setattr)(target, name, value)
+    return registry
 
 
 def _state(slam):
@@ -32,12 +43,14 @@ def _state(slam):
             "poses": torch.stack(slam.estimate_pose_list[:3])}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, native=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from mm3dgs_slam_amd.window_parallel import WindowParallel
-    slam = _build(WindowParallel(rank, world))
+    if native:
+        _install_cpu_engine()
+    slam = _build(WindowParallel(rank, world), native)
     for i in range(3):
         slam.step(i)
     torch.save(_state(slam), os.path.join(out, f"r{rank}.pt"))
@@ -83,3 +96,34 @@ def test_window_reduce_single_rank_is_identity():
     assert torch.equal(before, g._xyz.grad)
     assert torch.allclose(c[:, 0], res["visibility_filter"].float()) and n.shape == (g._xyz.shape[0], 1)
     assert torch.equal(r, torch.where(res["visibility_filter"], res["radii"], torch.zeros_like(res["radii"])).float())
+
+
+
+def test_native_window_orchestration_two_ranks_equal_window_batch_two_and_the_torch_graph_window(tmp_path, monkeypatch):
+    """The N > 1 path of the NATIVE loops (what `bench.py --gpus N` runs: per-view mm3dgs_slam_map with gradient outputs, local
+    accumulation, ONE flat all-reduce, mm3dgs_adam) on CPU: fused.py's orchestration over the CPU stand-in engine, two gloo ranks
+    == one rank with window-batch 2 == the torch-graph loop with the same window."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert a["xyz"].shape == b["xyz"].shape and a["xyz"].shape[0] > 0
+    assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["op"], b["op"]) and torch.equal(a["poses"], b["poses"])
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    torch.set_num_threads(2)
+    registry = _install_cpu_engine(monkeypatch.setattr)
+    one = _build(WindowParallel(0, 1, batch=2), native=True)
+    for i in range(3):
+        one.step(i)
+    assert type(one.mapper).__name__ == "FusedMapper" and any(c[0] == "map" for e in registry.values() for c in e.calls)
+    ref = _state(one)
+    for k in ref:
+        assert ref[k].shape == a[k].shape, k
+        assert torch.allclose(ref[k], a[k], rtol=1e-5, atol=1e-7), (k, (ref[k] - a[k]).abs().max())
+    monkeypatch.undo()
+    graph = _build(WindowParallel(0, 1, batch=2))
+    for i in range(3):
+        graph.step(i)
+    tg = _state(graph)
+    for k in tg:
+        assert tg[k].shape == ref[k].shape, k
+        assert torch.allclose(tg[k], ref[k], rtol=2e-4, atol=2e-6), (k, (tg[k] - ref[k]).abs().max())
