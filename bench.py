@@ -63,6 +63,9 @@ def parse():
                     help="slam, 1 GPU: a second run with the reference-faithful seeding (one Gaussian per valid frame-0 pixel, ~292 k), "
                          "this many timed frames, reported as `full_seed` (0 = skip)")
     ap.add_argument("--window-batch", type=int, default=1, help="views per rank and optimiser step in the mapping window (SURVEY 8e)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
+                         "(gradient-output loops, the flat all-reduce over RCCL, separate Adam launch) -- the code path of --gpus N, measurable on one GPU")
     return ap.parse_args()
 
 
@@ -253,8 +256,14 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            import socket
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
@@ -268,18 +277,40 @@ def main():
     rasterizer.set_binning_policy(args.policy)
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
 
+    collective = world > 1 or args.force_collectives
+
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
     def finish(out):
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if collective:
             dist.barrier()
             dist.destroy_process_group()
+
+    def verify_ranks(slam_=None):
+        """Self-check of the multi-GPU run for the line's reader: how many ranks the process group really has, an all-reduce whose
+        result is known in closed form (sum of rank + 1), and -- the property the window design rests on -- that every replica
+        holds the same map at the end (min == max over the ranks of a checksum of the Gaussian parameters)."""
+        if not collective:
+            return None
+        t = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "allreduce_checksum": float(t.item()),
+                "allreduce_expected": world * (world + 1) / 2.0}
+        if slam_ is not None:
+            g_ = slam_.gaussians
+            c = torch.stack([g_._xyz.double().sum(), g_._opacity.double().sum(), g_._scaling.double().sum(),
+                             torch.tensor(float(g_._xyz.shape[0]), device=dev, dtype=torch.float64)])
+            lo, hi = c.clone(), c.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            info["replicas_identical"] = bool(torch.equal(lo, hi))
+            info["map_checksum"] = [float(v) for v in hi]
+        return info
 
     if args.workload == "c5":
         step, info = c5_workload(args, rank, world, dev)
@@ -294,7 +325,7 @@ def main():
         elapsed = time.perf_counter() - t0
         _lib.profile_enable(0)
         prof = _lib.profile_read()
-        if world > 1:
+        if collective:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -305,7 +336,8 @@ def main():
         out = {"metric": "raster Mpix/s (forward + backward), synthetic 1920x1080, 3M Gaussians, SH3", "value": H * W * args.steps * world / elapsed / 1e6,
                "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": info["workload"], "gaussians": info["P"], "image": [H, W]},
+               "config": {"workload": info["workload"], "gaussians": info["P"], "image": [H, W],
+                          "multi_gpu": {"description": "independent views of the same map, one per rank; no data-path collective", **(verify_ranks() or {})} if collective else "single GPU"},
                "kernel_us": kus, "event_overhead_us": ev_us,
                "roofline": {"bound": "hbm", "kernel": "whole forward + backward pass (sum of its kernels)",
                             "achieved": (info["alg_fwd"] + info["alg_bwd"]) / gpu_s / 1e9 if gpu_s else None, "peak": 8000.0, "unit": "GB/s",
@@ -319,7 +351,7 @@ def main():
     # the reference seeds one Gaussian per valid frame-0 pixel (~292k at 640x480); BASELINE.json's configs[1] is quoted
     # at ~150k Gaussians, so the seeding is thinned to hit that count (stated in config.workload)
     frac = args.seed_fraction or min(1.0, args.gaussians / (0.95 * args.height * args.width))
-    extras = world == 1 and rank == 0
+    extras = world == 1 and rank == 0 and not args.force_collectives
     steady = args.steady_frames if extras else 0
 
     c3 = args.workload == "c3"
@@ -342,7 +374,8 @@ def main():
                                  mapping={"iters": args.map_iters, "seed_fraction": frac_})
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         seq = SyntheticSequence(cfg, n_frames, n_target, seed=0)        # untimed: builds the RGB-D frames on the GPU
-        window = WindowParallel(rank, world, batch=args.window_batch) if (world > 1 or args.window_batch > 1) else None
+        window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives)
+                  if (world > 1 or args.window_batch > 1 or args.force_collectives) else None)
         return SLAM(cfg, seq, render_mode=args.render_mode, window=window)
 
     log("process warm-up (6-frame SLAM run with a few iterations per frame: loads every operator once)")
@@ -375,10 +408,11 @@ def main():
     if phases:
         for k, v in phases.items():
             log(f"  phase {k:34s} {v / args.steps * 1e3:8.2f} ms/frame")
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    rank_check = verify_ranks(slam)
 
     P_now = int(slam.gaussians.get_xyz.shape[0])
     # measured N (tile-splat pairs) of a representative render, for the algorithmic-bytes figure
@@ -409,8 +443,9 @@ def main():
                                f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
                                f"the same run, `full_seed` = a second run seeded like the reference (one Gaussian per valid frame-0 pixel)",
                    "gaussians": P_now, "image": [H, W], "iterations_per_frame": views_per_frame,
-                   "multi_gpu": (f"mapping window sharded: {world} rank(s) x {args.window_batch} view(s) per optimiser step, one all-reduce of the "
-                                 f"Gaussian gradients per step; tracking replicated") if vps > 1 else "single GPU"},
+                   "multi_gpu": ({"description": f"mapping window sharded: {world} rank(s) x {args.window_batch} view(s) per optimiser step, one all-reduce of the "
+                                                f"Gaussian gradients per step; tracking replicated", **(rank_check or {})}
+                                 if (vps > 1 or collective) else "single GPU")},
         "raster_mpix_per_s_fwd_bwd": mpix,
         "render_iterations_per_s": renders * frame_equiv / elapsed,
         "num_rendered_pairs": N,

@@ -219,7 +219,6 @@ static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in
   return 0;
 }
 
-static int bwd2_requested() { return env_flag("MM3DGS_BWD2", 0); }
 static bool slam_fused_sort(int flags) {
   static const int no_fused_sort = env_flag("MM3DGS_NO_FUSED_SORT", 0);
   return (flags & MM3DGS_FWD_SHORT_LISTS) && !no_fused_sort;
@@ -258,6 +257,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   if (!(flags & MM3DGS_FWD_STATE_CLEAN))
     if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
   cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
+  cd.bg_extras = 1;
   // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
@@ -315,6 +315,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   ImageView iv = image_view((void*)image_state, cd.H, cd.W);
   BinView b = bin_view((void*)binning_state, N_capacity);
   BwdView bw = bwd_view(backward_scratch, P, N_capacity);
+  cd.bg_extras = 1;
   SlamGrads sg = {};
   if (grads) {
     const bool any = grads->d_xyz || grads->d_f_dc || grads->d_opacity || grads->d_scaling || grads->d_rotation;
@@ -350,17 +351,10 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
-  if (tl && !tracking && (bwd2_requested() == 2 || bwd2_requested() == 4)) return fail(-1, "internal: the second-generation backward compositor has no folded mapping loss");
-  // MM3DGS_BWD2=1 selects the 2-pixels-per-lane / MFMA-reduction backward compositor (composite_bwd2.hip).  Default off: it
-  // executes 29 % fewer VALU instructions but, with half the waves per SIMD (2.3 instead of 4.7), cannot keep the VALU busy
-  // (58 % active; 61 us against 49 us at SLAM size, and no better at 1200x680 -- profiles/r02_bwd2_experiment.md).  Kept as a
-  // checked alternative (tests/test_gpu_fused.py compares it with the first-generation kernel).
-  const int bwd2 = bwd2_requested();   // read per call: tests compare both in one process
   if (!compositor_done)
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
-    if (bwd2) launch_composite_bwd2_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, bwd2);
-    else launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, (bwd2 == 2 || bwd2 == 3) ? 1 : 0, slam_direct_bins(flags, cd, P, N_capacity).on); }
+    launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, slam_direct_bins(flags, cd, P, N_capacity).on); }
   return check_launch("slam_backward");
 }
 
@@ -434,7 +428,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
     if (loss_cfg->H != cam->image_height || loss_cfg->W != cam->image_width) return fail(-1, "loss and camera image sizes differ");
   }
   // masked L1 alone (normalisation deferred to the pose gradient): the backward compositor runs in the forward launch
-  const bool fuse_track = fold && tl.defer_scale && !bwd2_requested() && !env_flag("MM3DGS_NO_FUSED_TRACK", 0) && backward_scratch;
+  const bool fuse_track = fold && tl.defer_scale && !env_flag("MM3DGS_NO_FUSED_TRACK", 0) && backward_scratch;
   float* track_dsub = nullptr;
   if (fuse_track) {
     track_dsub = bwd_view(backward_scratch, P, N_capacity).dsub;
@@ -499,9 +493,9 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       tl.gt = views[it].gt_color; tl.ref = views[it].ref_depth_or_null;
       rc = slam_forward_impl(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, &tl);
       if (rc) return rc;
-      // the gradient-image pass itself runs in the backward compositor's prologue (tl.dmaps set) unless the second-generation
-      // compositor or MM3DGS_NO_FOLDED_LOSS asks for the separate launch
-      const bool fold_grad = bwd2_requested() != 2 && bwd2_requested() != 4 && !env_flag("MM3DGS_NO_FOLDED_LOSS", 0);
+      // the gradient-image pass itself runs in the backward compositor's prologue (tl.dmaps set) unless MM3DGS_NO_FOLDED_LOSS asks
+      // for the separate launch
+      const bool fold_grad = !env_flag("MM3DGS_NO_FOLDED_LOSS", 0);
       { ProfScope ps(MM3DGS_PROF_LOSS, (hipStream_t)stream);
         launch_loss_after_forward_rows(lc, out_color, tl.gt, tl.ref, dmaps, sums, partial, fold_grad ? nullptr : dL_dout, (hipStream_t)stream); }
       if (loss4 && it == n_iter - 1) launch_loss_finish(lc, sums, partial, (hipStream_t)stream, loss4);

@@ -134,7 +134,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
   float fin[C];
 #pragma unroll
-  for (int ch = 0; ch < C; ch++) fin[ch] = acc[ch] + (ch < 3 ? Tr * cam.bg[ch] : 0.f);
+  for (int ch = 0; ch < C; ch++) fin[ch] = acc[ch] + ((ch < 3 || cam.bg_extras) ? Tr * cam.bg[ch % 3] : 0.f);   // (SLAM bundle: the depth pass is composited over bg too, slam/renderer.py:207-214)
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   if (inside) {
     iv.final_T[pix] = Tr;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
 #pragma unroll
   for (int ch = 0; ch < C; ch++) {
     if (!dl_done) dL[ch] = (inside && ch < dl_planes) ? dL_dout[ch * HW + pix] : 0.f;
-    if (ch < 3) bg_dot += cam.bg[ch] * dL[ch];
+    if (ch < 3 || cam.bg_extras) bg_dot += cam.bg[ch % 3] * dL[ch];
   }
   const float Tf_bg = T_final * bg_dot;
   float Tr = T_final;

@@ -1,4 +1,4 @@
-// Pieces shared by the compositing kernels (composite.hip, composite_bwd2.hip): the skip / stop constants, the power of the
+// Pieces shared by the compositing kernels (composite.hip): the skip / stop constants, the power of the
 // Gaussian (ONE instruction sequence, so that forward and backward take identical skip decisions), the packed splat record.
 #pragma once
 #include "mm3dgs_common.h"

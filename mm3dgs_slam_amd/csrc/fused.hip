@@ -348,7 +348,7 @@ void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t
 template <bool TRACK, bool DIRECT>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma, int yshift) {
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
   const int idx = blockIdx.x * FB + threadIdx.x;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
@@ -379,7 +379,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = btile + toff;
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, yshift != 0, m64);
+    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, m64);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4, int yshift, bool direct) {
+                                const PoseLossScale* pls, float* loss4, bool direct) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
@@ -717,7 +717,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
     const bool map = out.d_xyz || ma.on;
     auto kern = map ? (direct ? slam_preprocess_bwd_kernel<false, true> : slam_preprocess_bwd_kernel<false, false>)
                     : (direct ? slam_preprocess_bwd_kernel<true, true> : slam_preprocess_bwd_kernel<true, false>);
-    hipLaunchKernelGGL(kern, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, yshift);
+    hipLaunchKernelGGL(kern, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma);
   }
   if (want_pose)
   {

@@ -9,35 +9,13 @@
 // 6 + C); NTHREADS: workgroup size.
 // Inputs per lane: area (tiles in the splat's rectangle, 0 = culled), goff (first pair index), r0/r1 (tile rectangle),
 // sA/sB (first 32 bytes of the splat record), bblk + boff (first record).  Output: acc0..acc2 = sum of the records.
-// yshift (SLAM record layouts only): the records were written by composite_bwd2_kernel, whose y-moments are taken about the
-// centre row of each 4x4 block (yc = 4 * block_row + 1.5) instead of the splat centre; with d0 = y_splat - yc
-//   My = d0 M0 - My~,   Mxy = d0 Mx - Mxy~,   Myy = d0^2 M0 - 2 d0 My~ + Myy~
-// is applied per record before it is added (mapping layout [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy], tracking [M0 Mx Mxx cz | My Mxy Myy]).
-template <bool TRACK>
-__device__ __forceinline__ void add_record(bool on, bool ys, float d0, const float4& a, const float4& b, const float4& c,
-                                           float4& acc0, float4& acc1, float4& acc2) {
-  if (!on) return;
-  const float sg = ys ? -1.f : 1.f;
-  acc0.x += a.x; acc0.y += a.y; acc0.z += a.z; acc0.w += a.w;
-  if (TRACK) {
-    acc1.x += fmaf(d0, a.x, sg * b.x);
-    acc1.y += fmaf(d0, a.y, sg * b.y);
-    acc1.z += fmaf(d0 * d0, a.x, fmaf(-2.f * d0, b.x, b.z));
-  } else {
-    acc1.x += b.x; acc1.y += b.y; acc1.z += b.z;
-    acc1.w += fmaf(d0, a.x, sg * b.w);
-    acc2.x += fmaf(d0, a.y, sg * c.x);
-    acc2.y += fmaf(d0 * d0, a.x, fmaf(-2.f * d0, b.w, c.y));
-  }
-}
-
 // DIRECT (direct bins, which have no Gaussian-major pair index to address submask[] with): the block masks of a small splat
 // arrive as one 64-bit word (m64: written per Gaussian by the binning kernel), the blocks of a big splat are re-tested with
 // the very rule the lists were built with (tile_mask.h).
 template <int NF4, int RECF_T, int NTHREADS, bool DIRECT = false>
 __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t r0, uint32_t r1, const float4& sA, const float4& sB,
                                                uint32_t rec_first, const float* __restrict__ dsub, const BinView& bn, uint32_t N_cap,
-                                               float4& acc0, float4& acc1, float4& acc2, bool yshift = false, unsigned long long m64 = 0ull, int recf = 0) {
+                                               float4& acc0, float4& acc1, float4& acc2, unsigned long long m64 = 0ull, int recf = 0) {
   const int RECF = RECF_T ? RECF_T : recf;
   constexpr bool TRACK = NF4 == 2;
   {
@@ -62,12 +40,11 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
       }
     }
     // M: block masks of up to four pairs; (ox[p], oy[p]) = block coordinates of pair p's tile relative to the block rectangle
-    auto drain = [&](unsigned long long M, const int (&ox)[4], const int (&oy)[4], int bw, uint32_t base, int by0) {
+    auto drain = [&](unsigned long long M, const int (&ox)[4], const int (&oy)[4], int bw, uint32_t base) {
       constexpr int UB = 8;   // records in flight per lane
       while (__ballot(M != 0ull) != 0ull) {
         float4 a[UB], b[UB], c[UB];
         bool on[UB];
-        float d0[UB];
 #pragma unroll
         for (int u = 0; u < UB; u++) {
           on[u] = M != 0ull;
@@ -77,21 +54,16 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
           const int oxp = pq == 0 ? ox[0] : (pq == 1 ? ox[1] : (pq == 2 ? ox[2] : ox[3]));
           const int oyp = pq == 0 ? oy[0] : (pq == 1 ? oy[1] : (pq == 2 ? oy[2] : oy[3]));
           const int bx = oxp + ((Lb >> 2) & 1) * 2 + (Lb & 1), by = oyp + (Lb >> 3) * 2 + ((Lb >> 1) & 1);
-          d0[u] = yshift ? sA.y - (4.f * (float)(by0 + by) + 1.5f) : 0.f;
           const float* r = dsub + (on[u] ? (size_t)(base + (uint32_t)(by * bw + bx)) * RECF : (size_t)0);
           a[u] = ld4u(r); b[u] = ld4u(r + 4);      // (packed records: the lanes past a record's own floats are never used)
           c[u] = TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4u(r + 8);
         }
 #pragma unroll
         for (int u = 0; u < UB; u++) {
-          if (yshift) {
-            add_record<TRACK>(on[u], true, d0[u], a[u], b[u], c[u], acc0, acc1, acc2);
-          } else {
-            acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
-            acc1.x += on[u] ? b[u].x : 0.f; acc1.y += on[u] ? b[u].y : 0.f; acc1.z += on[u] ? b[u].z : 0.f; acc1.w += on[u] ? b[u].w : 0.f;
-            if (!TRACK) {
-              acc2.x += on[u] ? c[u].x : 0.f; acc2.y += on[u] ? c[u].y : 0.f; acc2.z += on[u] ? c[u].z : 0.f; acc2.w += on[u] ? c[u].w : 0.f;
-            }
+          acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
+          acc1.x += on[u] ? b[u].x : 0.f; acc1.y += on[u] ? b[u].y : 0.f; acc1.z += on[u] ? b[u].z : 0.f; acc1.w += on[u] ? b[u].w : 0.f;
+          if (!TRACK) {
+            acc2.x += on[u] ? c[u].x : 0.f; acc2.y += on[u] ? c[u].y : 0.f; acc2.z += on[u] ? c[u].z : 0.f; acc2.w += on[u] ? c[u].w : 0.f;
           }
         }
       }
@@ -115,7 +87,7 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
           ox[k] = (tminx + tx) * 4 - br.bx0; oy[k] = (tminy + ty) * 4 - br.by0;
           if (++tx == tw) { tx = 0; ty++; }
         }
-        drain(M, ox, oy, br.bw, rec0, br.by0);
+        drain(M, ox, oy, br.bw, rec0);
       }
     }
     // ---- flat work list of the wave's big splats: item = one 4x4 block of a big splat's block rectangle (its records are
@@ -124,7 +96,7 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
     // crosses to that owner's accumulator in LDS.  Same code, same data, same lane order every run -> deterministic.
     const int lane = threadIdx.x & 63, wvq = threadIdx.x >> 6;
     if (__ballot(isbig && area > 0) != 0ull) {
-      __shared__ int s_par[NTHREADS / 64][64][DIRECT ? 15 : 9];      // [8]: the splat's centre y (float bits), for the y-shift; [9..14]: mask constants
+      __shared__ int s_par[NTHREADS / 64][64][DIRECT ? 15 : 9];      // [8]: unused; [9..14]: mask constants
       __shared__ uint32_t s_pref[NTHREADS / 64][64];
       __shared__ float s_acc[NTHREADS / 64][64][12];
       const bool own = isbig && area > 0;
@@ -138,7 +110,7 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
       s_pref[wvq][lane] = incl;
       int* par = s_par[wvq][lane];
       par[0] = (int)rec0; par[1] = br.bw; par[2] = br.bx0; par[3] = br.by0; par[4] = tminx; par[5] = tminy; par[6] = tw; par[7] = (int)goff;
-      par[8] = __float_as_int(sA.y);
+      par[8] = 0;
       if (DIRECT) {
         par[9] = __float_as_int(mc.cx); par[10] = __float_as_int(mc.cy); par[11] = __float_as_int(mc.hx); par[12] = __float_as_int(mc.hy);
         par[13] = __float_as_int(mc.r2); par[14] = mc.mode;
@@ -175,7 +147,6 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
         uint32_t mk[UF];
         int Lq[UF];
         bool have[UF];
-        float d0q[UF];
 #pragma unroll
         for (int u = 0; u < UF; u++) {
           const uint32_t i = i0 + t0 + (uint32_t)u;
@@ -191,7 +162,6 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
           if ((by + 1) * bw <= j) by++;
           const int bx = j - by * bw;
           const int ax = pp[2] + bx, ay = pp[3] + by;                 // global block coordinates
-          d0q[u] = yshift ? __int_as_float(pp[8]) - (4.f * (float)ay + 1.5f) : 0.f;
           const int k = ((ay >> 2) - pp[5]) * pp[6] + ((ax >> 2) - pp[4]);
           Lq[u] = 4 * ((((ay >> 1) & 1) * 2) + ((ax >> 1) & 1)) + (ay & 1) * 2 + (ax & 1);
           recq[u] = (uint32_t)pp[0] + (uint32_t)j;
@@ -218,16 +188,9 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
         for (int u = 0; u < UF; u++) {
           if (have[u] && ow[u] != cur) { flush(cur); cur = ow[u]; }
           if (on[u]) {
-            if (yshift) {
-              float4 q0 = make_float4(pa[0], pa[1], pa[2], pa[3]), q1 = make_float4(pa[4], pa[5], pa[6], pa[7]), q2 = make_float4(pa[8], pa[9], pa[10], pa[11]);
-              add_record<TRACK>(true, true, d0q[u], a[u], b4[u], TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : c4[u], q0, q1, q2);
-              pa[0] = q0.x; pa[1] = q0.y; pa[2] = q0.z; pa[3] = q0.w; pa[4] = q1.x; pa[5] = q1.y; pa[6] = q1.z; pa[7] = q1.w;
-              pa[8] = q2.x; pa[9] = q2.y; pa[10] = q2.z; pa[11] = q2.w;
-            } else {
-              pa[0] += a[u].x; pa[1] += a[u].y; pa[2] += a[u].z; pa[3] += a[u].w;
-              pa[4] += b4[u].x; pa[5] += b4[u].y; pa[6] += b4[u].z; pa[7] += b4[u].w;
-              if (!TRACK) { pa[8] += c4[u].x; pa[9] += c4[u].y; pa[10] += c4[u].z; pa[11] += c4[u].w; }
-            }
+            pa[0] += a[u].x; pa[1] += a[u].y; pa[2] += a[u].z; pa[3] += a[u].w;
+            pa[4] += b4[u].x; pa[5] += b4[u].y; pa[6] += b4[u].z; pa[7] += b4[u].w;
+            if (!TRACK) { pa[8] += c4[u].x; pa[9] += c4[u].y; pa[10] += c4[u].z; pa[11] += c4[u].w; }
           }
         }
       }

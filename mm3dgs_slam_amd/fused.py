@@ -355,7 +355,7 @@ class FusedMapper(Mapper):
         m = self.cfg["mapping"]
         do_ba = bool(m["do_BA"]) and idx > 0
         if (num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians)
-                or (do_ba and self.window is not None and self.window.views_per_step > 1)):     # (BA with a sharded window: torch-graph loop)
+                or (do_ba and self.window is not None and self.window.sharded)):     # (BA with a sharded window: torch-graph loop)
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
@@ -432,7 +432,7 @@ class FusedMapper(Mapper):
                 if new_gaussians_mask is not None:
                     om = om | new_gaussians_mask
                 self._opt_mask = om.to(torch.uint8).contiguous()
-        multi = self.window is not None and self.window.views_per_step > 1
+        multi = self.window is not None and self.window.sharded
         # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
         # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
         # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
@@ -442,7 +442,7 @@ class FusedMapper(Mapper):
         for attempt in range(4):
             self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
             ok = eng.check_capacity()
-            if self.window is not None and self.window.world > 1:
+            if self.window is not None and self.window._collective:
                 ok = not self.window.any_flag(not ok, device=eng.dev)
             if ok:
                 break

@@ -333,7 +333,7 @@ class Mapper:
                 g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
                 if do_ba:
-                    if self.window is not None and self.window.world > 1:
+                    if self.window is not None and self.window._collective:
                         # every replica must take the identical pose step: sum the pose gradients of the ranks' views
                         self.window.reduce_pose_grads(qs + Ts)
                     pose_opt.step()

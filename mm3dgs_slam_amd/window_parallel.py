@@ -23,8 +23,21 @@ class WindowParallel:
     ``WindowParallel(0, 1, batch=G)`` is the single-GPU "window-batch = G" mode: the parity baseline of a G-rank run (the same
     G views per step, gradients summed locally instead of by the all-reduce)."""
 
-    def __init__(self, rank: int, world: int, group=None, batch: int = 1):
+    def __init__(self, rank: int, world: int, group=None, batch: int = 1, always_reduce: bool = False):
         self.rank, self.world, self.group, self.batch = rank, world, group, int(batch)
+        # always_reduce: issue the collectives even with a single rank (an all-reduce over one rank is the identity): runs the
+        # whole multi-GPU orchestration -- gradient-output loops, flat buffer, RCCL launch, separate Adam -- on a 1-GPU box
+        self.always_reduce = bool(always_reduce)
+
+    @property
+    def _collective(self):
+        return self.world > 1 or self.always_reduce
+
+    @property
+    def sharded(self):
+        """True when an optimiser step goes through the gradient-output + reduce + Adam path (more than one view per step, or
+        collectives forced)."""
+        return self.views_per_step > 1 or self.always_reduce
 
     @property
     def views_per_step(self):
@@ -58,7 +71,7 @@ class WindowParallel:
         norm, count, rmax = stats
         cols += [norm, count]
         flat = torch.cat(cols, 1).contiguous()
-        if self.world > 1:
+        if self._collective:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
         off = 0
@@ -73,22 +86,26 @@ class WindowParallel:
         return flat[:, off:off + 1], flat[:, off + 1:off + 2], rmax
 
     def reduce_pose_grads(self, tensors):
-        """Bundle adjustment with a sharded window: each rank holds the pose gradients of ITS view only; sum them (missing
-        gradients count as zero) so that the keyframe-pose Adam step is identical on every replica."""
-        if self.world <= 1 or not tensors:
+        """Bundle adjustment with a sharded window: each rank holds the pose gradients of ITS views only; sum them so that the
+        keyframe-pose Adam step is identical on every replica.  A has-gradient flag per tensor travels with the gradients (same
+        all-reduce): a pose that NO rank rendered this step keeps ``grad = None``, so Adam skips it -- moments and step counter
+        untouched -- exactly like the single-rank window-batch run (and the reference's ``zero_grad(set_to_none=True)`` loop)."""
+        if not self._collective or not tensors:
             return
-        flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors])
+        flat = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in tensors]
+                         + [torch.tensor([0.0 if t.grad is None else 1.0 for t in tensors], dtype=tensors[0].dtype, device=tensors[0].device)])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        has = flat[-len(tensors):] > 0
         off = 0
-        for t in tensors:
+        for i, t in enumerate(tensors):
             n = t.numel()
-            t.grad = flat[off:off + n].reshape(t.shape).clone()
+            t.grad = flat[off:off + n].reshape(t.shape).clone() if bool(has[i]) else None
             off += n
 
     def any_flag(self, flag: bool, device="cpu") -> bool:
         """Logical OR of a host flag over the ranks (a rank-local event such as a binning overflow must lead to the same
         decision -- re-run the loop -- on every replica)."""
-        if self.world <= 1:
+        if not self._collective:
             return bool(flag)
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -97,7 +114,7 @@ class WindowParallel:
     def reduce_flat(self, flat, rmax=None):
         """Native-loop variant: `flat` is (a prefix of) the engine's single gradient+statistics buffer (sum), `rmax` the radii
         (max; None outside the densification phase, when neither the statistics columns nor the radii are consumed)."""
-        if self.world > 1:
+        if self._collective:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if rmax is not None:
                 dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)

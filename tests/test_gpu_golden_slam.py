@@ -1,0 +1,115 @@
+"""G9 on the GPU: the NATIVE loops (FusedTracker / FusedMapper over mm3dgs_slam_track / mm3dgs_slam_map, i.e. the HIP kernels) on
+the frames of the G9 fixtures, against the trajectories the reference's own Tracker / Mapper / GaussianModel / Renderer classes
+produced (tests/golden/make_golden_slam.py: slam/tracker.py:94-177, slam/mapper.py:718-950, slam/renderer.py:80-83,207-214 driven
+like slam/SLAM.py:375-493 with the CPU oracle standing in for the absent CUDA extension).  Every native-eligible variant: the
+shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU configuration, no sensor depth, white background.
+
+Bars (the same as the CPU runs of tests/test_golden_slam.py hold for the torch-graph loops): identical keyframe lists, covisibility
+graph and RNG end state; map size within 0.5 %; while no threshold decision has flipped (the maps still have the same rows) camera
+matrices to 1e-4 (5e-4 for bundle adjustment / white background, whose weakly constrained directions amplify rounding ~10x per
+frame on the reference side as well) and map moments to 1e-4; afterwards 1e-3 / 5e-3."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda:0"
+
+
+class _Frames:
+    def __init__(self, F, n):
+        self.frames = [(torch.from_numpy(c).to(DEV), torch.from_numpy(d).to(DEV)) for c, d in zip(F["color"][:n], F["depth"][:n])]
+        self.poses = [torch.from_numpy(p).to(DEV) for p in F["gt_poses"][:n]]
+        self.imu_rows = torch.from_numpy(F["imu"][:n])
+        self.tstamps = [float(t) for t in F["tstamps"][:n]]
+        self.tf = {"c2i": torch.eye(4)}
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        return self.frames[i][0], self.frames[i][1], self.poses[i]
+
+
+def run_variant(variant, verbose=False):
+    """Drives the native loops over the fixture's frames; returns the per-frame measurements (also used by tools/g9_native_check.py)."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor as M
+    from mm3dgs_slam_amd.slam import SLAM
+    F = np.load(os.path.join(HERE, "golden", "g9_frames.npz"))
+    G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
+    overrides = eval(str(G["overrides"]), {"__builtins__": {}})          # a dict literal written by the generator
+    cfg = default_config(device=DEV, height=int(F["H"]), width=int(F["W"]), **overrides)
+    n = G["est_poses"].shape[0]
+    seq = _Frames(F, n)
+    use_imu = cfg["tracking"]["dynamics_model"].lower() == "imu"
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    slam = SLAM(cfg, seq)                               # default: native loops on the HIP library
+    assert type(slam.tracker).__name__ == "FusedTracker" and type(slam.mapper).__name__ == "FusedMapper"
+    from mm3dgs_slam_amd.fused import FusedEngine
+    assert FusedEngine.eligible(cfg, slam.gaussians), "this variant must run on the native loops"
+    rows = []
+    for idx in range(len(seq)):
+        color, depth, gt_pose = seq[idx]
+        e_raw, e_scaled = (None, None) if cfg["use_gt_depth"] else (torch.from_numpy(F["est"][idx]).to(DEV), torch.from_numpy(F["est_scaled"][idx]).to(DEV))
+        if idx == 0:
+            slam.estimate_pose_list[idx] = gt_pose.clone()
+        else:
+            slam.tracker.run_frame(idx, color, depth, e_raw, imu_meas=seq.imu_rows[idx].clone() if use_imu else None)
+        if idx == 0:
+            slam.mapper.camera_extent = float((depth if cfg["use_gt_depth"] else e_scaled).max()) / cfg["scene_radius_depth_ratio"]
+        slam.mapper.run_frame(idx, color, depth, e_scaled)
+        g = slam.gaussians
+        dM = float((M(slam.estimate_pose_list[idx].detach().cpu().float()) - M(torch.from_numpy(G["est_poses"][idx]))).abs().max())
+        with torch.no_grad():
+            op = torch.sigmoid(g._opacity)
+            got = np.array([float(g._xyz.mean()), float(g._xyz.std()), float(op.mean()), float(op.std()), float(g._scaling.mean()),
+                            float(g._scaling.std()), float(g._features_dc.mean()), float(g._rotation[:, 0].mean())])
+        rows.append(dict(idx=idx, keyframes=[kf.idx for kf in slam.mapper.keyframes], P=int(g._xyz.shape[0]), P_ref=int(G["per_frame"][idx, 0]),
+                         pose_diff=dM, moments=got, moments_ref=G["per_frame"][idx, 1:]))
+        if verbose:
+            print(f"  {variant} frame {idx}: keyframes {rows[-1]['keyframes']} (reference {G['keyframes'][idx]})  P {rows[-1]['P']} (reference {rows[-1]['P_ref']})  "
+                  f"pose diff {dM:.2e}  max moment diff {np.abs(got - G['per_frame'][idx, 1:]).max():.2e}")
+    return slam, G, rows
+
+
+@pytest.mark.parametrize("variant", ["vigs", "splatam", "ba", "imu", "estdepth", "white_bg"])
+def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
+    from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
+    slam, G, rows = run_variant(variant)
+    want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
+    aligned = True
+    for r in rows:
+        idx = r["idx"]
+        assert r["keyframes"] == want_kf[idx], (idx, r["keyframes"], want_kf[idx])
+        assert abs(r["P"] - r["P_ref"]) <= max(2, 0.005 * r["P_ref"]), (idx, r["P"], r["P_ref"])
+        aligned = aligned and r["P"] == r["P_ref"]
+        if idx == 0:
+            assert aligned
+        bar = (5e-4 if variant in ("ba", "white_bg") else 1e-4) if aligned else 1e-3
+        assert r["pose_diff"] < bar, (idx, r["pose_diff"], bar)
+        tol = 1e-4 if aligned else 5e-3
+        assert np.allclose(r["moments"], r["moments_ref"], atol=tol, rtol=tol), (idx, r["moments"], r["moments_ref"])
+    graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
+    assert graph == [str(s) for s in G["graph"]]
+    for kf, ref in zip(slam.mapper.keyframes, G["keyframe_poses"]):
+        d = (get_camera_from_tensor(kf.pose.detach().cpu().float()) - get_camera_from_tensor(torch.from_numpy(ref))).abs().max()
+        assert d < 5e-4, (kf.idx, float(d))
+    # the final map as a population (rows are no longer aligned once a single pruning decision differs)
+    g = slam.gaussians
+    qs = torch.tensor([0.02, 0.1, 0.25, 0.5, 0.75, 0.9, 0.98])
+    for name, t in (("xyz", g._xyz), ("opacity", g._opacity), ("scaling", g._scaling), ("rotation", g._rotation), ("f_dc", g._features_dc)):
+        ref = torch.from_numpy(G[name])
+        t = t.detach().cpu()
+        for col in range(t.reshape(t.shape[0], -1).shape[1]):
+            a = torch.quantile(t.reshape(t.shape[0], -1)[:, col], qs)
+            b = torch.quantile(ref.reshape(ref.shape[0], -1)[:, col], qs)
+            assert (a - b).abs().max() < 0.02 * max(1.0, float(b.abs().max())), (name, col, a, b)
+    # the three RNG streams were consumed exactly as the reference consumes them
+    after = np.array([random.random(), float(np.random.rand()), float(torch.rand(1))])
+    assert np.allclose(after, G["rng_after"]), (after, G["rng_after"])
+    assert getattr(slam.mapper, "loop_reruns", 0) >= 0

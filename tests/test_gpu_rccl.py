@@ -1,0 +1,78 @@
+"""The RCCL path on the lease GPU: backend "nccl" (= RCCL on ROCm) initialised with world_size 1 and the NATIVE mapping loop driven
+in window mode -- mm3dgs_slam_map with gradient outputs -> WindowParallel.reduce_flat (dist.all_reduce on the engine's device
+buffers: RCCL kernels on the stream) -> mm3dgs_adam -- must reproduce the in-kernel-Adam single-view run.  It is the code path
+`bench.py --gpus N` takes on an N-GPU node, with the one difference that the all-reduce has a single participant.
+(Two ranks cannot share the one GPU of the test box under RCCL; the 2-rank halves are covered over gloo: tests/test_window_parallel.py
+on CPU, tests/test_gpu_fused.py::test_fused_mapper_window_parallel_two_ranks on this GPU.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, random, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+out = sys.argv[2]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from mm3dgs_slam_amd.config import default_config
+from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+from mm3dgs_slam_amd.window_parallel import WindowParallel
+res = {}
+for name, window in (("rccl", WindowParallel(0, 1, always_reduce=True)), ("plain", None)):
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg = default_config(device="cuda:0", height=120, width=160, tracking={"iters": 5}, mapping={"iters": 8, "kf_every": 1})
+    seq = SyntheticSequence(cfg, 3, 6000, seed=6)
+    slam = SLAM(cfg, seq, window=window)
+    assert type(slam.mapper).__name__ == "FusedMapper"
+    calls = {"n": 0}
+    if window is not None:
+        real = dist.all_reduce
+        def counted(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+        dist.all_reduce = counted
+    for i in range(3):
+        slam.step(i)
+    if window is not None:
+        dist.all_reduce = real
+    g = slam.gaussians
+    res[name] = {"xyz": g._xyz.detach().cpu(), "op": g._opacity.detach().cpu(), "sc": g._scaling.detach().cpu(), "acc": g.xyz_gradient_accum.cpu(),
+                 "radii": g.max_radii2D.cpu(), "poses": torch.stack([p.detach().cpu() for p in slam.estimate_pose_list[:3]]), "allreduces": calls["n"]}
+t = torch.ones(1 << 20, device="cuda:0")
+dist.all_reduce(t)
+res["backend"] = dist.get_backend()
+res["checksum"] = float(t.sum())
+torch.save(res, out)
+dist.destroy_process_group()
+'''
+
+
+def test_native_mapping_window_over_rccl_world_one_equals_the_in_kernel_adam_run(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "res.pt"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, str(script), ROOT, str(out), str(port)], env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-4000:]
+    res = torch.load(out)
+    assert res["backend"] == "nccl" and res["checksum"] == float(1 << 20)
+    a, b = res["rccl"], res["plain"]
+    # 3 frames x 8 mapping iterations, each with one flat all-reduce (+ one max-reduce of the radii while densifying, + the overflow vote per loop)
+    assert a["allreduces"] >= 24, a["allreduces"]
+    assert a["xyz"].shape == b["xyz"].shape and a["xyz"].shape[0] > 0
+    for k in ("xyz", "op", "sc", "acc", "radii", "poses"):
+        assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), (k, float((a[k] - b[k]).abs().max()))

@@ -14,13 +14,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _build(window, native=False):
+def _build(window, native=False, ba=False):
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.renderer import Renderer
     from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
     from oracle.raster_ref import RefRasterizer
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
-    cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 2}, mapping={"iters": 3, "kf_every": 1})
+    cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 2}, mapping={"iters": 5 if ba else 3, "kf_every": 1, "do_BA": ba})
     seq = SyntheticSequence(cfg, 3, 500, seed=5, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
     return SLAM(cfg, seq, rasterizer_cls=RefRasterizer, render_mode="reference" if native else "fused", window=window, native_loops=native)
 
@@ -43,16 +43,25 @@ def _state(slam):
             "poses": torch.stack(slam.estimate_pose_list[:3])}
 
 
-def _worker(rank, world, port, out, native=False):
+def _run(slam, ba=False):
+    for i in range(3):
+        slam.step(i)
+    if ba:
+        # a window of THREE views (two keyframe views + the current frame): with two views per optimiser step some steps render no
+        # current-frame view, i.e. leave the only optimised pose (reference quirk, mapper.py) without a gradient
+        color, depth, _ = slam.seq[2]
+        slam.mapper.optimize_map(2, 6, [0] * (len(slam.mapper.keyframes) + 1) + [-1] if len(slam.mapper.keyframes) < 2 else [0, 1, -1], None, slam.estimate_pose_list[2], color, depth, None)
+
+
+def _worker(rank, world, port, out, native=False, ba=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from mm3dgs_slam_amd.window_parallel import WindowParallel
     if native:
         _install_cpu_engine()
-    slam = _build(WindowParallel(rank, world), native)
-    for i in range(3):
-        slam.step(i)
+    slam = _build(WindowParallel(rank, world), native, ba)
+    _run(slam, ba)
     torch.save(_state(slam), os.path.join(out, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -127,3 +136,55 @@ def test_native_window_orchestration_two_ranks_equal_window_batch_two_and_the_to
     for k in tg:
         assert tg[k].shape == ref[k].shape, k
         assert torch.allclose(tg[k], ref[k], rtol=2e-4, atol=2e-6), (k, (tg[k] - ref[k]).abs().max())
+
+
+def test_two_rank_window_with_bundle_adjustment_equals_window_batch_two(tmp_path):
+    """do_BA with a sharded window (the torch-graph loop: fused.py hands such a configuration to it).  A pose that no rank rendered in
+    a step must keep grad = None on every rank -- Adam skips it, moments and step counter untouched -- as the single-rank
+    window-batch-2 run (and the reference's zero_grad(set_to_none=True) loop, slam/mapper.py:803-825,944-948) does; summing
+    "missing = zero" gradients instead would step the current pose by momentum in the iterations that render two keyframes."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), False, True), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["poses"], b["poses"])
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    torch.set_num_threads(2)
+    one = _build(WindowParallel(0, 1, batch=2), ba=True)
+    _run(one, True)
+    ref = _state(one)
+    for k in ref:
+        assert ref[k].shape == a[k].shape, k
+        assert torch.allclose(ref[k], a[k], rtol=1e-5, atol=1e-7), (k, (ref[k] - a[k]).abs().max())
+    # bundle adjustment really moved the poses (guards against comparing two runs without it)
+    plain = _build(WindowParallel(0, 1, batch=2), ba=False)
+    _run(plain, True)
+    assert not torch.allclose(_state(plain)["poses"], ref["poses"], rtol=1e-6, atol=1e-8)
+
+
+def _solo_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.set_num_threads(2)
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    _install_cpu_engine()
+    slam = _build(WindowParallel(0, 1, always_reduce=True), native=True)
+    for i in range(3):
+        slam.step(i)
+    torch.save(_state(slam), os.path.join(out, "solo.pt"))
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_one_rank_equal_the_plain_single_view_loop(tmp_path, monkeypatch):
+    """WindowParallel(always_reduce=True) with world_size 1: the multi-GPU orchestration of the native loops (gradient-output
+    mm3dgs_slam_map, the flat all-reduce -- the identity here --, mm3dgs_adam) must reproduce the in-kernel-Adam single-view loop.
+    The GPU suite runs the same thing over backend "nccl" (RCCL) on the HIP kernels (tests/test_gpu_rccl.py)."""
+    mp.spawn(_solo_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    a = torch.load(tmp_path / "solo.pt")
+    _install_cpu_engine(monkeypatch.setattr)
+    plain = _build(None, native=True)
+    for i in range(3):
+        plain.step(i)
+    ref = _state(plain)
+    for k in ref:
+        assert ref[k].shape == a[k].shape, k
+        assert torch.allclose(ref[k], a[k], rtol=1e-5, atol=1e-7), (k, (ref[k] - a[k]).abs().max())
