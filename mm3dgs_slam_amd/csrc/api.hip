@@ -229,6 +229,7 @@ struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks, slot_bits; 
 static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_capacity) {
   static const int no_direct = env_flag("MM3DGS_NO_DIRECT_BINS", 0);
   static const int no_fused_scan = env_flag("MM3DGS_NO_FUSED_SCAN", 0);
+  static const int max_tiles = env_flag("MM3DGS_DIRECT_MAX_TILES", MAX_FUSED_SCAN_TILES);
   DirectBins d;
   const int T = cd.gx * cd.gy;
   d.nblocks = (P + 255) / 256;
@@ -238,7 +239,7 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
   // records of the backward scratch per projection workgroup (the scratch holds NLIST records per pair of capacity)
   d.rec_cap = (uint32_t)std::min<size_t>((size_t)NLIST * N_capacity / nb, 0xffffffffull / nb);
   d.on = (flags & MM3DGS_FWD_DIRECT_BINS) && (flags & MM3DGS_FWD_STATE_CLEAN) && slam_fused_sort(flags) && !no_direct && !no_fused_scan &&
-         P > 0 && d.slot_bits >= DIRECT_SLOT_BITS_MIN && T <= MAX_FUSED_SCAN_TILES && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
+         P > 0 && d.slot_bits >= DIRECT_SLOT_BITS_MIN && T <= max_tiles && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
          N_capacity >= 4 * (size_t)P;
   return d;
 }

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 from random import randint
 
 import torch
@@ -194,7 +195,21 @@ class FusedEngine:
         self.img_state[32:36].zero_()
         self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
         self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
+        self._checked_P, self._checked_cap = self.P, self.n_cap
         return not overflow
+
+    def headroom(self):
+        """Smallest ratio capacity / (largest demand seen) over the three capacities a forward can run out of (pairs, per-tile
+        span, gradient records per projection workgroup), for the CURRENT buffers and map size; 0 when nothing has been measured
+        for them yet (fresh buffers, a map that changed size since the last check)."""
+        if self.ratio is None or self.P <= 0 or getattr(self, "_checked_P", -1) != self.P or getattr(self, "_checked_cap", -1) != self.n_cap:
+            return 0.0
+        T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        h = self.n_cap / max(self.ratio * self.P, 1.0)
+        if self.direct:
+            h = min(h, (self.n_cap // T) / max(self.max_tile_len, 1))
+            h = min(h, (16 * self.n_cap // max((self.P + 255) // 256, 1)) / max(getattr(self, "max_group_records", 0), 1))
+        return h
 
     def loss_call(self, cfg, gt_color, ref):
         _lib.check(self.lib.mm3dgs_loss(C.byref(cfg), _p(self.out), _p(gt_color), _p(ref), _p(self.loss_work), _p(self.dL),
@@ -237,6 +252,7 @@ class FusedTracker(Tracker):
             return super().optimize_cam(idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth, est_depth)
         eng = _engine(self.renderer)
         dev = eng.dev
+        t_start = time.perf_counter()
         with torch.no_grad():
             pose0 = torch.cat([camera_tensor_q.detach(), camera_tensor_T.detach()]).float().contiguous().clone()
             w_p, pmask, ref = 0.0, 0, None
@@ -270,11 +286,19 @@ class FusedTracker(Tracker):
                 raise RuntimeError("mm3dgs: tracking loop kept overflowing its binning capacity")
             camera_tensor_q.data.copy_(pose[:4])
             camera_tensor_T.data.copy_(pose[4:])
+            if self.cfg["debug"]["get_runtime_stats"]:
+                # the reference times each iteration on the host (slam/tracker.py:100,164-168); the native loop has no host iterations, so
+                # the whole loop is timed once (device-synchronised) and the averages time_sum / iter_count keep their meaning
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                self.tracking_time_sum += time.perf_counter() - t_start
             self.tracking_iter_count += num_iter
             return eng.loss[0].clone(), eng.out[:3].clone()
 
 
 class FusedMapper(Mapper):
+    always_snapshot = False      # debugging / tests: snapshot the map before every mapping loop (the round-2 behaviour)
+
     def _render_depth_sil(self, pose):
         # the keyframe test renders once per frame: one native forward instead of the ~40 torch launches of Renderer.render
         if not FusedEngine.eligible(self.cfg, self.gaussians):
@@ -359,6 +383,7 @@ class FusedMapper(Mapper):
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
+        t_start = time.perf_counter()
         g = self.gaussians
         lam = float(m["lambda_dssim"])
         w_p, pmask = 0.0, 0
@@ -438,13 +463,26 @@ class FusedMapper(Mapper):
         # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
         # (Pruning steps are NOT speculated on: measured on the benchmark sequence, 28 % of the frames prune something, and a
         # re-run of the whole loop costs far more than the 4-byte read-back of the new size that an exact step needs.)
-        snap, rng_state = g.snapshot(), _random.getstate()
+        # The snapshot (~24 device copies: every parameter, moment and statistic) is only taken when an overflow is conceivable: after
+        # the map changed size (a keyframe seeded, a step pruned), on fresh buffers, or when the largest demand seen is within 1.5x
+        # of a capacity (a frame's 150 Adam steps at the shipped learning rates cannot grow a tile list by that much).  Should a loop
+        # overflow without one, its iterations composited clamped tile lists (a few dropped (tile, splat) pairs): counted in
+        # `unrecovered_overflows`, warned about, capacity raised for the next frame.
+        eng._ensure(int(g._xyz.shape[0]), True)
+        need_snap = self.always_snapshot or getattr(eng, "headroom", lambda: 0.0)() < 1.5 or (self.window is not None and self.window._collective)
+        snap, rng_state = (g.snapshot() if need_snap else None), _random.getstate()
         for attempt in range(4):
             self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
             ok = eng.check_capacity()
             if self.window is not None and self.window._collective:
                 ok = not self.window.any_flag(not ok, device=eng.dev)
             if ok:
+                break
+            if snap is None:
+                import warnings
+                self.unrecovered_overflows = getattr(self, "unrecovered_overflows", 0) + 1
+                warnings.warn("mm3dgs: a mapping loop overflowed its binning capacity without a snapshot to restore (clamped tile lists "
+                              "in some of its iterations); capacity raised")
                 break
             self.loop_reruns = getattr(self, "loop_reruns", 0) + 1
             g.restore(snap)
@@ -463,6 +501,10 @@ class FusedMapper(Mapper):
             with torch.no_grad():
                 for k, (buf, _m, _v, _s, _ad, pose) in ba_state.items():
                     pose.data.copy_(buf)
+        if self.cfg["debug"]["get_runtime_stats"]:
+            if eng.dev.type == "cuda":
+                torch.cuda.synchronize(eng.dev)
+            self.mapping_time_sum += time.perf_counter() - t_start
         self.mapping_iter_count += num_iter
 
     def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):

@@ -229,6 +229,8 @@ class GaussianModel:
                 continue
             table[k].src, table[k].dst, table[k].width = old.data_ptr(), new.data_ptr(), w
             k += 1
+        if n == 0:
+            return      # every Gaussian pruned: the empty tensors are in place (their data_ptr() is NULL, nothing to move)
         _lib.check(lib.mm3dgs_compact_rows(P, C.c_void_p(keep.data_ptr()), C.c_void_p(work.data_ptr()), table, k, _stream()))
         self._surgery_keepalive = (pairs, keep, work)      # the launch is asynchronous
 

@@ -1,13 +1,20 @@
 """Frame loop: load -> track -> map (reference ``slam/SLAM.py:375-493``), over an in-memory RGB-D sequence.
 
-Only the hot-path part of the reference's orchestrator is mirrored: frame 0 takes the ground-truth pose
-(``SLAM.py:399-401``), later frames are tracked, ``camera_extent = max(depth) / scene_radius_depth_ratio`` is fixed on
-frame 0 (``:456-463``), then the mapper runs.  Dataset loaders, MiDaS depth alignment, video/checkpoint output and the
-evaluation metrics are out of scope."""
+The hot-path part of the reference's orchestrator: frame 0 takes the ground-truth pose (``SLAM.py:399-401``), later frames are
+tracked, ``camera_extent = max(depth) / scene_radius_depth_ratio`` is fixed on frame 0 (``:456-463``), then the mapper runs.
+Harness outputs in the reference's formats: ``save_map`` = ``outputdir/point_cloud/iteration_<n>/point_cloud.ply``
+(``SLAM.py:286-292``), ``save_iterations`` checkpoints inside ``run`` (``:488-492``) and the final map (``:497-500``),
+``save_results`` = ``outputdir/results.npz`` with the reference's key set (``:294-373``: pose_est, pose_gt, keyframes, ate_rmse,
+psnr_list, ssim_list, lpips_list, avg_tracking_it_time, avg_mapping_it_time), and resuming from a checkpoint when the
+configuration carries ``iteration`` (``:90-104`` map + poses, ``slam/mapper.py:65-71`` keyframes + covisibility graph).  Dataset
+loaders, MiDaS depth alignment, debug videos and LPIPS (a downloaded network; its list stays empty) are out of scope
+(SURVEY.md section 2)."""
 from __future__ import annotations
 
 import math
+import os
 
+import numpy as np
 import torch
 
 from . import synthetic
@@ -116,6 +123,10 @@ class SLAM:
         self.cfg = cfg
         self.seq = sequence
         self.gaussians = GaussianModel(cfg)
+        resume = None
+        if "iteration" in cfg:      # checkpoint: the map of save_map(iteration) and the poses / keyframes of results.npz (slam/SLAM.py:90-104)
+            self.gaussians.load_ply(os.path.join(cfg["outputdir"], "point_cloud", "iteration_" + str(cfg["iteration"]), "point_cloud.ply"))
+            resume = np.load(os.path.join(cfg["outputdir"], "results.npz"), allow_pickle=True)
         self.gaussians.training_setup()
         self.renderer = Renderer(cfg, rasterizer_cls=rasterizer_cls, settings_cls=settings_cls, mode=render_mode)
         n = len(sequence)
@@ -130,6 +141,19 @@ class SLAM:
         self.tracker = TrackerCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list, tf=getattr(sequence, "tf", None),
                                   tstamps=getattr(sequence, "tstamps", None))
         self.mapper = MapperCls(cfg, self.gaussians, self.renderer, self.estimate_pose_list, n_img=n, window=window)
+        self.gt_pose_list = [None] * n
+        if resume is not None:
+            dev = cfg["device"]
+            for i, p in enumerate(resume["pose_est"][:n]):
+                self.estimate_pose_list[i] = torch.tensor(p, device=dev)
+            # slam/mapper.py:65-71: KeyFrame(**kf) for every stored keyframe, then the covisibility graph is rebuilt edge by edge
+            from .mapper import KeyFrame
+            to_dev = lambda v: None if v is None else torch.as_tensor(v).to(dev)
+            for kf in resume["keyframes"]:
+                self.mapper.keyframes.append(KeyFrame(int(kf["idx"]), to_dev(kf["gt_color"]), to_dev(kf["est_pose"]), to_dev(kf["gt_depth"]),
+                                                      to_dev(kf["est_depth"])))
+            for k in range(len(self.mapper.keyframes)):
+                self.mapper.update_covisibility_graph(k)
 
     def step(self, idx):
         """Track + map one frame (the unit the headline metric counts)."""
@@ -142,10 +166,68 @@ class SLAM:
         if idx == 0:
             self.mapper.camera_extent = float(depth.max()) / self.cfg["scene_radius_depth_ratio"]
         self.mapper.run_frame(idx, color, depth, depth)
+        self.gt_pose_list[idx] = gt_pose.detach().clone()
 
-    def run(self):
-        for idx in range(len(self.seq)):
-            self.step(idx)
+    def run(self, progress=None):
+        """slam/SLAM.py:375-503: every frame; `save_iterations` checkpoints on the way; with an `outputdir` the final map (as
+        iteration <last_idx>) and results.npz at the end -- also when a frame raised, like the reference's try / finally."""
+        last_idx = 0
+        try:
+            for idx in range(len(self.seq)):
+                self.step(idx)
+                if progress is not None:
+                    progress(idx)
+                if "outputdir" in self.cfg and idx in self.cfg.get("save_iterations", ()):
+                    self.save_map(idx)
+                last_idx += 1
+        finally:
+            if "outputdir" in self.cfg and last_idx > 0:
+                with torch.no_grad():
+                    self.save_map(last_idx)
+                    self.save_results(last_idx)
+
+    # ---- outputs in the reference's formats ------------------------------------------------------------------------------------
+    def save_map(self, iteration):
+        path = os.path.join(self.cfg["outputdir"], "point_cloud", "iteration_{}".format(iteration))
+        os.makedirs(path, exist_ok=True)
+        self.gaussians.save_ply(os.path.join(path, "point_cloud.ply"))
+        return os.path.join(path, "point_cloud.ply")
+
+    def evaluate_images(self, last_idx):
+        """PSNR / SSIM of the map rendered from the estimated pose of frame 0 and every `eval_every`-th frame (slam/SLAM.py:197-231;
+        LPIPS needs a downloaded network and is left out: its list stays empty)."""
+        from .eval_utils import psnr
+        from .loss_utils import ssim
+        every = int(self.cfg.get("eval_every", 1))
+        psnr_list, ssim_list = [], []
+        with torch.no_grad():
+            for idx in range(last_idx):
+                if idx != 0 and (idx + 1) % every != 0:
+                    continue
+                color = self.seq[idx][0]
+                image = self.renderer.render(self.gaussians, camera_pose=self.estimate_pose_list[idx])["render"]
+                psnr_list.append(psnr(image, color).mean().detach().cpu().numpy())
+                ssim_list.append(ssim(image, color).detach().cpu().numpy())
+        return psnr_list, ssim_list, []
+
+    def save_results(self, last_idx):
+        """results.npz with the key set, shapes and types of slam/SLAM.py:294-373 (np.load(..., allow_pickle=True) reads the keyframe
+        dicts back, as slam/mapper.py:65-71 does)."""
+        from .eval_utils import evaluate_ate_rmse
+        est = torch.stack([p.detach() for p in self.estimate_pose_list[:last_idx]])
+        gt = torch.stack([p.detach() for p in self.gt_pose_list[:last_idx]])
+        results = {"pose_est": est.cpu().numpy(), "pose_gt": gt.cpu().numpy()}
+        results["keyframes"] = [{"idx": kf.idx, "gt_color": kf.gt_color, "est_pose": kf.pose, "gt_depth": kf.gt_depth, "est_depth": kf.est_depth}
+                                for kf in self.mapper.keyframes]
+        _, results["ate_rmse"] = evaluate_ate_rmse(est, gt, method="umeyama")          # on the raw (world->camera) vectors, as the reference does
+        psnr_list, ssim_list, lpips_list = self.evaluate_images(last_idx)
+        results["psnr_list"], results["ssim_list"], results["lpips_list"] = psnr_list, ssim_list, lpips_list
+        if self.cfg["debug"]["get_runtime_stats"]:
+            results["avg_tracking_it_time"] = self.tracker.tracking_time_sum / max(self.tracker.tracking_iter_count, 1) * 1000
+            results["avg_mapping_it_time"] = self.mapper.mapping_time_sum / max(self.mapper.mapping_iter_count, 1) * 1000
+        os.makedirs(self.cfg["outputdir"], exist_ok=True)
+        np.savez(os.path.join(self.cfg["outputdir"], "results"), **results)
+        return results
 
     def pose_errors(self):
         """Translation error (m) of every estimated pose against the sequence's ground truth."""

@@ -7,8 +7,11 @@ default of `mm3dgs_slam_amd.config.default_config`); a reference config whose `d
 accepted for its hot-path settings (iteration budgets, learning rates, pipeline flags, intrinsics) and run on the
 synthetic sequence as well, with `use_gt_depth` forced on and `niqe_kf` off (both need downloaded networks).
 
-Outputs in `outputdir`: `map.ply` (attribute layout of slam/gaussian_model.py:205-257) and `results.npz` (estimated and
-ground-truth poses, per-frame translation error, timings -- the pose part of slam/SLAM.py:294-373).
+Outputs in `outputdir`, in the reference's formats (slam/SLAM.py:286-373,488-500): `point_cloud/iteration_<n>/point_cloud.ply` for
+every frame index in `save_iterations` and for the final map (attribute layout of slam/gaussian_model.py:205-257), `results.npz`
+with the reference's keys (pose_est, pose_gt, keyframes, ate_rmse, psnr_list, ssim_list, lpips_list [empty: LPIPS needs a downloaded
+network], avg_tracking_it_time / avg_mapping_it_time with debug.get_runtime_stats).  A config that carries `iteration: <n>` resumes
+from that checkpoint (map, poses, keyframes, covisibility graph), like the reference.
 """
 import argparse
 import os
@@ -49,25 +52,25 @@ def main():
     cfg["use_gt_depth"] = True
     cfg["mapping"]["niqe_kf"] = False
     cfg["tracking"]["dynamics_model"] = "const_velocity" if cfg["tracking"].get("dynamics_model") == "imu" else cfg["tracking"].get("dynamics_model")
-    cfg["debug"] = {"get_runtime_stats": False, "create_video": False, "save_keyframes": False}
-    outdir = cfg.get("outputdir", "output/synthetic")
+    dbg = dict(cfg.get("debug") or {})
+    cfg["debug"] = {"get_runtime_stats": bool(dbg.get("get_runtime_stats", False)), "create_video": False, "save_keyframes": False}
+    cfg.setdefault("outputdir", "output/synthetic")
+    outdir = cfg["outputdir"]
     os.makedirs(outdir, exist_ok=True)
     seq = SyntheticSequence(cfg, args.frames, args.gaussians, seed=0)
     slam = SLAM(cfg, seq)
-    times = []
-    for i in range(len(seq)):
-        t0 = time.perf_counter()
-        slam.step(i)
+    times, t_last = [], [time.perf_counter()]
+
+    def progress(i):
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+        now = time.perf_counter()
+        times.append(now - t_last[0]); t_last[0] = now
         err = slam.pose_errors()[-1]
         print(f"frame {i:4d}  {times[-1] * 1e3:8.1f} ms  gaussians {slam.gaussians.get_xyz.shape[0]:7d}  pose error {err * 100:.2f} cm")
-    slam.gaussians.save_ply(os.path.join(outdir, "map.ply"))
-    np.savez(os.path.join(outdir, "results.npz"), estimate_pose_list=torch.stack(slam.estimate_pose_list).cpu().numpy(),
-             gt_pose_list=torch.stack(seq.poses).cpu().numpy(), translation_error=np.array(slam.pose_errors()),
-             frame_seconds=np.array(times), keyframes=np.array([kf.idx for kf in slam.mapper.keyframes]))
-    print(f"ATE-like RMSE {float(np.sqrt(np.mean(np.square(slam.pose_errors())))) * 100:.2f} cm; "
-          f"{1.0 / np.mean(times[1:]):.2f} frames/s after frame 0; outputs in {outdir}")
+
+    slam.run(progress)          # checkpoints, the final map and results.npz are written inside (reference formats)
+    res = np.load(os.path.join(outdir, "results.npz"), allow_pickle=True)
+    print(f"Average Trajectory Error RMSE: {float(res['ate_rmse'])} m; {1.0 / np.mean(times[1:]):.2f} frames/s after frame 0; outputs in {outdir}")
 
 
 if __name__ == "__main__":

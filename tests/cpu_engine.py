@@ -82,6 +82,9 @@ def install(fused_module, registry=None):
 
 
 class CpuEngine:
+    def headroom(self):
+        return 0.0          # (always snapshot: the stand-in has no capacity model)
+
     lib = _CpuLib()
 
     def __init__(self, renderer):

@@ -8,6 +8,7 @@ import torch
 from mm3dgs_slam_amd import general_utils, graphics_utils, pose_utils, sh_utils
 
 G = os.path.join(os.path.dirname(__file__), "golden")
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def load(name):
@@ -181,3 +182,49 @@ def test_g8_rel_pose_loss():
         c.grad = None
         q_l.backward()
         close(c.grad, d["rel_dq"][i], 2e-4)
+
+
+# ---- G10: harness outputs (slam/SLAM.py:294-373 executed by tests/golden/make_golden_results.py) ---------------------------------
+def test_g10_ate_rmse_matches_the_reference_umeyama_alignment():
+    from mm3dgs_slam_amd.eval_utils import evaluate_ate_rmse
+    F = np.load(os.path.join(HERE, "golden", "g10_results.npz"))
+    for k in range(3):
+        aligned, rmse = evaluate_ate_rmse(torch.from_numpy(F[f"ate{k}_est"]), torch.from_numpy(F[f"ate{k}_gt"]), method="umeyama")
+        assert abs(rmse - float(F[f"ate{k}_rmse"])) < 1e-6 * max(1.0, float(F[f"ate{k}_rmse"])), (k, rmse, F[f"ate{k}_rmse"])
+        a, b = np.asarray(aligned), F[f"ate{k}_aligned"]
+        assert np.allclose(a[:, 4:], b[:, 4:], atol=1e-5)
+        # quaternions up to sign (q and -q are the same rotation; the reference's rotation2quad picks a branch per matrix)
+        assert np.allclose(np.abs((a[:, :4] * b[:, :4]).sum(1)), 1.0, atol=1e-5)
+
+
+def test_g10_save_results_writes_the_reference_key_set_and_values(tmp_path):
+    """This repository's SLAM.save_results on the state the reference's own save_results was run on: same keys in the same order,
+    same shapes / dtypes / values, keyframe dicts that slam/mapper.py:65-71 could read back (KeyFrame(**kf))."""
+    import types
+    from mm3dgs_slam_amd.mapper import KeyFrame
+    from mm3dgs_slam_amd.slam import SLAM
+    F = np.load(os.path.join(HERE, "golden", "g10_results.npz"))
+    est, gt, last = torch.from_numpy(F["sr_est"]), torch.from_numpy(F["sr_gt"]), int(F["sr_last_idx"])
+    kfs = [KeyFrame(int(i), torch.from_numpy(c), torch.from_numpy(p), torch.from_numpy(d), None)
+           for i, c, p, d in zip(F["sr_kf_idx"], F["sr_kf_gt_color"], F["sr_kf_est_pose"], F["sr_kf_gt_depth"])]
+    t_sum, t_n, m_sum, m_n = (float(v) for v in F["sr_timing_inputs"])
+    ev = tuple([np.float32(v) for v in row] for row in F["sr_eval_lists"])
+    fake = types.SimpleNamespace(cfg={"outputdir": str(tmp_path), "debug": {"create_video": False, "get_runtime_stats": True}},
+                                 estimate_pose_list=list(est), gt_pose_list=list(gt),
+                                 mapper=types.SimpleNamespace(keyframes=kfs, mapping_time_sum=m_sum, mapping_iter_count=int(m_n)),
+                                 tracker=types.SimpleNamespace(tracking_time_sum=t_sum, tracking_iter_count=int(t_n)),
+                                 evaluate_images=lambda last_idx: ev)
+    SLAM.save_results(fake, last)
+    res = np.load(tmp_path / "results.npz", allow_pickle=True)
+    assert list(res.keys()) == [str(k) for k in F["keys"]]
+    for k in ("pose_est", "pose_gt", "psnr_list", "ssim_list", "lpips_list"):
+        assert res[k].shape == F["sr_" + k].shape and res[k].dtype == F["sr_" + k].dtype, (k, res[k].shape, res[k].dtype, F["sr_" + k].dtype)
+        assert np.allclose(res[k], F["sr_" + k], atol=1e-7), k
+    for k in ("ate_rmse", "avg_tracking_it_time", "avg_mapping_it_time"):
+        assert res[k].shape == () and abs(float(res[k]) - float(F["sr_" + k])) < 1e-6 * max(1.0, abs(float(F["sr_" + k]))), (k, res[k], F["sr_" + k])
+    kf_read = list(res["keyframes"])
+    assert sorted(kf_read[0].keys()) == [str(k) for k in F["sr_kf_keys"]]
+    assert [kf["idx"] for kf in kf_read] == [int(i) for i in F["sr_kf_idx"]]
+    for kf, c, p, d, none in zip(kf_read, F["sr_kf_gt_color"], F["sr_kf_est_pose"], F["sr_kf_gt_depth"], F["sr_kf_est_depth_is_none"]):
+        assert torch.is_tensor(kf["gt_color"]) and np.array_equal(kf["gt_color"].numpy(), c) and np.array_equal(kf["est_pose"].numpy(), p)
+        assert np.array_equal(kf["gt_depth"].numpy(), d) and (kf["est_depth"] is None) == bool(none)

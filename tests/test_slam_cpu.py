@@ -351,3 +351,47 @@ def test_native_loops_hand_the_reference_loss_of_each_method_to_the_c_loops(monk
             else:
                 assert as_dict(lc) == dict(w_l1=0.8, w_ssim=0.2, w_pearson=0.05, l1_mask=0.0, pearson_mask=2.0, pearson_invert=0.0, sil_thr=0.5,
                                            w_depth_l1=0.0, depth_l1_mask=0.0, l1_sum=0.0)
+
+
+def test_checkpoints_results_and_resume_in_the_reference_formats(tmp_path):
+    """slam/SLAM.py:286-292,488-500 (point_cloud/iteration_<n>/point_cloud.ply for `save_iterations` and the final map), :294-373
+    (results.npz) and :90-104 + slam/mapper.py:65-71 (`iteration` in the configuration resumes: map, poses, keyframes, graph)."""
+    import os
+    import random
+    import numpy as np
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.renderer import Renderer
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    from oracle.raster_ref import RefRasterizer
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 2}, mapping={"iters": 3, "kf_every": 1, "min_covisibility": 2.0},
+                         outputdir=str(tmp_path), save_iterations=[1], debug={"get_runtime_stats": True, "create_video": False, "save_keyframes": False})
+    seq = SyntheticSequence(cfg, 3, 500, seed=5, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
+    slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer)
+    slam.run()
+    for it in (1, 3):
+        assert os.path.exists(tmp_path / "point_cloud" / f"iteration_{it}" / "point_cloud.ply")
+    res = np.load(tmp_path / "results.npz", allow_pickle=True)
+    assert list(res.keys()) == ["pose_est", "pose_gt", "keyframes", "ate_rmse", "psnr_list", "ssim_list", "lpips_list", "avg_tracking_it_time",
+                                "avg_mapping_it_time"]
+    assert res["pose_est"].shape == (3, 7) and res["pose_gt"].shape == (3, 7) and len(res["psnr_list"]) == 3 and len(res["lpips_list"]) == 0
+    assert float(res["avg_tracking_it_time"]) > 0 and float(res["avg_mapping_it_time"]) > 0
+    assert [kf["idx"] for kf in res["keyframes"]] == [kf.idx for kf in slam.mapper.keyframes]
+    # resume from the final checkpoint
+    cfg2 = dict(cfg, iteration=3)
+    again = SLAM(cfg2, seq, rasterizer_cls=RefRasterizer)
+    g0, g1 = slam.gaussians, again.gaussians
+    assert g1._xyz.shape == g0._xyz.shape and g1._xyz.shape[0] > 0
+    for name in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+        assert torch.allclose(getattr(g1, name).detach(), getattr(g0, name).detach(), atol=1e-6), name
+    assert [kf.idx for kf in again.mapper.keyframes] == [kf.idx for kf in slam.mapper.keyframes]
+    assert len(slam.mapper.keyframes) >= 2
+    # (the reference rebuilds the graph with update_covisibility_graph(k) for every k, slam/mapper.py:65-71, which compares keyframe k
+    #  with keyframes[:-1] -- itself included: a resumed graph carries self-loops the live one does not; mirrored, not "fixed")
+    graph = lambda m: {k: {j for j in v if j != k} for k, v in m.covisibility_graph.items() if set(v) - {k}}
+    assert graph(again.mapper) == graph(slam.mapper) and graph(slam.mapper)
+    for a, b in zip(again.estimate_pose_list, slam.estimate_pose_list):
+        assert torch.allclose(a, b.detach(), atol=1e-7)
+    n_before = g1._xyz.shape[0]
+    again.step(0)       # frame 0 of a resumed run does NOT reseed every pixel (slam/mapper.py:409-418: `"iteration" not in cfg`)
+    assert again.gaussians._xyz.shape[0] < n_before + 0.5 * 32 * 48

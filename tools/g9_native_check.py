@@ -11,7 +11,7 @@ import torch
 from tests.test_gpu_golden_slam import run_variant
 
 if __name__ == "__main__":
-    for variant in (sys.argv[1:] or ["vigs", "splatam", "ba", "imu", "estdepth", "white_bg"]):
+    for variant in (sys.argv[1:] or ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"]):
         try:
             slam, G, rows = run_variant(variant, verbose=True)
         except Exception as e:      # keep going: this is a survey
