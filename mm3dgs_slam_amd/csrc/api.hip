@@ -229,7 +229,7 @@ struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks, slot_bits; 
 static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_capacity) {
   static const int no_direct = env_flag("MM3DGS_NO_DIRECT_BINS", 0);
   static const int no_fused_scan = env_flag("MM3DGS_NO_FUSED_SCAN", 0);
-  static const int max_tiles = env_flag("MM3DGS_DIRECT_MAX_TILES", MAX_FUSED_SCAN_TILES);
+  static const int max_tiles = env_flag("MM3DGS_DIRECT_MAX_TILES", 11264);   // the binning kernel keeps one LDS word per tile beside 18 KB of static LDS: 62 KB at this limit (1920x1080 = 8160 tiles, 1920x1440 = 10800)
   DirectBins d;
   const int T = cd.gx * cd.gy;
   d.nblocks = (P + 255) / 256;
@@ -259,6 +259,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
     if (hipMemsetAsync(image_state, 0, iv.zero_bytes, s) != hipSuccess) return fail(-10, "memset failed");
   cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
   cd.bg_extras = 1;
+  cd.state_clean = (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0;
   // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
@@ -277,8 +278,8 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
   { ProfScope ps((fused_sort && track_dsub) ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
-    if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, *tl, 0, track_dsub);
-    else if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, cd.fused_scan ? 1 : 0, s, tl);
+    if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, (cd.fused_scan || cd.state_clean) ? 1 : 0, s, *tl, 0, track_dsub);
+    else if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, (cd.fused_scan || cd.state_clean) ? 1 : 0, s, tl);
     else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");
 }

@@ -247,7 +247,10 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
   int T = cam.gx * cam.gy;
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const int lds_tiles = T <= MAX_LDS_TILES ? T : 0;
-  const int clean = cam.fused_scan ? 1 : 0;
+  // persistent state: the sort leaves cursor[] (and tile_count[]) zero -- the direct-bin path of the NEXT forward counts from zero.
+  // (Without the fused scan, scan_tiles seeds cursor[] with the range starts and the scatter leaves the range ends there: on tile grids
+  //  above MAX_FUSED_SCAN_TILES a following direct-bin forward read those as pair counts -- garbage ids, out-of-bounds records.)
+  const int clean = (cam.fused_scan || cam.state_clean) ? 1 : 0;
   if (cam.fused_scan)   // P > 0 and T <= MAX_FUSED_SCAN_TILES guaranteed by the caller
     hipLaunchKernelGGL(scatter_scan_kernel, dim3((P + 255) / 256), dim3(256), (size_t)T * 8, s, P, cam.gx, T, (P + 255) / 256, g, iv, b, ncap);
   else if (P > 0)

@@ -196,6 +196,7 @@ struct CamDev {
   int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
   int bg_extras;    // 1 (SLAM entry points): channels 3..5 are the depth bundle of a second reference pass and get T_final * bg[ch - 3] as well
+  int state_clean;  // 1: persistent state buffers (MM3DGS_FWD_STATE_CLEAN): every forward leaves tile_count[] and cursor[] zero for the next one
   int fused_scan;   // 1: no scan_tiles launch, every scatter workgroup scans the tile counters itself (persistent state)
   const float* bg;
   const float* view;
@@ -220,6 +221,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.exp = env_flag("MM3DGS_EXP", 0);
   d.sort_single = 0;
   d.bg_extras = 0;
+  d.state_clean = 0;
   d.fused_scan = 0;
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
   return d;

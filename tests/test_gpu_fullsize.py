@@ -122,11 +122,17 @@ def test_native_engine_agrees_with_generic_path_at_full_size(name):
     assert pu.rel_l2(eng.grads["xyz"], g._xyz.grad) < 5e-3 and pu.rel_l2(eng.grads["opacity"], g._opacity.grad) < 5e-3
 
 
-@pytest.mark.parametrize("name", ["C2_tum_150k", "C4_replica_1M"])
+CONFIGS["D_1080p_600k"] = (1080, 1920, 600000, False, 0)      # 8160 tiles: above the 4096-tile limit of the fused scan
+
+
+@pytest.mark.parametrize("name", ["C2_tum_150k", "C4_replica_1M", "D_1080p_600k"])
 def test_direct_bins_equal_packed_bins_at_full_size(name):
     """The native engine's first render of a map uses packed bins (it has not seen a tile list yet), the following ones direct bins
     (projection + binning in one launch; at 1 M Gaussians the key's low word splits 20 id bits / 12 slot bits): same image, same
-    radii, same gradients, bit for bit."""
+    radii, same gradients, bit for bit.  1920x1080 (8160 tiles) is the grid on which round 2's first attempt "did not terminate": above
+    4096 tiles the packed path runs without the fused scan, whose scan / scatter kernels used to leave the tile cursors at the range
+    ends -- the following direct-bin forward read them as pair counts (garbage ids and record indices: out-of-bounds accesses, or
+    endless sort loops).  The sort now zeroes them whenever the state buffers are persistent."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.fused import FusedEngine
     from mm3dgs_slam_amd.gaussian_model import GaussianModel
@@ -144,14 +150,16 @@ def test_direct_bins_equal_packed_bins_at_full_size(name):
     eng = FusedEngine(Renderer(cfg))
     w = torch.randn(6, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     outs = []
-    for want_direct in (False, True):
+    for want_direct in (False, True, True):
         si = eng.forward(pose, g, need_grads=True)
         assert eng.direct == want_direct, (eng.direct, eng.max_tile_len, eng.n_cap)
+        torch.cuda.synchronize()
+        assert (int(eng.img_state[:32].view(torch.int32)[7].item()) != 0) == want_direct      # header.bin_cap: the library really took that path
         eng.dL.copy_(w)
         eng.backward(si, grads=eng.grads, dpose=eng.dpose)
         outs.append((eng.out.clone(), eng.radii.clone(), eng.dpose.clone(), {k: v.clone() for k, v in eng.grads.items()}))
         assert eng.check_capacity()
-    a, b = outs
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    for k in a[3]:
-        assert torch.equal(a[3][k], b[3][k]), k
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k

@@ -108,10 +108,10 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
             bar = 1e-2 if variant == "ba" else 1e-3
         assert r["pose_diff"] < bar, (idx, r["pose_diff"], bar)
         tol = np.full(8, 1e-4 if aligned else 5e-3)
-        if not tight:
-            tol[7] = 2e-3                               # mean quaternion w: the noise-driven random walk described above
-            if idx > 1:
-                tol[:7] = np.maximum(tol[:7], 5e-4)
+        if variant != "vigs_rotfrozen":
+            tol[7] = 2e-3                               # mean quaternion w: the noise-driven random walk described above (`imu`: unobservable, force_isotropic)
+        if not tight and idx > 1:
+            tol[:7] = np.maximum(tol[:7], 5e-4)
         assert np.all(np.abs(r["moments"] - r["moments_ref"]) <= tol + tol * np.abs(r["moments_ref"])), (idx, r["moments"], r["moments_ref"])
     graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
     assert graph == [str(s) for s in G["graph"]]
