@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--full-seed-steps", type=int, default=10,
                     help="slam, 1 GPU: a second run with the reference-faithful seeding (one Gaussian per valid frame-0 pixel, ~292 k), "
                          "this many timed frames, reported as `full_seed` (0 = skip)")
+    ap.add_argument("--moving-frames", type=int, default=60,
+                    help="slam, 1 GPU: a further run on a camera that keeps moving (cumulative ~1 cm / 0.45 deg per frame, peaks 1.4 cm / 0.65 deg: a keyframe "
+                         "every few frames, seeding, a growing map, a filling window), this many timed frames, reported as `moving` (0 = skip)")
     ap.add_argument("--window-batch", type=int, default=1, help="views per rank and optimiser step in the mapping window (SURVEY 8e)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
@@ -364,7 +367,7 @@ def main():
         frac = args.seed_fraction or 1.0      # the reference's seeding: ~0.78 M Gaussians from frame 0, growing with every keyframe
         steady = 0
 
-    def build(frac_, n_frames, n_target):
+    def build(frac_, n_frames, n_target, motion="bounded"):
         if c3:
             from mm3dgs_slam_amd.config import utmm_config
             cfg = utmm_config(device=dev, tracking={"iters": args.track_iters, "use_imu_loss": True, "imu_T_weight": 1.0, "imu_q_weight": 0.1},
@@ -373,7 +376,7 @@ def main():
             cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
                                  mapping={"iters": args.map_iters, "seed_fraction": frac_})
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
-        seq = SyntheticSequence(cfg, n_frames, n_target, seed=0)        # untimed: builds the RGB-D frames on the GPU
+        seq = SyntheticSequence(cfg, n_frames, n_target, seed=0, motion=motion)        # untimed: builds the RGB-D frames on the GPU
         window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives)
                   if (world > 1 or args.window_batch > 1 or args.force_collectives) else None)
         return SLAM(cfg, seq, render_mode=args.render_mode, window=window)
@@ -496,6 +499,12 @@ def main():
             for pre, match in pmc_names.items():
                 if r_["kernel"].startswith(pre):
                     r_["traffic"], r_["traffic_source"] = pmc_traffic(match)
+                    if r_["traffic"]:
+                        # the same duration against the bytes the kernel really moved (counters): what `frac` would be if the contract's
+                        # algorithmic bytes were exactly what goes over the HBM pins (above 1x: re-reads / records; below: bytes of the
+                        # contract that this design never moves, e.g. the 6-pass global radix sort)
+                        r_["traffic_frac"] = r_["traffic"] / (r_["avg_launch_us"] * 1e-6) / 1e9 / 8000.0
+                        r_["traffic_over_algorithmic"] = r_["traffic"] / r_["algorithmic_bytes_per_launch"]
             if r_["kernel"].startswith("composite_bwd_kernel<6,1>"):
                 # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any early-out, ~25 flop + 1 exp
                 # each, against the dense f32 VALU peak -- the ceiling this kernel actually runs into (profiles/r01_sq_counters.md)
@@ -518,9 +527,15 @@ def main():
             slam.step(i)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        with torch.no_grad():
+            slam.renderer.render(slam.gaussians, slam.estimate_pose_list[first + steady - 1])
+        N_end = rasterizer.last_header()["num_rendered"]
         out["steady_state"] = {"frames": steady, "value": steady / el, "unit": "frames/s", "ms_per_frame": el / steady * 1e3,
                                "gaussians_at_end": int(slam.gaussians.get_xyz.shape[0]), "keyframes": len(slam.mapper.keyframes),
-                               "note": f"frames {first}..{first + steady - 1} of the run above (same map, same budget, keyframe work included)"}
+                               "num_rendered_pairs_at_end": N_end, "pairs_growth": N_end / max(N, 1),
+                               "note": f"frames {first}..{first + steady - 1} of the run above (same map, same budget, keyframe work included).  The map keeps "
+                                       f"optimising: with the thinned seeding the splats grow to close the gaps, so the (tile, splat) pairs N -- the unit every "
+                                       f"kernel's work is proportional to -- grow by `pairs_growth` while the Gaussian count stays put"}
     if extras and args.full_seed_steps and frac < 1.0 and not c3 and not c4:
         log("full-seed run (one Gaussian per valid frame-0 pixel)")
         del slam
@@ -539,6 +554,36 @@ def main():
         out["full_seed"] = {"frames": args.full_seed_steps, "value": args.full_seed_steps / el, "unit": "frames/s", "ms_per_frame": el / args.full_seed_steps * 1e3,
                             "gaussians": int(slam2.gaussians.get_xyz.shape[0]),
                             "note": "reference-faithful frame-0 seeding (slam/mapper.py:437-474: every valid-depth pixel), same iteration budget"}
+    if extras and args.moving_frames and not c3 and not c4:
+        log("moving-camera run")
+        try:
+            del slam2
+        except NameError:
+            pass
+        slam = None
+        torch.cuda.empty_cache()
+        n_mv = 3 + args.moving_frames
+        slam3 = build(frac, n_mv, args.gaussians, motion="moving")
+        slam3.step(0)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        for i in (1, 2):
+            slam3.step(i)
+        torch.cuda.synchronize()
+        P0, kf0 = int(slam3.gaussians.get_xyz.shape[0]), len(slam3.mapper.keyframes)
+        t0 = time.perf_counter()
+        for i in range(3, n_mv):
+            slam3.step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        errs = slam3.pose_errors()
+        out["moving"] = {"frames": args.moving_frames, "value": args.moving_frames / el, "unit": "frames/s", "ms_per_frame": el / args.moving_frames * 1e3,
+                         "gaussians_start": P0, "gaussians_end": int(slam3.gaussians.get_xyz.shape[0]), "keyframes_start": kf0,
+                         "keyframes_end": len(slam3.mapper.keyframes), "final_translation_error_cm": errs[-1] * 100.0,
+                         "rmse_translation_error_cm": float(np.sqrt(np.mean(np.square(errs)))) * 100.0,
+                         "note": "same scene, map size and iteration budget on a camera that keeps moving (mm3dgs_slam_amd.slam.trajectory_moving: lateral sweep "
+                                 "past the scene, cumulative ~1 cm / 0.45 deg per frame): keyframe insertion, seeding of the newly seen regions, map growth and a "
+                                 "mapping window of several keyframes are inside the timed frames (the headline trajectory is a bounded +-3 cm wobble)"}
+        del slam3
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")
         out["cpu_baseline"] = cpu_baseline(args)

@@ -42,18 +42,45 @@ def trajectory(n, step_t=0.01, step_r=0.008):
     return out
 
 
+def trajectory_moving(n, step_t=0.014, step_r=0.014):
+    """A camera that keeps MOVING (the bench's `moving` line): a lateral sweep of +-0.5 m past the scene at up to `step_t` m per frame
+    (TUM fr1/desk: ~1.4 cm per frame) with the yaw that keeps the scene centre (3 m ahead) in view, a slow vertical bob and a roll /
+    pitch wobble of up to `step_r` rad (0.8 degrees) per frame.  Unlike `trajectory` the displacement accumulates -- tens of
+    centimetres within a few dozen frames --, so the keyframe test fires every handful of frames, new Gaussians are seeded, the map
+    grows and the mapping window fills.  Returns n 4x4 world->camera matrices."""
+    out = []
+    A = 0.5
+    w = step_t / A                                    # peak speed A w = step_t
+    for i in range(n):
+        x = A * math.sin(w * i)
+        y = 0.08 * math.sin(0.5 * w * i + 0.7)
+        z = 0.10 * (1.0 - math.cos(0.6 * w * i))
+        yaw = math.atan2(x, 3.0)                      # look at the point 3 m in front of the start pose
+        pitch = -math.atan2(y, 3.0) + (0.55 * step_r / 0.15) * math.sin(0.15 * i)      # wobble: amplitude x frequency = rate per frame
+        roll = (0.5 * step_r / 0.2) * math.sin(0.2 * i + 0.4)
+        cy_, sy_, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+        Ry = torch.tensor([[cy_, 0, -sy_], [0, 1, 0], [sy_, 0, cy_]])          # camera-to-world yaw about the camera's y axis (x right, y down, z forward)
+        Rx = torch.tensor([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = torch.tensor([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        c2w = torch.eye(4)
+        c2w[:3, :3] = (Ry @ Rx @ Rz).float()
+        c2w[:3, 3] = torch.tensor([x, y, z])
+        out.append(torch.linalg.inv(c2w))
+    return out
+
+
 class SyntheticSequence:
     """RGB-D frames rendered from a fixed ground-truth Gaussian map along ``trajectory`` (built once, untimed).
     The ground-truth map is the seeded first frame of ``synthetic.rgbd_frame``."""
 
-    def __init__(self, cfg, n_frames, n_gaussians, seed=0, renderer=None):
+    def __init__(self, cfg, n_frames, n_gaussians, seed=0, renderer=None, motion="bounded"):
         dev = cfg["device"]
         H, W = int(cfg["desired_height"]), int(cfg["desired_width"])
         c = cfg["cam"]
         color, depth = synthetic.rgbd_frame(H, W, seed=seed)
         G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], n_gaussians, seed=seed)
         self.seed_params = {k: v.to(dev) for k, v in G.items()}
-        self.poses = [get_tensor_from_camera(M).to(dev) for M in trajectory(n_frames)]
+        self.poses = [get_tensor_from_camera(M).to(dev) for M in (trajectory_moving if motion == "moving" else trajectory)(n_frames)]
         self.frames = []
         renderer = renderer or Renderer(cfg)
         gt = _FixedMap(self.seed_params, cfg, opaque=True)

@@ -5,10 +5,11 @@
 # C5 = 1080p / 3 M Gaussians / SH degree 3).
 # Run on the GPU box from the repo root: bash tools/profile_round.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG; mkdir -p $OUT
-SHORT="--steps 2 --warmup 1 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0"
+# the counter passes run the bench's OWN default steps / warm-up (the same frames, the same map state as the line they annotate)
+SHORT="--no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --profile 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_$C -o pmc -- python bench.py $SHORT > /dev/null 2>&1
   python - "$C" "$OUT" <<'PY'
@@ -31,7 +32,7 @@ done
 mkdir -p profiles; cp $OUT/slam_pmc_FETCH_SIZE.csv profiles/${TAG}_slam_pmc_FETCH_SIZE.csv; cp $OUT/slam_pmc_WRITE_SIZE.csv profiles/${TAG}_slam_pmc_WRITE_SIZE.csv
 python bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
 # same command as the bench line (minus the follow-up runs), so the per-kernel averages are over the same frames as roofline.avg_launch_us
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 > $OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 > $OUT/bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 python bench.py --workload c3 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 2>/dev/null | tee $OUT/bench_c3.json | cut -c1-300
 python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_c4.json | cut -c1-300
