@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmm3dgs_hip.so")
+# MM3DGS_LIB: developer switch -- a variant build of the same library (tools/build_variant.sh), for accuracy / speed experiments
+LIB_PATH = os.environ.get("MM3DGS_LIB") or os.path.join(_HERE, "csrc", "libmm3dgs_hip.so")
 
 
 class Mm3dgsCamera(C.Structure):

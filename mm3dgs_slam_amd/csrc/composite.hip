@@ -97,7 +97,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
       n_iter++;
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
-      const float alpha = fminf(0.99f, B.y * __expf(power));
+      const float alpha = fminf(0.99f, B.y * SPLAT_EXP(power));
       const bool ok = !done && (base + (uint32_t)j < count) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       const float test_T = Tr * (1.f - alpha);
       const bool stop = ok && (test_T < T_EPS);
@@ -480,7 +480,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
       const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the row's list (garbage when !row_on)
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
-      const float G = __expf(power);
+      const float G = SPLAT_EXP(power);
       const float alpha = fminf(0.99f, B.y * G);
       const bool valid = row_on && (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       float tot = 0.f;
@@ -491,7 +491,11 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         const float G_eff = valid ? G : 0.f;
         // generic mode: correctly rounded division -- T is rebuilt by ~50 successive divisions per pixel and the 1-ulp v_rcp_f32
         // showed up as 5e-6 of noise on every gradient (camera gradients are held to 1e-5); the SLAM modes keep v_rcp_f32
+#ifdef MM3DGS_SLAM_EXACT_DIV      // developer experiment (tools/build_variant.sh): what the 1-ulp v_rcp_f32 costs the SLAM modes in accuracy
+        const float r = 1.f / (1.f - a_eff);
+#else
         const float r = MODE == 0 ? 1.f / (1.f - a_eff) : __builtin_amdgcn_rcpf(1.f - a_eff);
+#endif
         Tr *= r;  // transmittance in front of this splat
         const float w = a_eff * Tr;
         float col[C];

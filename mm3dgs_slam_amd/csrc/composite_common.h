@@ -29,6 +29,13 @@ __device__ __forceinline__ void st_part(float* p, const float4& v, int n) {
   else if (n == 1) p[0] = v.x;
 }
 
+// exp of the Gaussian's power: v_exp_f32 on power * log2(e) (forward and backward use the same sequence: same decisions).
+// MM3DGS_SLAM_EXACT_EXP: developer experiment (tools/build_variant.sh) with the correctly rounded expf.
+#ifdef MM3DGS_SLAM_EXACT_EXP
+#define SPLAT_EXP(p) expf(p)
+#else
+#define SPLAT_EXP(p) __expf(p)
+#endif
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 

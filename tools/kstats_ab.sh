@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 VAR=${1:-MM3DGS_NO_DIRECT_BINS}; VALS=${2:-"0 1"}
 for V in $VALS; do
   rm -rf /tmp/p_ks
-  env $VAR=$V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -o ks -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --profile 0 > /tmp/ks.json 2>/dev/null
+  env $VAR=$V rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -o ks -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --profile 0 > /tmp/ks.json 2>/dev/null
   python - "$VAR=$V" <<'PY'
 import csv, glob, json, sys
 d = json.load(open("/tmp/ks.json"))
