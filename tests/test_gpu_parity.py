@@ -181,3 +181,27 @@ def test_tracker_converges_to_ground_truth_pose_on_gpu():
     errs = slam.pose_errors()
     motion = float((seq.poses[2][4:] - seq.poses[0][4:]).norm())
     assert errs[1] < 0.01 and errs[2] < 0.01, (errs, motion)
+
+
+def test_seed_sweep_of_the_generic_path_states_how_often_the_bar_is_met():
+    """20 consecutive seeds (nothing hand-picked; SH degree cycling 0..3, every third scene with extra channels): the fraction of
+    scenes whose camera gradients all meet the 1e-5 bar, and the worst case.  Measured on MI355X (tools/parity_sweep.py, 24 scenes): all
+    under 3.5e-6.  Asserted: at least 90 % of the scenes under 1e-5 and no scene above FLIP_TOL (5e-5) -- so that a regression cannot
+    be absorbed by re-picking the seeds of the cases above."""
+    worst, under = 0.0, 0
+    n = 20
+    for i in range(n):
+        deg = i % 4
+        kw = dict(P=2000, H=80, W=112, seed=2000 + i, sh_degree=deg, posed=True)
+        if i % 3 == 1:
+            kw["extras"] = 3 if deg == 0 else 0
+        m = pu.compare(pu.make_case(**kw))
+        cam = max(m[k] for k in ("d_view", "d_proj", "d_campos") if k in m)
+        assert m["img"] <= pu.IMG_TOL, (i, m)
+        worst = max(worst, cam)
+        under += 1 if cam <= pu.POSE_TOL else 0
+        for k, v in m.items():
+            if k.startswith("d_") and k not in ("d_view", "d_proj", "d_campos") and isinstance(v, float):
+                assert v <= pu.GRAD_TOL, (i, k, m)
+    assert under >= 0.9 * n, (under, n, worst)
+    assert worst <= 5e-5, worst
