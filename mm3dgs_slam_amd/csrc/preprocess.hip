@@ -32,50 +32,6 @@ __device__ __forceinline__ void sh_row_store(float* __restrict__ row, const floa
   for (int j = 0; j < MV * 3 / 4; j++) r[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
-// ---- SH rows of degree 3 (M = 16: 192 B per Gaussian) through LDS -------------------------------------------------------------
-// Even as float4s a lane-per-row access makes every load / store instruction of a wave touch 64 different cache lines (row stride
-// 192 B).  The wave's 64 rows are one contiguous 12 KB span: it is moved with lane-contiguous float4 accesses (6 instructions x 1 KB
-// per half row) and transposed through a wave-private LDS slice, half a row (8 coefficients) at a time (28-word row stride: 16-byte
-// aligned, the lanes of a ds_read_b128 phase start on different banks).  28.7 KB per workgroup: three workgroups per CU stay resident.
-#define SHS_HALF_F 24                 // floats per half row
-#define SHS_STRIDE 28                 // LDS words per staged half row
-// half h of the wave's rows -> this lane's 24 floats (coefficients 8h .. 8h+7)
-__device__ __forceinline__ void shs_stage_load_half(const float* __restrict__ shs, long long wave_row0, int rows_live, float* ws, int lane, int h,
-                                                    float (&sv)[SHS_HALF_F]) {
-  float4 q[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int f = j * 64 + lane, row = f / 6, c4 = f - row * 6;
-    q[j] = row < rows_live ? *(const float4*)(shs + (size_t)(wave_row0 + row) * 48 + h * SHS_HALF_F + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int f = j * 64 + lane, row = f / 6, c4 = f - row * 6;
-    *(float4*)(ws + row * SHS_STRIDE + c4 * 4) = q[j];
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const float4 v = *(const float4*)(ws + lane * SHS_STRIDE + j * 4);
-    sv[4 * j] = v.x; sv[4 * j + 1] = v.y; sv[4 * j + 2] = v.z; sv[4 * j + 3] = v.w;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-// this lane's 24 floats of half h -> the wave's rows in memory
-__device__ __forceinline__ void shs_stage_store_half(float* __restrict__ dshs, long long wave_row0, int rows_live, float* ws, int lane, int h,
-                                                     const float (&ov)[SHS_HALF_F]) {
-#pragma unroll
-  for (int j = 0; j < 6; j++) *(float4*)(ws + lane * SHS_STRIDE + j * 4) = make_float4(ov[4 * j], ov[4 * j + 1], ov[4 * j + 2], ov[4 * j + 3]);
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    const int f = j * 64 + lane, row = f / 6, c4 = f - row * 6;
-    const float4 v = *(const float4*)(ws + row * SHS_STRIDE + c4 * 4);
-    if (row < rows_live) *(float4*)(dshs + (size_t)(wave_row0 + row) * 48 + h * SHS_HALF_F + c4 * 4) = v;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
 template <int MV>
 __global__ void __launch_bounds__(PP_BLOCK)
 preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
@@ -233,7 +189,7 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
 // finishing kernel adds the rows in double precision in a fixed order (deterministic, no atomics).
 #define NCAM 27
 template <int MV>
-__global__ void __launch_bounds__(PP_BLOCK, 3)   // three waves per SIMD (<= 170 VGPRs): the degree-3 variant sat at 175
+__global__ void __launch_bounds__(PP_BLOCK)
 preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
                       const float* __restrict__ shs, const float* __restrict__ colors,
                       const float* __restrict__ opac, const float* __restrict__ scales,
@@ -277,17 +233,12 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     // a record shorter than 12 floats: what the last float4 picked up past its end belongs to the next record
     if (C < 6) { if (C < 3) { acc2.x = 0.f; } if (C < 4) acc2.y = 0.f; if (C < 5) acc2.z = 0.f; acc2.w = 0.f; if (C < 2) acc1.w = 0.f; if (C < 1) acc1.z = 0.f; }
   }
-  // MV == 16 (degree-3 rows): the SH section runs wave-wide between the per-Gaussian chain rule and the output stores, with the
-  // rows staged through LDS (shs_stage_*): its per-lane inputs are kept here, lanes without a gradient carry zeros
-  constexpr bool STAGE = MV == 16;
-  __shared__ __align__(16) float shs_lds[STAGE ? (PP_BLOCK / 64) * 64 * SHS_STRIDE : 4];
-  float st_gc[3] = {0.f, 0.f, 0.f}, st_u[3] = {0.f, 0.f, 1.f}, st_inv = 0.f;
-  float dmean[3] = {0.f, 0.f, 0.f};
-  float gnx = 0.f, gny = 0.f;
-  float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f}, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float dop = 0.f;
-  float dcol[MM3DGS_MAX_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (idx < P) {
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float gnx = 0.f, gny = 0.f;
+    float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f}, dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f;
+    float dcol[MM3DGS_MAX_CHANNELS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool vis = radii[idx] > 0;
     if (vis) {
       float4 d0 = acc0, d1 = acc1, d2 = acc2;
@@ -385,9 +336,6 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         float ux = vx * inv, uy = vy * inv, uz = vz * inv;
         int deg = cam.sh_degree;
         int nb = (deg + 1) * (deg + 1);
-        if (STAGE) {
-          st_gc[0] = gc0; st_gc[1] = gc1; st_gc[2] = gc2; st_u[0] = ux; st_u[1] = uy; st_u[2] = uz; st_inv = inv;
-        } else {
         if (!skip_g && dshs) {
           float bb[16];
           sh_basis(deg, ux, uy, uz, bb);
@@ -432,7 +380,6 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
           dmean[0] += mx; dmean[1] += my; dmean[2] += mz;
           if (want_cam) { cg[24] = -mx; cg[25] = -my; cg[26] = -mz; }
         }
-        }   // !STAGE
       }
       // covariance parameters
       if (!skip_g) {
@@ -464,7 +411,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
                          y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
       }
-    } else if (!STAGE && !skip_g && shs && dshs) {
+    } else if (!skip_g && shs && dshs) {
       float* o = dshs + (size_t)idx * M * 3;
       if (MV) {
 #pragma unroll
@@ -473,54 +420,6 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         for (int k = 0; k < M * 3; k++) o[k] = 0.f;
       }
     }
-  }
-  if constexpr (STAGE) {
-    if (shs) {
-      const int lane = threadIdx.x & 63;
-      float* const ws = shs_lds + (threadIdx.x >> 6) * 64 * SHS_STRIDE;
-      const long long wave_row0 = (long long)blockIdx.x * PP_BLOCK + (threadIdx.x & ~63);
-      const int rows_live = (int)max(0ll, min(64ll, (long long)P - wave_row0));
-      const int deg = cam.sh_degree, nb = (deg + 1) * (deg + 1);
-      float bb[16];
-      sh_basis(deg, st_u[0], st_u[1], st_u[2], bb);
-      if (deg > 0) {
-        // d colour / d direction: sum_k grad(b_k) (sh_k . gc), k >= 1 -- in double (see the lane-per-row path above)
-        float bx[16], by[16], bz[16];
-        sh_basis_grad(deg, st_u[0], st_u[1], st_u[2], bx, by, bz);
-        double ddx = 0.0, ddy = 0.0, ddz = 0.0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          float sv[SHS_HALF_F];
-          shs_stage_load_half(shs, wave_row0, rows_live, ws, lane, h, sv);
-#pragma unroll
-          for (int kk = 0; kk < 8; kk++) {
-            const int k = 8 * h + kk;
-            if (k >= 1 && k < nb) {
-              const double w = (double)sv[kk * 3] * st_gc[0] + (double)sv[kk * 3 + 1] * st_gc[1] + (double)sv[kk * 3 + 2] * st_gc[2];
-              ddx += bx[k] * w; ddy += by[k] * w; ddz += bz[k] * w;
-            }
-          }
-        }
-        const double dot = st_u[0] * ddx + st_u[1] * ddy + st_u[2] * ddz;
-        const float mx = (float)((ddx - st_u[0] * dot) * st_inv), my = (float)((ddy - st_u[1] * dot) * st_inv), mz = (float)((ddz - st_u[2] * dot) * st_inv);
-        dmean[0] += mx; dmean[1] += my; dmean[2] += mz;       // (zero for lanes without a gradient: st_gc = 0, st_inv = 0)
-        if (want_cam) { cg[24] = -mx; cg[25] = -my; cg[26] = -mz; }
-      }
-      if (!skip_g && dshs) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          float ov[SHS_HALF_F];
-#pragma unroll
-          for (int kk = 0; kk < 8; kk++) {
-            const float bk = (8 * h + kk) < nb ? bb[8 * h + kk] : 0.f;
-            ov[kk * 3] = bk * st_gc[0]; ov[kk * 3 + 1] = bk * st_gc[1]; ov[kk * 3 + 2] = bk * st_gc[2];
-          }
-          shs_stage_store_half(dshs, wave_row0, rows_live, ws, lane, h, ov);
-        }
-      }
-    }
-  }
-  if (idx < P) {
     // every Gaussian writes its slots (culled ones write zeros): no memset of the outputs is needed
     if (dmeans3D) { dmeans3D[(size_t)idx * 3] = dmean[0]; dmeans3D[(size_t)idx * 3 + 1] = dmean[1]; dmeans3D[(size_t)idx * 3 + 2] = dmean[2]; }
     if (dmeans2D) { dmeans2D[(size_t)idx * 3] = gnx; dmeans2D[(size_t)idx * 3 + 1] = gny; dmeans2D[(size_t)idx * 3 + 2] = 0.f; }
