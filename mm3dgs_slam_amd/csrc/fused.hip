@@ -359,6 +359,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   int rad = 0;
   float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;   // first 32 bytes of this Gaussian's splat record (xy, conic, opacity)
+  float px3[3] = {0.f, 0.f, 0.f}, q_raw[4] = {1.f, 0.f, 0.f, 0.f}, ls_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
   {
     uint32_t goff = 0;
     int area = 0;
@@ -367,6 +368,13 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     uint32_t r0 = 0, r1 = 0, toff = 0, boff = 0, btile = 0, bblk = 0;
     unsigned long long m64 = 0ull;   // direct bins: the block masks of a splat of up to four tiles, left at submask-as-u64[idx]
     if (idx < P) {
+      // the Gaussian's own parameters depend on nothing but idx: requested with the first round, they land while the records are
+      // gathered (the chain rule below used to start with a memory round trip of its own)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { px3[k] = in.xyz[(size_t)idx * 3 + k]; ls_raw[k] = in.scaling[(size_t)idx * 3 + k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) q_raw[k] = in.rotation[(size_t)idx * 4 + k];
+      op_raw = in.opacity[idx];
       rad = radii[idx];
       r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
       boff = g.blkoff[idx]; bblk = g.block_blk[idx >> 8];
@@ -408,12 +416,12 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       const float dz_tot = TRACK ? acc0.w : acc1.z;               // d/dz of the [z, 1, z^2] bundle, already chained by the compositor
       const float gpx = -(qa * m_x + qb * m_y), gpy = -(qc * m_y + qb * m_x);
       const float gA = -0.5f * m_xx, gB = -m_xy, gC = -0.5f * m_yy;
-      const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
+      const float x0 = px3[0], x1 = px3[1], x2 = px3[2];
       float p[3];
 #pragma unroll
       for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
       float S3[3][3], R[3][3], sm[3], qn[4], qinv;
-      slam_cov3d(in, idx, cam.scale_modifier, S3, R, sm, qn, qinv);
+      slam_cov3d_vals(q_raw, ls_raw, in.isotropic != 0, cam.scale_modifier, S3, R, sm, qn, qinv);
       Ewa e;
       ewa_project(cam, Vi, p, S3, e);
       const float a = e.a, b = e.b, c = e.c;
@@ -466,7 +474,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
         dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;
         dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
         dfd[2] = (cl & 4) ? 0.f : SH_C0F * dc2;
-        const float o = 1.f / (1.f + expf(-in.opacity[idx]));
+        const float o = 1.f / (1.f + expf(-op_raw));
         dlogit = M0 * (1.f - o);   // sum G dL/dalpha = M0 / o, times d sigmoid = o (1 - o)
         float dM[3][3], dR[3][3], ds[3];
 #pragma unroll
