@@ -15,6 +15,10 @@
 #include "tile_mask.h"
 
 #define FB 256
+// workgroup size of the backward projection (its rows of pose partials, its gather lists): independent of the projection kernels' 256
+#ifndef SLAM_BWD_FB
+#define SLAM_BWD_FB 256
+#endif
 #define SH_C0F 0.28209479177387814f
 
 struct PoseDev { float R[3][3]; float t[3]; float qn[4]; float inv_norm; };
@@ -346,10 +350,10 @@ void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 template <bool TRACK, bool DIRECT>
-__global__ void __launch_bounds__(FB)
+__global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
-  const int idx = blockIdx.x * FB + threadIdx.x;
+  const int idx = blockIdx.x * SLAM_BWD_FB + threadIdx.x;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(in.pose);
@@ -387,7 +391,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       goff = btile + toff;
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, m64);
+    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, SLAM_BWD_FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, m64);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -440,6 +444,15 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) dS[i][j] = e.A[0][i] * GA[0][j] + e.A[1][i] * GA[1][j];
+      // dSigma3 is symmetric in exact arithmetic; in float32 the two triangles round differently, and their difference IS the rotation
+      // gradient of an isotropic Gaussian with identity rotation (every freshly seeded one, slam/mapper.py:644-668): rounding noise that
+      // Adam(eps=1e-15) turns into full +-lr steps of the quaternion.  torch's autograd of Sigma = L L^T forms (dSigma + dSigma^T) L and
+      // is exactly zero there; so is this once the triangles are averaged (found with the G9 runs of the reference's own classes:
+      // pose error to the reference 1.4e-5 -> 8e-8 after the first tracked frame).
+      {
+        const float s01 = 0.5f * (dS[0][1] + dS[1][0]), s02 = 0.5f * (dS[0][2] + dS[2][0]), s12 = 0.5f * (dS[1][2] + dS[2][1]);
+        dS[0][1] = s01; dS[1][0] = s01; dS[0][2] = s02; dS[2][0] = s02; dS[1][2] = s12; dS[2][1] = s12;
+      }
 #pragma unroll
       for (int r = 0; r < 2; r++)
 #pragma unroll
@@ -541,7 +554,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     }
   }
   if (posepartial) {   // mapping without pose optimisation never consumes the pose gradient
-    __shared__ float red[4][NPOSE];
+    __shared__ float red[SLAM_BWD_FB / 64][NPOSE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NPOSE; k++) {
@@ -551,7 +564,10 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
     __syncthreads();
     if (threadIdx.x < NPOSE) {
       const int k = threadIdx.x;
-      posepartial[(size_t)blockIdx.x * 32 + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+      float t = red[0][k];
+#pragma unroll
+      for (int w = 1; w < SLAM_BWD_FB / 64; w++) t += red[w][k];
+      posepartial[(size_t)blockIdx.x * 32 + k] = t;
     }
   }
 }
@@ -725,12 +741,14 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
     const bool map = out.d_xyz || ma.on;
     auto kern = map ? (direct ? slam_preprocess_bwd_kernel<false, true> : slam_preprocess_bwd_kernel<false, false>)
                     : (direct ? slam_preprocess_bwd_kernel<true, true> : slam_preprocess_bwd_kernel<true, false>);
-    hipLaunchKernelGGL(kern, dim3((P + FB - 1) / FB), dim3(FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma);
+    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma);
   }
   if (want_pose)
   {
     PoseLossScale none = {nullptr, 0, 0.f, nullptr};
-    hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? bw.nrows : 0, in.pose, dpose, ad,
+    // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds
+    //  twice as many float rows)
+    hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? (P + SLAM_BWD_FB - 1) / SLAM_BWD_FB : 0, in.pose, dpose, ad,
                        pls ? *pls : none, loss4);
   }
 }

@@ -276,6 +276,15 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) dS[i][j] = e.A[0][i] * GA[0][j] + e.A[1][i] * GA[1][j];
+      // dSigma3 is symmetric in exact arithmetic; in float32 the two triangles round differently, and their difference IS the rotation
+      // gradient of an isotropic Gaussian with identity rotation (every freshly seeded one, slam/mapper.py:644-668): rounding noise that
+      // Adam(eps=1e-15) turns into full +-lr steps of the quaternion.  torch's autograd of Sigma = L L^T forms (dSigma + dSigma^T) L and
+      // is exactly zero there; so is this once the triangles are averaged (found with the G9 runs of the reference's own classes:
+      // pose error to the reference 1.4e-5 -> 8e-8 after the first tracked frame).
+      {
+        const float s01 = 0.5f * (dS[0][1] + dS[1][0]), s02 = 0.5f * (dS[0][2] + dS[2][0]), s12 = 0.5f * (dS[1][2] + dS[2][1]);
+        dS[0][1] = s01; dS[1][0] = s01; dS[0][2] = s02; dS[2][0] = s02; dS[1][2] = s12; dS[2][1] = s12;
+      }
       // dA = 2 G2 A Sigma3
       float dA[2][3];
 #pragma unroll
