@@ -7,7 +7,7 @@ shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU configu
 Bars (the same as the CPU runs of tests/test_golden_slam.py hold for the torch-graph loops): identical keyframe lists, covisibility
 graph and RNG end state; map size within 0.5 %; while no threshold decision has flipped (the maps still have the same rows) camera
 matrices to 1e-4 (5e-4 for bundle adjustment / white background, whose weakly constrained directions amplify rounding ~10x per
-frame on the reference side as well) and map moments to 1e-4; afterwards 1e-3 / 5e-3."""
+frame on the reference side as well) and every map moment to 1e-4; afterwards 1e-3 / 5e-3."""
 import os
 import random
 
@@ -77,15 +77,16 @@ def run_variant(variant, verbose=False):
     return slam, G, rows
 
 
-# Why two sets of bars.  The reference seeds exactly isotropic Gaussians (slam/mapper.py:644-668): d(loss)/d(rotation) is analytically
-# zero there and numerically rounding noise, and Adam(eps=1e-15) (slam/gaussian_model.py:143-195) turns noise into full +-lr steps -- the
-# quaternions random-walk in a direction no two float32 implementations share, and once the scales have gone anisotropic that walk is
-# a real (small) change of the map.  Measured on MI355X: with the rotation learning rate at 0 (`*_rotfrozen` fixtures) the HIP loops
-# stay on the reference trajectory to ~1e-5 over all five frames; `imu` (force_isotropic: the rotation never matters) likewise; with it
-# live, camera matrices agree to 1.4e-5 after the first tracked frame and drift to 1e-4 .. 4e-4 by frame 4, and the one moment that
-# moves is the mean quaternion w (3e-4 at frame 0 already).  TIGHT variants are held to the verdict's bars; the others to tight bars
-# on frames 0-1 and to the measured drift (x ~2) afterwards, rotation moment at 2e-3.
-TIGHT = ("vigs_rotfrozen", "imu")
+# What this test found (round 3).  The reference seeds exactly isotropic Gaussians with identity rotation (slam/mapper.py:644-668).  Their
+# rotation gradient is 2 s^2 (dSigma[j][k] - dSigma[k][j]): zero in exact arithmetic, and exactly zero in torch, whose autograd of
+# Sigma = L L^T forms (dSigma + dSigma^T) L.  The kernels computed the two triangles of dSigma separately; their float32 rounding
+# difference is noise that Adam(eps=1e-15) (slam/gaussian_model.py:143-195) turns into full +-lr steps of the quaternions, a random walk
+# the reference does not take: poses drifted to 1.4e-5 after the first tracked frame and 4e-4 by frame 4, the mean quaternion w by 3e-4
+# within frame 0 (with the rotation learning rate at 0 -- the `vigs_rotfrozen` fixture -- the drift was gone: 2e-8).  With dSigma averaged
+# over its triangles (fused.hip / preprocess.hip) the HIP loops follow the reference's own classes to 1e-8 .. 5e-7 in the camera matrices
+# and 6e-6 in every map moment for as long as no threshold decision flips (measured: vigs 1.2e-8, 6.8e-8, 5.2e-7, 1.8e-5 over frames
+# 1-4; imu 5e-9 .. 2e-5; splatam 9e-7 at frame 1).  Bundle adjustment stays loose from frame 3 on: at 64x48 the rotation about the
+# optical axis is barely constrained, and the reference's own arithmetic re-run by the torch-graph loops on CPU drifts from it by 6e-3 there.
 
 
 @pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"])
@@ -94,7 +95,6 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
     slam, G, rows = run_variant(variant)
     want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
     aligned = True
-    tight = variant in TIGHT
     for r in rows:
         idx = r["idx"]
         assert r["keyframes"] == want_kf[idx], (idx, r["keyframes"], want_kf[idx])
@@ -102,22 +102,16 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
         aligned = aligned and r["P"] == r["P_ref"]
         if idx == 0:
             assert aligned
-        if tight or idx <= 1:
-            bar = (5e-4 if variant.startswith("ba") else 1e-4) if aligned else 1e-3
-        else:
-            bar = 1e-2 if variant == "ba" else 1e-3
+        loose_ba = variant == "ba" and idx >= 3
+        bar = 1e-2 if loose_ba else (((5e-4 if variant in ("ba", "white_bg") else 1e-4) if aligned else 1e-3))
         assert r["pose_diff"] < bar, (idx, r["pose_diff"], bar)
-        tol = np.full(8, 1e-4 if aligned else 5e-3)
-        if variant != "vigs_rotfrozen":
-            tol[7] = 2e-3                               # mean quaternion w: the noise-driven random walk described above (`imu`: unobservable, force_isotropic)
-        if not tight and idx > 1:
-            tol[:7] = np.maximum(tol[:7], 5e-4)
+        tol = 1e-4 if (aligned and not loose_ba) else 5e-3
         assert np.all(np.abs(r["moments"] - r["moments_ref"]) <= tol + tol * np.abs(r["moments_ref"])), (idx, r["moments"], r["moments_ref"])
     graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
     assert graph == [str(s) for s in G["graph"]]
     for kf, ref in zip(slam.mapper.keyframes, G["keyframe_poses"]):
         d = (get_camera_from_tensor(kf.pose.detach().cpu().float()) - get_camera_from_tensor(torch.from_numpy(ref))).abs().max()
-        assert d < (5e-4 if tight else (1e-2 if variant == "ba" else 1e-3)), (kf.idx, float(d))
+        assert d < (1e-2 if variant == "ba" else 5e-4), (kf.idx, float(d))
     # the final map as a population (rows are no longer aligned once a single pruning decision differs)
     g = slam.gaussians
     qs = torch.tensor([0.02, 0.1, 0.25, 0.5, 0.75, 0.9, 0.98])
