@@ -15,10 +15,14 @@
 #include "tile_mask.h"
 
 #define FB 256
-// workgroup size of the backward projection (its rows of pose partials, its gather lists): independent of the projection kernels' 256
+// workgroup size of the backward projection (its rows of pose partials, its gather lists): independent of the projection kernels' 256.
+// 128: at 157 k Gaussians 1226 workgroups instead of 613 spread evenly over the 256 CUs (613 = two on some CUs, three on others):
+// mapping 33.1 -> 30.8 us, tracking 21.5 -> 20.4 us per launch, the pose-finish kernel reads twice the rows (+1.3 us).  The partial-row
+// region of the scratch is sized for 256-lane workgroups writing double rows, i.e. it holds exactly twice as many float rows: 64 would not fit.
 #ifndef SLAM_BWD_FB
-#define SLAM_BWD_FB 256
+#define SLAM_BWD_FB 128
 #endif
+static_assert(SLAM_BWD_FB == 128 || SLAM_BWD_FB == 256, "the partial-row region holds (P / 256 + 1) * 64 floats");
 #define SH_C0F 0.28209479177387814f
 
 struct PoseDev { float R[3][3]; float t[3]; float qn[4]; float inv_norm; };
