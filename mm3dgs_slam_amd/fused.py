@@ -151,13 +151,10 @@ class FusedEngine:
         (and map_adam None) the gradients of the last view are written out instead of stepped (multi-GPU window)."""
         P = int(g._xyz.shape[0])
         self._ensure(P, True)
+        arr = getattr(views, "table", None)      # built ahead of time by FusedMapper (a _Views list)
+        if arr is None:
+            arr = self.view_table(views)
         si = self.inputs(views[0][0], g)
-        arr = (_lib.Mm3dgsMapView * len(views))()
-        for i, view in enumerate(views):
-            pose, gt_color, ref = view[:3]
-            arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
-            if len(view) > 3 and view[3] is not None:        # bundle adjustment: this view's pose takes an Adam step on the device
-                arr[i].pose_adam_or_null = C.addressof(view[3])
         sg = None
         if stats is not None or grads is not None:
             sg = _lib.Mm3dgsSlamGrads()
@@ -172,6 +169,18 @@ class FusedEngine:
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
                                             _p(self.dL), _p(self.loss), _p(self.scratch), C.byref(sg) if sg is not None else None,
                                             C.byref(map_adam) if map_adam is not None else None, _stream()))
+
+    @staticmethod
+    def view_table(views):
+        """The Mm3dgsMapView array of a run (pure host work: ~1 us per view).  FusedMapper builds the table of the run that FOLLOWS a
+        pruning step before it blocks on that step's read-back, so the run is enqueued the moment the new map size is known."""
+        arr = (_lib.Mm3dgsMapView * len(views))()
+        for i, view in enumerate(views):
+            pose, gt_color, ref = view[:3]
+            arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
+            if len(view) > 3 and view[3] is not None:        # bundle adjustment: this view's pose takes an Adam step on the device
+                arr[i].pose_adam_or_null = C.addressof(view[3])
+        return arr
 
     def visibility(self, pose, g, seen):
         """seen[i] += 1 for every Gaussian the projection stage would hand to the rasterizer from `pose` (radii > 0): the
@@ -226,6 +235,11 @@ class FusedEngine:
                                                  _p(self.binning), self.n_cap, _p(self.dL), _p(self.scratch), C.byref(sg), _p(dpose),
                                                  C.byref(pose_adam) if pose_adam is not None else None,
                                                  C.byref(map_adam) if map_adam is not None else None, self._flags(), _stream()))
+
+
+class _Views(list):
+    """The views of a run with their Mm3dgsMapView table (FusedEngine.view_table) attached: a plain list for every other consumer."""
+    table = None
 
 
 def _loss_cfg(H, W, w_l1, w_ssim, w_pearson, l1_mask, pearson_mask, invert, sil_thr, w_depth_l1=0.0, depth_l1_mask=0, l1_sum=0):
@@ -470,7 +484,7 @@ class FusedMapper(Mapper):
         # `unrecovered_overflows`, warned about, capacity raised for the next frame.
         eng._ensure(int(g._xyz.shape[0]), True)
         need_snap = self.always_snapshot or getattr(eng, "headroom", lambda: 0.0)() < 1.5 or (self.window is not None and self.window._collective)
-        snap, rng_state = (g.snapshot() if need_snap else None), _random.getstate()
+        snap, rng_state = (g.snapshot(), _random.getstate()) if need_snap else (None, None)
         for attempt in range(4):
             self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
             ok = eng.check_capacity()
@@ -513,18 +527,27 @@ class FusedMapper(Mapper):
         def dens(it):
             return (not splatam) and it <= m["densify_until_iter"]
 
+        def run_length(start):
+            n = 1
+            while start + n < num_iter and not prune_at(start + n) and dens(start + n) == dens(start):
+                n += 1
+            return n
+
         with torch.no_grad():
             iteration = 0
+            prepared = None      # (first iteration, views, table) of a run whose host side was built while the GPU was still busy
             while iteration < num_iter:
                 densify = dens(iteration)
                 if not multi and not prune_at(iteration):
                     # single GPU: the run of iterations up to the next pruning step (or the end of the densification phase)
                     # is enqueued by ONE C call -- no Python between the ~9 launches of an iteration
-                    n = 1
-                    while (iteration + n < num_iter and not prune_at(iteration + n)
-                           and dens(iteration + n) == densify):
-                        n += 1
-                    views = [view_of(pop()) for _ in range(n)]
+                    if prepared is not None and prepared[0] == iteration:
+                        views = prepared[1]
+                    else:
+                        views = _Views(view_of(pop()) for _ in range(run_length(iteration)))
+                        views.table = FusedEngine.view_table(views)
+                    prepared = None
+                    n = len(views)
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
                     eng.map_loop(views, g, lcfg, stats, self._inline_adam(n))
                     iteration += n
@@ -565,7 +588,13 @@ class FusedMapper(Mapper):
                     eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads)
                 if prune_now:
                     # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
-                    # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py)
+                    # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py).
+                    # The read-back blocks until the GPU has drained: the views of the run that follows (same keyframe picks, in the
+                    # same order, whatever the pruning decides) are popped and tabulated first, while the GPU is still working.
+                    if not multi and iteration + 1 < num_iter and not prune_at(iteration + 1):
+                        nxt = _Views(view_of(pop()) for _ in range(run_length(iteration + 1)))
+                        nxt.table = FusedEngine.view_table(nxt)
+                        prepared = (iteration + 1, nxt)
                     pruned = g.prune(m["min_opacity"], self.camera_extent, None if splatam else m["size_threshold"])
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
                         self._opt_mask = self._opt_mask[~pruned].contiguous()
