@@ -171,6 +171,10 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
   const float* prior_pose; float prior_w_t, prior_w_q;
 } Mm3dgsPoseAdam;
 
+/* The SLAM entry points (mm3dgs_slam_*) render the reference's bundle -- RGB and, as channels 3..5, the depth pass [z, 1, z^2] of
+ * slam/renderer.py:207-214 -- in one pass.  The reference composites BOTH passes over cam->bg (renderer.py:80-83,196-214), so here
+ * channels 3..5 receive T_final * bg[ch - 3] as well (with `white_background` the silhouette channel is 1 everywhere), and the backward
+ * carries the corresponding -T_final bg . dL term.  (mm3dgs_forward with C = 6 keeps "extra channels over black", see above.) */
 /* flags for mm3dgs_slam_forward */
 #define MM3DGS_FWD_STATE_CLEAN 1 /* image_state's header+tile counters are already zero (the library leaves them zero
                                     after every forward), so the per-call memset is skipped: for persistent state buffers */
