@@ -335,6 +335,87 @@ struct SepReduce {
   }
 };
 
+// Round 3: the same separable reduction with the Y direction FIRST and its halving steps done by bank-masked DPP adds.  A DPP bank =
+// four consecutive lanes = one pixel row of the block (lane bits 2, 3 = y): `v_add_f32_dpp ... bank_mask` writes only the lanes of the
+// selected pixel rows, so "lanes with y even keep value i, lanes with y odd keep value i + 4" is two masked adds into one register
+// instead of two full adds and a select (the halving on lane bits 0, 1 needs the selects: a mask cannot tell the lanes of a bank apart).
+//   Y stage on 8 (mapping) / 4 (tracking) values  { u, u dy, u dy^2, c0, c1, c2, cz, u }  /  { u, u dy, u dy^2, cz }:
+//     partner row y ^ 1 (row_ror:12 = lane + 4 for the even rows, row_ror:4 = lane - 4 for the odd ones), then y ^ 2 (row_ror:8);
+//     afterwards pixel row y holds the column sums (over y) of two (one) of the values.
+//   X stage: up to three x-weighted copies per row ( 1 | dx | dx^2 ), full butterfly over the four lanes of the bank (quad_perm).
+// 27 (mapping) / 18 (tracking) instructions per (row, splat) step instead of 33 / 27.  The masked adds are inline assembly (the compiler's
+// DPP combiner does not form them); `s_nop 1` covers the VALU-write -> DPP-read hazard at the head of the block, inside it every
+// register is read at least two instructions after it was written.  Summation order differs from SepReduce in the last bit only.
+template <bool RGB>
+struct SepReduce2 {
+  // record position of the value lane q ends up with (-1: nothing to store); layouts as SepReduce
+  __device__ static __forceinline__ int slot(int q) {
+    const int x = q & 3, y = q >> 2;
+    if (RGB) {
+      // row 0: Mx My Mxy | row 1: c1 c2 - | row 2: Myy c0 - | row 3: cz M0 Mxx      ([M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy])
+      const int t[4][4] = {{1, 7, 8, -1}, {4, 5, -1, -1}, {9, 3, -1, -1}, {6, 0, 2, -1}};
+      return t[y][x];
+    }
+    // row 0: M0 Mx Mxx | row 1: Myy | row 2: My Mxy | row 3: cz                     ([M0 Mx Mxx cz | My Mxy Myy])
+    const int t[4][4] = {{0, 1, 2, -1}, {6, -1, -1, -1}, {4, 5, -1, -1}, {3, -1, -1, -1}};
+    return t[y][x];
+  }
+  __device__ static __forceinline__ float run(float u, float dx, float dy, float c0, float c1, float c2, float cz, int lane) {
+#pragma clang fp contract(off)
+    const int x = lane & 3, y = (lane >> 2) & 3;
+    const float udy = u * dy, udyy = udy * dy;
+    float t0, t1, t2;
+    if (RGB) {
+      float r0, r1, r2, r3, s0, s1;
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_add_f32_dpp %0, %6, %6 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     // rows 0, 2: u
+          "v_add_f32_dpp %1, %7, %7 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     //            u dy
+          "v_add_f32_dpp %2, %8, %8 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     //            u dy^2
+          "v_add_f32_dpp %3, %9, %9 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     //            c0
+          "v_add_f32_dpp %0, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"    // rows 1, 3: c1
+          "v_add_f32_dpp %1, %11, %11 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"    //            c2
+          "v_add_f32_dpp %2, %12, %12 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"    //            cz
+          "v_add_f32_dpp %3, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"      //            u (again)
+          "v_add_f32_dpp %4, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"      // rows 0, 1 keep r0, r1
+          "v_add_f32_dpp %5, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+          "v_add_f32_dpp %4, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"      // rows 2, 3 keep r2, r3
+          "v_add_f32_dpp %5, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+          : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s0), "=&v"(s1)
+          : "v"(u), "v"(udy), "v"(udyy), "v"(c0), "v"(c1), "v"(c2), "v"(cz));
+      // row 0: s0 = U, s1 = U1 | row 1: c1, c2 | row 2: U2, c0 | row 3: cz, U
+      const float w0 = y == 0 ? dx : 1.f;
+      const float w2 = dx * (y == 0 ? 1.f : dx);
+      t0 = s0 * w0;       // U dx | c1 | U2 | cz
+      t1 = s1;            // U1   | c2 | c0 | U
+      t2 = s1 * w2;       // U1 dx | -  | -  | U dx^2
+    } else {
+      float r0, r1, sy;
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_add_f32_dpp %0, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     // rows 0, 2: u
+          "v_add_f32_dpp %1, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     //            u dy
+          "v_add_f32_dpp %0, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"      // rows 1, 3: u dy^2
+          "v_add_f32_dpp %1, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"      //            cz
+          "v_add_f32_dpp %2, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"      // rows 0, 1 keep r0: U | U2
+          "v_add_f32_dpp %2, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"      // rows 2, 3 keep r1: U1 | cz
+          : "=&v"(r0), "=&v"(r1), "=&v"(sy)
+          : "v"(u), "v"(udy), "v"(udyy), "v"(cz));
+      t0 = sy;            // U | U2 | U1 | cz
+      t1 = sy * dx;       // U dx | - | U1 dx | -
+      t2 = t1 * dx;       // U dx^2 | - | - | -
+    }
+    t0 += dpp_all<QP_XOR1>(t0); t1 += dpp_all<QP_XOR1>(t1); t2 += dpp_all<QP_XOR1>(t2);
+    t0 += dpp_all<QP_XOR2>(t0); t1 += dpp_all<QP_XOR2>(t1); t2 += dpp_all<QP_XOR2>(t2);
+    return x == 0 ? t0 : (x == 1 ? t1 : t2);
+  }
+};
+#ifdef MM3DGS_OLD_REDUCE
+#define SEP_REDUCE2 0
+#else
+#define SEP_REDUCE2 1
+#endif
+
 // Record written per (4x4 block, splat); the moments m = sum_p u_p (1, dx, dy, dx^2, dx dy, dy^2) of u = dL/dG * G over the
 // block's pixels give d/dxy and d/dconic with the splat's conic (preprocess_bwd).
 // MODE 0: generic, record = [m_x m_y m_xx m_xy m_yy | dopacity | dcolour(C)].
@@ -441,9 +522,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   }
   if (maxtodo == 0) return;   // wave-uniform
 
-  const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : SepReduce<MODE == 1>::slot(q);
+  const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : (SEP_REDUCE2 ? SepReduce2<MODE == 1>::slot(q) : SepReduce<MODE == 1>::slot(q));
   float ym_0 = 0.f, ym_1a = 0.f, ym_1b = 0.f;
-  if (MODE != 0) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
+  if (MODE != 0 && !SEP_REDUCE2) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
   // this lane's component of record 0; the list entries carry the record index of their (splat, block)
   float* const my_rec = dsub + (my_slot >= 0 ? my_slot : 0);
   uint32_t n_visit = 0, n_red = 0;
@@ -531,7 +612,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         } else {
           // SLAM records: the zeroth moment M0 = sum u also carries the opacity gradient (sum G dL/dalpha = M0 / opacity)
           const float cz = Z45 ? w * dL[3] : w * fmaf(2.f * col[3], dL[5], dL[3]);   // d/dz of the [z, 1, z^2] bundle, chained here
-          tot = SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_0, ym_1a, ym_1b);
+          if constexpr (SEP_REDUCE2) tot = SepReduce2<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane);
+          else tot = SepReduce<MODE == 1>::run(u, dx, dy, w * dL[0], w * dL[1], w * dL[2], cz, lane, ym_0, ym_1a, ym_1b);
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
