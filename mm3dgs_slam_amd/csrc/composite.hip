@@ -405,9 +405,19 @@ struct SepReduce2 {
       t1 = sy * dx;       // U dx | - | U1 dx | -
       t2 = t1 * dx;       // U dx^2 | - | - | -
     }
-    t0 += dpp_all<QP_XOR1>(t0); t1 += dpp_all<QP_XOR1>(t1); t2 += dpp_all<QP_XOR1>(t2);
-    t0 += dpp_all<QP_XOR2>(t0); t1 += dpp_all<QP_XOR2>(t1); t2 += dpp_all<QP_XOR2>(t2);
-    return x == 0 ? t0 : (x == 1 ? t1 : t2);
+    // X stage: full butterfly over the four lanes of every pixel row (six fused DPP adds: left to the compiler, the second level came out
+    // as v_mov_b32_dpp + v_add_f32 inside exec-masked branches), then the lane picks the total it stores
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(t0), "+v"(t1), "+v"(t2));
+    const float t01 = x == 0 ? t0 : t1;
+    return x >= 2 ? t2 : t01;
   }
 };
 #ifdef MM3DGS_OLD_REDUCE
