@@ -225,7 +225,7 @@ static bool slam_fused_sort(int flags) {
 }
 
 // direct bins (MM3DGS_FWD_DIRECT_BINS): one decision for the forward and the backward of a render
-struct DirectBins { bool on; uint32_t bin_cap, rec_cap; int nblocks, slot_bits; };
+struct DirectBins { bool on; uint32_t bin_cap, rec_cap, trec_cap; int nblocks, slot_bits; };
 static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_capacity) {
   static const int no_direct = env_flag("MM3DGS_NO_DIRECT_BINS", 0);
   static const int no_fused_scan = env_flag("MM3DGS_NO_FUSED_SCAN", 0);
@@ -238,8 +238,10 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
   d.bin_cap = (uint32_t)std::min<size_t>(N_capacity / (size_t)std::max(T, 1), (size_t)((1u << std::max(d.slot_bits, 1)) - 1u));
   // records of the backward scratch per projection workgroup (the scratch holds NLIST records per pair of capacity)
   d.rec_cap = (uint32_t)std::min<size_t>((size_t)NLIST * N_capacity / nb, 0xffffffffull / nb);
+  // per-tile records (one per pair) per projection workgroup: the region holds N_capacity of them
+  d.trec_cap = (uint32_t)std::min<size_t>(N_capacity / nb, 0xffffffffull / nb);
   d.on = (flags & MM3DGS_FWD_DIRECT_BINS) && (flags & MM3DGS_FWD_STATE_CLEAN) && slam_fused_sort(flags) && !no_direct && !no_fused_scan &&
-         P > 0 && d.slot_bits >= DIRECT_SLOT_BITS_MIN && T <= max_tiles && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 &&
+         P > 0 && d.slot_bits >= DIRECT_SLOT_BITS_MIN && T <= max_tiles && T <= MAX_LDS_TILES && d.bin_cap >= 32 && d.rec_cap >= 1024 && d.trec_cap >= 256 &&
          N_capacity >= 4 * (size_t)P;
   return d;
 }
@@ -267,6 +269,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   if (tl && !fused_sort) return fail(-1, "internal: folded tracking loss needs the fused sort path");
   // direct bins: the host sized the binning state as T x (per-tile capacity), so projection and binning are one launch
   const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
+  cd.trec_cap = db.on ? db.trec_cap : 0u;
   if (db.on) {
     { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s); }
     { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
@@ -318,6 +321,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   BinView b = bin_view((void*)binning_state, N_capacity);
   BwdView bw = bwd_view(backward_scratch, P, N_capacity);
   cd.bg_extras = 1;
+  const DirectBins db_bwd = slam_direct_bins(flags, cd, P, N_capacity);
+  cd.trec_cap = db_bwd.on ? db_bwd.trec_cap : 0u;
   SlamGrads sg = {};
   if (grads) {
     const bool any = grads->d_xyz || grads->d_f_dc || grads->d_opacity || grads->d_scaling || grads->d_rotation;
@@ -356,7 +361,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   if (!compositor_done)
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, slam_direct_bins(flags, cd, P, N_capacity).on); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on); }
   return check_launch("slam_backward");
 }
 

@@ -189,7 +189,7 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap, slot_bits);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap, slot_bits, 1);
   if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
   composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
@@ -530,7 +530,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   for (uint32_t e = todo + q; e < count; e += 16) {
     zero_record<NV>(dsub + (size_t)list[e].y * RECF);
   }
-  if (maxtodo == 0) return;   // wave-uniform
+  if (maxtodo != 0) {   // wave-uniform (a wave without work still takes part in the workgroup's per-tile combine below)
 
   const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : (SEP_REDUCE2 ? SepReduce2<MODE == 1>::slot(q) : SepReduce<MODE == 1>::slot(q));
   float ym_0 = 0.f, ym_1a = 0.f, ym_1b = 0.f;
@@ -658,6 +658,51 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     atomicAdd(&iv.hdr->bwd_wave_visits, n_visit);
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);
   }
+  }   // maxtodo != 0
+  if constexpr (MODE != 0) {
+    // ---- per-tile combine (SLAM modes): one record per (tile, splat) pair = the sum of the pair's block records, in ascending
+    // block order (deterministic).  The backward projection then reads ONE record per pair (contiguous per Gaussian) instead of one
+    // per listed 4x4 block: a quarter of the bytes on the kernel that the counters show to be bandwidth bound on exactly them
+    // (148 MB per mapping launch, 56 MB of it block records).  The block records were written by this workgroup's own waves a
+    // moment ago (same CU: visible after the barrier); a pair is found by its position in the tile's bin (payload / trec).
+    __syncthreads();
+    float* __restrict__ dtile = dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F;
+    for (uint32_t e = (uint32_t)tid; e < len; e += 256u) {
+      const unsigned long long pl = b.payload[start + e];
+      const uint32_t tr = b.trec[start + e];
+      uint32_t mask = (uint32_t)pl & 0xffffu;
+      const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+      while (mask) {
+        // up to four records in flight
+        float4 ra[4], rb[4], rc[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          on[u] = mask != 0u;
+          const int L = on[u] ? __ffs((int)mask) - 1 : 0;
+          mask &= mask - 1u;
+          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
+          const float* r = dsub + (on[u] ? (size_t)rec * RECF : (size_t)0);
+          ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
+          rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
+          a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
+          if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
+        }
+      }
+      if (tr != 0xffffffffu) {
+        float* o = dtile + (size_t)tr * RECF;
+        const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
+        *(f4u*)o = q0;
+        if (MODE == 1) { const f4u q1 = {a1.x, a1.y, a1.z, a1.w}; *(f4u*)(o + 4) = q1; const f2u q2 = {a2.x, a2.y}; *(f2u*)(o + 8) = q2; }
+        else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
+      }
+    }
+  }
 }
 
 template <int C, int MODE>
@@ -690,7 +735,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   const int T = cam.gx * cam.gy;
   const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits, 1);
   __syncthreads();
   composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, &tl, red, &sh);
   __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free

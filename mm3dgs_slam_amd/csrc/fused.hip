@@ -11,7 +11,7 @@
 // Everything downstream (scan, scatter, sort, compositors) is the generic pipeline with C = 6.
 #include "mm3dgs_math.h"
 #include "fused_api.h"
-#include "gather_records.h"
+#include "composite_common.h"
 #include "tile_mask.h"
 
 #define FB 256
@@ -230,6 +230,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
 // here and lists none of the splats that do not fit (both sticky, like a packed bin that runs out of capacity).
 struct PairCtx {           // what a lane needs to emit the pairs of ITS Gaussian (broadcast lane by lane for huge splats)
   MaskConsts mc; BlkRect br; uint32_t rec0; uint32_t khi, idbits; int minx, miny, w, area;   // rec0: first record (absolute)
+  uint32_t trec0;            // per-tile record of the splat's first pair (absolute; pair k of the tile rectangle, row-major: trec0 + k); ~0u: none
 };
 __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t* hist, int gx, uint32_t cap, const BinView& b) {
   const int ttx = c.minx + k % c.w, tty = c.miny + k / c.w;
@@ -242,6 +243,7 @@ __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t*
     const size_t at = (size_t)t * cap + slot;
     b.keys[at] = ((unsigned long long)c.khi << 32) | (unsigned long long)(c.idbits | slot);
     b.payload[at] = (unsigned long long)mask | ((unsigned long long)(uint32_t)min(c.br.bw, 0xffff) << 16) | ((unsigned long long)rec_local << 32);
+    b.trec[at] = c.trec0 == 0xffffffffu ? 0xffffffffu : c.trec0 + (uint32_t)k;
   }
   return mask;
 }
@@ -282,11 +284,15 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
     const uint32_t base = (uint32_t)blockIdx.x * rec_cap;
     c.rec0 = base + local;
     if (local + pr.nblk > rec_cap) { c.br.bw = 0; c.br.bh = 0; }     // does not fit: listed nowhere (clip_mask_to_rect), flagged below
+    // per-tile records: this workgroup's pairs own [w * trec_cap, (w + 1) * trec_cap); a Gaussian's pairs are contiguous in it
+    const uint32_t plocal = pre2 + x2 - (uint32_t)c.area;
+    if (live) g.tileoff[idx] = plocal;
+    c.trec0 = plocal + (uint32_t)c.area <= cam.trec_cap ? (uint32_t)blockIdx.x * cam.trec_cap + plocal : 0xffffffffu;
     if (tid == FB - 1) {
       const uint32_t tot = pre + x;
       g.block_blk[blockIdx.x] = base;     // first record of this workgroup's splats (read by the backward projection)
-      g.tileoff[blockIdx.x] = pre2 + x2;  // pairs of this workgroup (summed into num_rendered by the sort)
-      if (tot > rec_cap) iv.hdr->overflow = 1u;
+      g.block_tiles[blockIdx.x] = pre2 + x2;  // pairs of this workgroup (summed into num_rendered by the sort)
+      if (tot > rec_cap || pre2 + x2 > cam.trec_cap) iv.hdr->overflow = 1u;
       if (tot > iv.hdr->max_group_records) atomicMax(&iv.hdr->max_group_records, tot);   // (rare: the maximum is sticky)
     }
   }
@@ -315,7 +321,7 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   constexpr int OWN = 4;
   unsigned long long m64 = 0ull;
   for (int k = 0; k < min(c.area, OWN); k++) m64 |= (unsigned long long)emit_pair(c, k, hist, cam.gx, cap, b) << (16 * k);
-  if (live) ((unsigned long long*)b.submask)[idx] = c.area <= OWN ? m64 : 0ull;
+  (void)m64;
   uint32_t incl = (uint32_t)max(c.area - OWN, 0);
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -351,6 +357,55 @@ void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t
   hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits);
 }
 
+// Sum of a Gaussian's per-tile gradient records (composite.hip's per-tile combine: one record per (tile, splat) pair, the pairs of a
+// Gaussian contiguous).  Every lane of the wave must call it.  Small rectangles (<= 16 tiles: practically every splat of a SLAM map)
+// are summed by their own lane, four records in flight, in ascending pair order; a bigger one is read by the whole wave (lane-strided,
+// then a fixed-order DPP reduction) -- deterministic either way.  Mapping records: 10 floats, tracking: 7 (composite_common.h).
+template <bool TRACK>
+__device__ __forceinline__ void gather_tile_records(int area, uint32_t first, const float* __restrict__ dtile, float4& acc0, float4& acc1, float4& acc2) {
+  constexpr int RECF = TRACK ? REC_TRACK_F : REC_MAP_F;
+  const int lane = threadIdx.x & 63;
+  const bool big = area > 16;
+  const int n_own = big ? 0 : area;
+  for (int k0 = 0; __ballot(k0 < n_own) != 0ull; k0 += 4) {
+    float4 a[4], b4[4], c4[4];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      on[u] = k0 + u < n_own;
+      const float* r = dtile + (on[u] ? (size_t)(first + (uint32_t)(k0 + u)) * RECF : (size_t)0);
+      a[u] = ld4u(r); b4[u] = ld4u(r + 4);
+      c4[u] = TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4u(r + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
+      acc1.x += on[u] ? b4[u].x : 0.f; acc1.y += on[u] ? b4[u].y : 0.f; acc1.z += on[u] ? b4[u].z : 0.f; acc1.w += on[u] ? b4[u].w : 0.f;
+      if (!TRACK) { acc2.x += on[u] ? c4[u].x : 0.f; acc2.y += on[u] ? c4[u].y : 0.f; }
+    }
+  }
+  for (unsigned long long bigs = __ballot(big); bigs; bigs &= bigs - 1ull) {
+    const int src = __ffsll((long long)bigs) - 1;
+    const int sarea = __builtin_amdgcn_readlane(area, src);
+    const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
+    float v[RECF];
+#pragma unroll
+    for (int f = 0; f < RECF; f++) v[f] = 0.f;
+    for (int k = lane; k < sarea; k += 64) {
+      const float* r = dtile + (size_t)(sfirst + (uint32_t)k) * RECF;
+#pragma unroll
+      for (int f = 0; f < RECF; f++) v[f] += r[f];
+    }
+#pragma unroll
+    for (int f = 0; f < RECF; f++) v[f] = wave_sum(v[f]);
+    if (lane == src) {
+      acc0 = make_float4(v[0], v[1], v[2], v[3]);
+      acc1 = make_float4(v[4], v[5], v[6], TRACK ? 0.f : v[RECF > 7 ? 7 : 0]);
+      if (!TRACK) acc2 = make_float4(v[RECF > 8 ? 8 : 0], v[RECF > 9 ? 9 : 0], 0.f, 0.f);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 template <bool TRACK, bool DIRECT>
@@ -369,12 +424,11 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
   float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;   // first 32 bytes of this Gaussian's splat record (xy, conic, opacity)
   float px3[3] = {0.f, 0.f, 0.f}, q_raw[4] = {1.f, 0.f, 0.f, 0.f}, ls_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
   {
-    uint32_t goff = 0;
+    uint32_t first = 0;
     int area = 0;
     // one round of independent loads for everything the gather needs (this kernel is a chain of memory latencies: every
     // dependent step costs ~2 us).  A culled Gaussian has rect = 0 (and an unwritten splat record, read but never used).
-    uint32_t r0 = 0, r1 = 0, toff = 0, boff = 0, btile = 0, bblk = 0;
-    unsigned long long m64 = 0ull;   // direct bins: the block masks of a splat of up to four tiles, left at submask-as-u64[idx]
+    uint32_t r0 = 0, r1 = 0, toff = 0, btile = 0;
     if (idx < P) {
       // the Gaussian's own parameters depend on nothing but idx: requested with the first round, they land while the records are
       // gathered (the chain rule below used to start with a memory round trip of its own)
@@ -385,17 +439,20 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       op_raw = in.opacity[idx];
       rad = radii[idx];
       r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
-      boff = g.blkoff[idx]; bblk = g.block_blk[idx >> 8];
-      if (DIRECT) m64 = ((const unsigned long long*)bn.submask)[idx];
-      else { toff = g.tileoff[idx]; btile = g.block_tiles[idx >> 8]; }
+      toff = g.tileoff[idx];
+      if (!DIRECT) btile = g.block_tiles[idx >> 8];
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
       sA = spl[0]; sB = spl[1];
     }
     if (r1 != r0) {   // <=> radii > 0
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
-      goff = btile + toff;
+      // first per-tile record of this Gaussian's pairs (contiguous, row-major over its tile rectangle): direct bins -- inside its
+      // projection workgroup's span; packed bins -- its Gaussian-major pair index
+      first = DIRECT ? (uint32_t)(idx >> 8) * cam.trec_cap + toff : btile + toff;
+      const bool fits = DIRECT ? (toff + (uint32_t)area <= cam.trec_cap) : true;
+      if (!fits || (size_t)first + (size_t)area > (size_t)N_cap) area = 0;      // beyond the capacity (flagged by the forward): nothing was written
     }
-    gather_records<TRACK ? 2 : 3, TRACK ? REC_TRACK_F : REC_MAP_F, SLAM_BWD_FB, DIRECT>(area, goff, r0, r1, sA, sB, bblk + boff, dsub, bn, N_cap, acc0, acc1, acc2, m64);
+    gather_tile_records<TRACK>(area, first, dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F, acc0, acc1, acc2);
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};

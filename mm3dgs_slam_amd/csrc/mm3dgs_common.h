@@ -98,11 +98,12 @@ struct BinView {
   unsigned long long* keys;  // [N_cap]
   uint2* sublist;            // [16*N_cap]
   uint16_t* submask;         // [N_cap]
-  unsigned long long* payload;  // [N_cap] direct bins only: block mask | block-rectangle width << 16 | record of the tile's first block << 32
+  unsigned long long* payload;  // [N_cap] by position in the tile's bin (direct bins: slot; packed bins: sorted position): block mask | block-rectangle width << 16 | record of the tile's first block << 32
+  uint32_t* trec;               // [N_cap] same indexing: the pair's per-tile gradient record (SLAM modes; ~0u: none)
 };
 static inline size_t binning_bytes_impl(size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * 8, 256) + align_up(N * NLIST * 8, 256) + align_up(N * 2, 256) + align_up(N * 8, 256);
+  return align_up(N * 8, 256) + align_up(N * NLIST * 8, 256) + align_up(N * 2, 256) + align_up(N * 8, 256) + align_up(N * 4, 256);
 }
 static inline BinView bin_view(void* base, size_t N) {
   if (N < 1) N = 1;
@@ -111,7 +112,8 @@ static inline BinView bin_view(void* base, size_t N) {
   b.keys = (unsigned long long*)c;  c += align_up(N * 8, 256);
   b.sublist = (uint2*)c;            c += align_up(N * NLIST * 8, 256);
   b.submask = (uint16_t*)c;         c += align_up(N * 2, 256);
-  b.payload = (unsigned long long*)c;
+  b.payload = (unsigned long long*)c;  c += align_up(N * 8, 256);
+  b.trec = (uint32_t*)c;
   return b;
 }
 
@@ -140,6 +142,9 @@ __device__ __forceinline__ void tile_span(const ImageView& iv, int tile, uint32_
 
 struct BwdView {
   float* dsub;        // [16*N_cap][12] per-(4x4 block, splat) screen-space gradient records
+  float* dtile;       // [N_cap][12] SLAM modes: one record per (tile, splat) pair = the sum of the pair's block records, formed by the
+                      // compositor's workgroup after its rows are done; a Gaussian's pair records are contiguous (tile rectangle, row-major).
+                      // Directly behind dsub: the kernels find it at dsub + NLIST * N_cap * SPLAT_F
   float* campartial;  // [nrows][32] per-workgroup camera-gradient partial sums (SLAM path: float rows; generic path:
                       // the same region read as double rows -- it is sized for doubles)
   int nrows;
@@ -147,13 +152,14 @@ struct BwdView {
 static inline int bwd_rows(int P) { return (P + 255) / 256; }
 static inline size_t bwd_bytes_impl(int P, size_t N) {
   if (N < 1) N = 1;
-  return align_up(N * NLIST * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 8, 256);
+  return align_up(N * NLIST * SPLAT_F * 4, 256) + align_up(N * SPLAT_F * 4, 256) + align_up((size_t)(bwd_rows(P) + 1) * 32 * 8, 256);
 }
 static inline BwdView bwd_view(void* base, int P, size_t N) {
   if (N < 1) N = 1;
   char* c = (char*)base;
   BwdView b;
   b.dsub = (float*)c;  c += align_up(N * NLIST * SPLAT_F * 4, 256);
+  b.dtile = (float*)c; c += align_up(N * SPLAT_F * 4, 256);
   b.campartial = (float*)c;
   b.nrows = bwd_rows(P);
   return b;
@@ -196,6 +202,7 @@ struct CamDev {
   int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
   int bg_extras;    // 1 (SLAM entry points): channels 3..5 are the depth bundle of a second reference pass and get T_final * bg[ch - 3] as well
+  uint32_t trec_cap; // direct bins: per-tile gradient records per projection workgroup (workgroup w owns [w * trec_cap, (w + 1) * trec_cap)); 0: packed bins (Gaussian-major pair index)
   int state_clean;  // 1: persistent state buffers (MM3DGS_FWD_STATE_CLEAN): every forward leaves tile_count[] and cursor[] zero for the next one
   int fused_scan;   // 1: no scan_tiles launch, every scatter workgroup scans the tile counters itself (persistent state)
   const float* bg;
@@ -222,6 +229,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.sort_single = 0;
   d.bg_extras = 0;
   d.state_clean = 0;
+  d.trec_cap = 0;
   d.fused_scan = 0;
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
   return d;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX, int tile_table = 0) {
   const uint32_t slot_mask = (1u << slot_bits) - 1u;
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
@@ -80,10 +80,10 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       if (cnt > seen_max) atomicMax(&iv.hdr->max_tile_len, cnt);     // (rare: the maximum is sticky)
     }
     if (tile == 0) {
-      // N = pairs touched = sum of the projection workgroups' totals (g.tileoff[0..direct_blocks)); ONE writer -- 1200
+      // N = pairs touched = sum of the projection workgroups' totals (g.block_tiles[0..direct_blocks)); ONE writer -- 1200
       // same-address atomics would serialise in L2 for ~20 us
       uint32_t x = 0;
-      for (int i = tid; i < direct_blocks; i += 256) x += g.tileoff[i];
+      for (int i = tid; i < direct_blocks; i += 256) x += g.block_tiles[i];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
       if (lane == 0) sh.scan_tot[wv] = x;
@@ -240,6 +240,12 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
       if (pidx < N_cap && (size_t)rec0 + (size_t)br.bw * br.bh <= (size_t)NLIST * N_cap) b.submask[pidx] = (uint16_t)mask;
       else mask = 0;   // only on capacity overflow (flagged in the header)
+      // the compositor's per-tile combine (SLAM modes) finds every pair of the bin by its position: mask, block-rectangle width, first
+      // block record, and the pair's per-tile record = its Gaussian-major pair index
+      if (tile_table) {
+        b.payload[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)min(bw, 0xffffu) << 16) | ((unsigned long long)recT << 32);
+        b.trec[start + (uint32_t)i] = pidx < N_cap ? pidx : 0xffffffffu;
+      }
     }
     unsigned long long bal[NLIST];
 #pragma unroll
