@@ -454,6 +454,25 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
+  // per-tile combine (end of this function).  Measured on a static 150 k scene (tools/exp_ab.sh, MM3DGS_EXP bits 4 / 5): the pass costs
+  // 7.6 us of a 77.5 us launch -- 4.7 without its record loads (barrier, table loads, stores: the tail of every workgroup, and all
+  // 1200 of them end together), 2.9 for the loads; 2, 4 or 8 records in flight make no difference, and requesting the lane's table
+  // entries up here (COMBINE_TPRE) costs 5.5 us more than it saves.
+#ifndef COMBINE_TPRE
+#define COMBINE_TPRE 0
+#endif
+#ifndef COMBINE_UR
+#define COMBINE_UR 4
+#endif
+  constexpr int TPRE = COMBINE_TPRE;
+  unsigned long long tpl[TPRE > 0 ? TPRE : 1];
+  uint32_t ttr[TPRE > 0 ? TPRE : 1];
+#pragma unroll
+  for (int j = 0; j < TPRE; j++) {
+    const uint32_t e = (uint32_t)tid + 256u * (uint32_t)j;
+    tpl[j] = (MODE != 0 && e < len) ? b.payload[start + e] : 0ull;
+    ttr[j] = (MODE != 0 && e < len) ? b.trec[start + e] : 0xffffffffu;
+  }
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int RECF = MODE == 0 ? NV : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats: packed at the record's real size (composite_common.h; generic: 6 + C)
   // [buffer][wave][field A|B|C][row * 16 + entry] + [buffer][wave][row * 16 + entry] record indices: lane-contiguous
@@ -667,28 +686,27 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // moment ago (same CU: visible after the barrier); a pair is found by its position in the tile's bin (payload / trec).
     __syncthreads();
     float* __restrict__ dtile = dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F;
-    for (uint32_t e = (uint32_t)tid; e < len; e += 256u) {
-      const unsigned long long pl = b.payload[start + e];
-      const uint32_t tr = b.trec[start + e];
+    auto combine = [&](const unsigned long long pl, const uint32_t tr) {
       uint32_t mask = (uint32_t)pl & 0xffffu;
       const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
       float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
       while (mask) {
-        // up to four records in flight
-        float4 ra[4], rb[4], rc[4];
-        bool on[4];
+        // a few records in flight (a pair lists ~4 blocks on average: one round for most)
+        constexpr int UR = COMBINE_UR;
+        float4 ra[UR], rb[UR], rc[UR];
+        bool on[UR];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UR; u++) {
           on[u] = mask != 0u;
           const int L = on[u] ? __ffs((int)mask) - 1 : 0;
           mask &= mask - 1u;
           const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
-          const float* r = dsub + (on[u] ? (size_t)rec * RECF : (size_t)0);
+          const float* r = dsub + ((on[u] && !(cam.exp & 16)) ? (size_t)rec * RECF : (size_t)0);      // (MM3DGS_EXP bit 4: timing probe without the record gather)
           ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
           rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UR; u++) {
           a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
           a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
           if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
@@ -701,6 +719,12 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         if (MODE == 1) { const f4u q1 = {a1.x, a1.y, a1.z, a1.w}; *(f4u*)(o + 4) = q1; const f2u q2 = {a2.x, a2.y}; *(f2u*)(o + 8) = q2; }
         else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
       }
+    };
+    if (!(cam.exp & 32)) {      // (MM3DGS_EXP bit 5: timing probe without the combine)
+#pragma unroll
+    for (int j = 0; j < TPRE; j++)
+      if ((uint32_t)tid + 256u * (uint32_t)j < len) combine(tpl[j], ttr[j]);
+    for (uint32_t e = (uint32_t)tid + 256u * TPRE; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
     }
   }
 }
