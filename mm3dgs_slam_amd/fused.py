@@ -211,7 +211,9 @@ class FusedEngine:
         """Smallest ratio capacity / (largest demand seen) over the three capacities a forward can run out of (pairs, per-tile
         span, gradient records per projection workgroup), for the CURRENT buffers and map size; 0 when nothing has been measured
         for them yet (fresh buffers, a map that changed size since the last check)."""
-        if self.ratio is None or self.P <= 0 or getattr(self, "_checked_P", -1) != self.P or getattr(self, "_checked_cap", -1) != self.n_cap:
+        cp = getattr(self, "_checked_P", -1)
+        # (a map that shrank a little since the last check -- a pruning step -- can only need less)
+        if self.ratio is None or self.P <= 0 or not (0.9 * cp <= self.P <= cp) or getattr(self, "_checked_cap", -1) != self.n_cap:
             return 0.0
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         h = self.n_cap / max(self.ratio * self.P, 1.0)
@@ -260,6 +262,8 @@ def _engine(renderer):
 
 
 class FusedTracker(Tracker):
+    lazy_checks = True       # False: read the capacity header back after every loop (debugging / tests)
+
     def optimize_cam(self, idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth=None, est_depth=None):
         trk = self.cfg["tracking"]
         if (num_iter == 0 or self.keep_best_candidate or not FusedEngine.eligible(self.cfg, self.gaussians)):
@@ -294,6 +298,11 @@ class FusedTracker(Tracker):
                 if trk["use_imu_loss"] and self.cfg["method"].lower() != "splatam":      # rel_pose_loss against the pose the optimisation starts from (slam/tracker.py:87,146-155; not in the splatam branch)
                     ad.prior_pose, ad.prior_w_t, ad.prior_w_q = pose0.data_ptr(), float(trk["imu_T_weight"]), float(trk["imu_q_weight"])
                 eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
+                # With ample headroom (largest demand seen < 2/3 of every capacity, same map size) the read-back -- a device
+                # synchronisation per frame -- is left to the mapper's next drained point (the header's overflow word is sticky, so
+                # nothing is lost; a frame's 100 pose steps cannot grow a tile list by half).
+                if self.lazy_checks and getattr(eng, "headroom", lambda: 0.0)() >= 1.5:
+                    break
                 if eng.check_capacity():
                     break
             else:
@@ -311,6 +320,9 @@ class FusedTracker(Tracker):
 
 
 class FusedMapper(Mapper):
+    lazy_checks = True       # False: read the capacity header back after every loop (debugging / tests)
+    _piggybacked = False
+    _late_overflow = False
     always_snapshot = False      # debugging / tests: snapshot the map before every mapping loop (the round-2 behaviour)
 
     def _render_depth_sil(self, pose):
@@ -485,9 +497,15 @@ class FusedMapper(Mapper):
         eng._ensure(int(g._xyz.shape[0]), True)
         need_snap = self.always_snapshot or getattr(eng, "headroom", lambda: 0.0)() < 1.5 or (self.window is not None and self.window._collective)
         snap, rng_state = (g.snapshot(), _random.getstate()) if need_snap else (None, None)
+        self._late_overflow, self._piggybacked = False, False
         for attempt in range(4):
-            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at)
-            ok = eng.check_capacity()
+            self._map_loop_once(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, piggyback=snap is None)
+            if snap is None and self.lazy_checks and self._piggybacked and getattr(eng, "headroom", lambda: 0.0)() >= 1.5:
+                # no snapshot was needed (ample headroom) and the header was read at this loop's pruning steps, where the device is
+                # drained anyway: the end-of-loop read-back (one more synchronisation per frame) is left to the next drained point
+                ok = not self._late_overflow
+            else:
+                ok = eng.check_capacity() and not self._late_overflow
             if self.window is not None and self.window._collective:
                 ok = not self.window.any_flag(not ok, device=eng.dev)
             if ok:
@@ -521,7 +539,7 @@ class FusedMapper(Mapper):
             self.mapping_time_sum += time.perf_counter() - t_start
         self.mapping_iter_count += num_iter
 
-    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at):
+    def _map_loop_once(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, piggyback=False):
         splatam = self.cfg["method"].lower() == "splatam"       # prunes (prune_at), never collects densification statistics
 
         def dens(it):
@@ -596,6 +614,12 @@ class FusedMapper(Mapper):
                         nxt.table = FusedEngine.view_table(nxt)
                         prepared = (iteration + 1, nxt)
                     pruned = g.prune(m["min_opacity"], self.camera_extent, None if splatam else m["size_threshold"])
+                    if piggyback and hasattr(eng, "check_capacity"):
+                        # the pruning step has just synchronised on its 4-byte read-back: the capacity header (sticky: every forward
+                        # since the last read, the tracker's included) is read here for free
+                        if not eng.check_capacity():
+                            self._late_overflow = True
+                        self._piggybacked = True
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
                         self._opt_mask = self._opt_mask[~pruned].contiguous()
                 iteration += 1
