@@ -15,12 +15,12 @@
 #include "tile_mask.h"
 
 #define FB 256
-// workgroup size of the backward projection (its rows of pose partials, its gather lists): independent of the projection kernels' 256.
-// 128: at 157 k Gaussians 1226 workgroups instead of 613 spread evenly over the 256 CUs (613 = two on some CUs, three on others):
-// mapping 33.1 -> 30.8 us, tracking 21.5 -> 20.4 us per launch, the pose-finish kernel reads twice the rows (+1.3 us).  The partial-row
-// region of the scratch is sized for 256-lane workgroups writing double rows, i.e. it holds exactly twice as many float rows: 64 would not fit.
+// workgroup size of the backward projection (= its rows of pose partials): independent of the projection kernels' 256.  With the per-block
+// gather (its wave-level work lists, 28 KB of LDS) 128 lanes spread better over the CUs (mapping 33.1 -> 30.8 us); with one record per
+// (tile, splat) pair the kernel is two short rounds of loads and 256 lanes win again (mapping 19.1 -> 18.6 us, and the pose-finish
+// kernel reads half the rows: 8.4 -> 7.3 us).  The partial-row region of the scratch holds (P / 256 + 1) * 64 floats: 64-lane groups would not fit.
 #ifndef SLAM_BWD_FB
-#define SLAM_BWD_FB 128
+#define SLAM_BWD_FB 256
 #endif
 static_assert(SLAM_BWD_FB == 128 || SLAM_BWD_FB == 256, "the partial-row region holds (P / 256 + 1) * 64 floats");
 #define SH_C0F 0.28209479177387814f
