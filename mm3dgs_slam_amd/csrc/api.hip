@@ -248,7 +248,7 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
 
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                              void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
-                             const TrackLoss* tl, float* track_dsub = nullptr) {
+                             const TrackLoss* tl, float* track_dsub = nullptr, bool projected = false) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -271,7 +271,8 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   const DirectBins db = slam_direct_bins(flags, cd, P, N_capacity);
   cd.trec_cap = db.on ? db.trec_cap : 0u;
   if (db.on) {
-    { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s); }
+    // projected: the previous mapping iteration's backward launch already projected and binned this view (slam_bwd_project_kernel)
+    if (!projected) { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s); }
     { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
       if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap, db.slot_bits);
       else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks, db.bin_cap, db.slot_bits); }
@@ -308,7 +309,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
                               const void* geom_state, const void* image_state, const void* binning_state, size_t N_capacity,
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
                               const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, int flags, void* stream, const TrackLoss* tl,
-                              float* prior_loss4 = nullptr, int dl_planes = 6, bool compositor_done = false) {
+                              float* prior_loss4 = nullptr, int dl_planes = 6, bool compositor_done = false, const float* fuse_next_pose = nullptr,
+                              bool* fused_out = nullptr) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
@@ -361,6 +363,14 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   if (!compositor_done)
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
     launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
+  // mapping run, direct bins, in-kernel Adam, no pose step: this launch also projects and bins the NEXT iteration's view
+  const bool fuse = fuse_next_pose && !tracking && ma.on && db_bwd.on && !dL_dpose && !pa.pose && !sg.d_xyz;
+  if (fused_out) *fused_out = fuse;
+  if (fuse) {
+    ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s);
+    launch_slam_bwd_project(cd, P, slam_in(in), (int32_t*)radii, g, image_view((void*)image_state, cd.H, cd.W), b, N_capacity, bw, sg, ma, fuse_next_pose,
+                            db_bwd.bin_cap, db_bwd.rec_cap, db_bwd.slot_bits, s);
+  } else
   { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on); }
   return check_launch("slam_backward");
 }
@@ -490,6 +500,10 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
     lc = loss_cfg_dev(loss_cfg);
     tl.cfg = lc; tl.out = out_color; tl.sums = sums; tl.partial = partial; tl.loss4 = nullptr; tl.defer_scale = 0;
   }
+  // the backward launch of iteration `it` projects and bins the view of iteration `it + 1` when nothing stands between them (direct bins,
+  // in-kernel Adam, neither view steps its pose); MM3DGS_NO_FUSED_PROJECT keeps the two launches apart (tests compare both, bit for bit)
+  const int no_fuse_proj = env_flag("MM3DGS_NO_FUSED_PROJECT", 0);
+  bool projected = false;
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
     if (loss_cfg->w_pearson != 0.f && !views[it].ref_depth_or_null) return fail(-2, "view %d: Pearson term needs a reference depth", it);
@@ -498,7 +512,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
     int rc;
     if (rows) {
       tl.gt = views[it].gt_color; tl.ref = views[it].ref_depth_or_null;
-      rc = slam_forward_impl(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, &tl);
+      rc = slam_forward_impl(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, &tl, nullptr, projected);
       if (rc) return rc;
       // the gradient-image pass itself runs in the backward compositor's prologue (tl.dmaps set) unless MM3DGS_NO_FOLDED_LOSS asks
       // for the separate launch
@@ -509,8 +523,12 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       rc = check_launch("loss");
       if (rc) return rc;
       tl.dmaps = fold_grad ? dmaps : nullptr;
+      const float* next_pose = (!no_fuse_proj && map_adam && it + 1 < n_iter && !views[it].pose_adam_or_null && !views[it + 1].pose_adam_or_null &&
+                                views[it + 1].pose) ? views[it + 1].pose : nullptr;
+      projected = false;
       rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
-                              views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream, fold_grad ? &tl : nullptr, nullptr, 4);
+                              views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream, fold_grad ? &tl : nullptr, nullptr, 4, false,
+                              next_pose, &projected);
     } else {
       rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
       if (rc) return rc;

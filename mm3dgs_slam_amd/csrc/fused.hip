@@ -73,25 +73,22 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
 // Projection of one Gaussian (lane): pose transform, activations, EWA, SH degree 0 -> RGB, [z, 1, z^2], tile rectangle, block
 // rectangle.  Writes the splat record, depth, clamp bits, radii and rect; returns what the binning half of the kernels needs.
 struct Projected { uint32_t r0, r1, nblk; float4 sA, sB; BlkRect br; float z; int32_t rad; };
-__device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, int idx, const SlamIn& in, int32_t* __restrict__ radii,
-                                                      const GeomView& g) {
-  const bool live = idx < P;
+// raw parameters of one Gaussian, as the projection consumes them
+struct RawGaussian { float x[3], q[4], ls[3], fd[3], op; };
+
+// projection of a Gaussian whose raw parameters are already in registers (loaded by slam_project_one, or just stepped by the map's
+// in-kernel Adam: slam_bwd_project_kernel)
+__device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool live, int idx, const float* __restrict__ pose, bool isotropic,
+                                                       const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g) {
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
-  const PoseDev ps = load_pose(in.pose);
+  const PoseDev ps = load_pose(pose);
   float p[3] = {0.f, 0.f, 0.f};
-  // every parameter of this Gaussian is requested up front (one memory latency for the kernel, not two: the map is
-  // almost entirely in view in a SLAM iteration, so nothing is wasted on culled splats)
-  float q_raw[4] = {1.f, 0.f, 0.f, 0.f}, ls_raw[3] = {0.f, 0.f, 0.f}, fd_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
+  const float* q_raw = rg.q; const float* ls_raw = rg.ls; const float* fd_raw = rg.fd;
+  const float op_raw = rg.op;
   if (live) {
-    const float x0 = in.xyz[(size_t)idx * 3], x1 = in.xyz[(size_t)idx * 3 + 1], x2 = in.xyz[(size_t)idx * 3 + 2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) q_raw[k] = in.rotation[(size_t)idx * 4 + k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { ls_raw[k] = in.scaling[(size_t)idx * 3 + k]; fd_raw[k] = in.f_dc[(size_t)idx * 3 + k]; }
-    op_raw = in.opacity[idx];
-#pragma unroll
-    for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * x0 + ps.R[i][1] * x1 + ps.R[i][2] * x2 + ps.t[i];
+    for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * rg.x[0] + ps.R[i][1] * rg.x[1] + ps.R[i][2] * rg.x[2] + ps.t[i];
   }
   Projected o;
   o.r0 = 0; o.r1 = 0; o.nblk = 0; o.rad = 0; o.z = 0.f;
@@ -103,7 +100,7 @@ __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, 
     float hw = p[0] * PV[3] + p[1] * PV[7] + p[2] * PV[11] + PV[15];
     float pw = 1.f / (hw + 1e-7f);
     float S3[3][3], R[3][3], sm[3], qn[4], qinv;
-    slam_cov3d_vals(q_raw, ls_raw, in.isotropic != 0, cam.scale_modifier, S3, R, sm, qn, qinv);
+    slam_cov3d_vals(q_raw, ls_raw, isotropic, cam.scale_modifier, S3, R, sm, qn, qinv);
     Ewa e;
     ewa_project(cam, Vi, p, S3, e);
     float det = e.a * e.c - e.b * e.b;
@@ -146,6 +143,24 @@ __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, 
     g.rect[(size_t)idx * 2 + 1] = o.r1;
   }
   return o;
+}
+
+__device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, int idx, const SlamIn& in, int32_t* __restrict__ radii,
+                                                      const GeomView& g) {
+  const bool live = idx < P;
+  // every parameter of this Gaussian is requested up front (one memory latency for the kernel, not two: the map is
+  // almost entirely in view in a SLAM iteration, so nothing is wasted on culled splats)
+  RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) rg.x[k] = in.xyz[(size_t)idx * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rg.q[k] = in.rotation[(size_t)idx * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rg.ls[k] = in.scaling[(size_t)idx * 3 + k]; rg.fd[k] = in.f_dc[(size_t)idx * 3 + k]; }
+    rg.op = in.opacity[idx];
+  }
+  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g);
 }
 
 __global__ void __launch_bounds__(FB)
@@ -248,17 +263,13 @@ __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t*
   return mask;
 }
 
-__global__ void __launch_bounds__(FB)
-slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
-                        uint32_t rec_cap, int slot_bits) {
-  extern __shared__ uint32_t hist[];     // [T]: pairs of this workgroup per tile, then the next slot of each touched tile
+// The binning half of the projection kernels: every lane hands in the projection of ITS Gaussian (slam_project_one / _vals); hist = the
+// workgroup's [T] words of LDS, cleared by the caller before (the first barrier inside orders the clear).
+__device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx, const Projected& pr, const GeomView& g, const ImageView& iv,
+                                               const BinView& b, uint32_t cap, uint32_t rec_cap, int slot_bits, uint32_t* hist) {
   const int T = cam.gx * cam.gy;
   const int tid = threadIdx.x, lane = tid & 63, wvi = tid >> 6;
-  for (int t = tid; t < T; t += FB) hist[t] = 0;
-  if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
-  const int idx = blockIdx.x * FB + tid;
   const bool live = idx < P;
-  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
   PairCtx c;
   c.mc = mask_consts(pr.sA, pr.sB);
   c.br = pr.br;
@@ -350,6 +361,19 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   }
 }
 
+__global__ void __launch_bounds__(FB)
+slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
+                        uint32_t rec_cap, int slot_bits) {
+  extern __shared__ uint32_t hist[];     // [T]: pairs of this workgroup per tile, then the next slot of each touched tile
+  const int T = cam.gx * cam.gy;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < T; t += FB) hist[t] = 0;
+  if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
+  const int idx = blockIdx.x * FB + tid;
+  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
+  slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
+}
+
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
                              uint32_t rec_cap, int slot_bits, hipStream_t s) {
   if (P <= 0) return;
@@ -408,10 +432,11 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
+// stepped: (the map's in-kernel Adam, ma.on) the lane's parameters AFTER the step -- what the next iteration's projection reads
 template <bool TRACK, bool DIRECT>
-__global__ void __launch_bounds__(SLAM_BWD_FB)
-slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
+__device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
+                                              uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
+                                              const MapAdam& ma, RawGaussian* stepped) {
   const int idx = blockIdx.x * SLAM_BWD_FB + threadIdx.x;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
@@ -610,8 +635,16 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
           const float mi = am[q] + (gr - am[q]) * ma.omb1;                 // exp_avg.lerp_(grad, 1 - beta1)
           const float vi = av[q] * ma.beta2 + gr * gr * ma.omb2;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
           ma.m[gq][off] = mi; ma.v[gq][off] = vi;
-          ma.p[gq][off] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+          ap[q] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+          ma.p[gq][off] = ap[q];
         }
+      if (stepped) {      // AG layout: xyz 0-2 | f_dc 3-5 | opacity 6 | scaling 7-9 | rotation 10-13
+#pragma unroll
+        for (int k = 0; k < 3; k++) { stepped->x[k] = ap[k]; stepped->fd[k] = ap[3 + k]; stepped->ls[k] = ap[7 + k]; }
+        stepped->op = ap[6];
+#pragma unroll
+        for (int k = 0; k < 4; k++) stepped->q[k] = ap[10 + k];
+      }
     }
   }
   if (posepartial) {   // mapping without pose optimisation never consumes the pose gradient
@@ -631,6 +664,46 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       posepartial[(size_t)blockIdx.x * 32 + k] = t;
     }
   }
+}
+
+template <bool TRACK, bool DIRECT>
+__global__ void __launch_bounds__(SLAM_BWD_FB)
+slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
+  slam_bwd_body<TRACK, DIRECT>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr);
+}
+
+// A mapping iteration's backward projection + Adam step and the NEXT iteration's projection + binning in one launch (direct bins, in-kernel
+// Adam, no per-view pose step): both are one lane per Gaussian over the same index space, the stepped parameters go from the optimiser
+// to the projection in registers (no second read of the map), and one launch with its ramp disappears from every mapping iteration.
+// The lane reads the geometry of iteration k (its own rect / pair offset / splat record) before the projection half overwrites it for
+// iteration k + 1; the bins and cursors were released by iteration k's sort; the per-tile records it sums were written by iteration k's
+// compositor and are not touched again before iteration k + 1's.
+static_assert(SLAM_BWD_FB == FB, "the fused backward + projection kernel uses one lane per Gaussian in both halves");
+__global__ void __launch_bounds__(FB)
+slam_bwd_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t N_cap,
+                        const float* __restrict__ dsub, SlamGrads out, MapAdam ma, const float* __restrict__ next_pose, uint32_t cap,
+                        uint32_t rec_cap, int slot_bits) {
+  extern __shared__ uint32_t hist[];
+  const int T = cam.gx * cam.gy;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < T; t += FB) hist[t] = 0;
+  if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
+  const int idx = blockIdx.x * FB + tid;
+  RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+  slam_bwd_body<false, true>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg);
+  const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g);
+  slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
+}
+
+void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, size_t N_cap,
+                             BwdView bw, const SlamGrads& out, const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap,
+                             int slot_bits, hipStream_t s) {
+  if (P <= 0) return;
+  const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
+  const int T = cam.gx * cam.gy;
+  hipLaunchKernelGGL(slam_bwd_project_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, ncap, bw.dsub, out, ma,
+                     next_pose, bin_cap, rec_cap, slot_bits);
 }
 
 // One wave: fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through

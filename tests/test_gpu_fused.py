@@ -948,3 +948,26 @@ def test_utmm_shaped_config_with_imu_runs_natively_and_tracks():
     want = propagate_imu(slam.estimate_pose_list[3].cpu(), slam.estimate_pose_list[2].cpu(), seq.imu(4), seq.tf["c2i"], seq.dt_cam, 0.01).to(DEV)
     assert torch.allclose(pred, want, atol=1e-6)
     assert (pred - seq.poses[4]).abs().max() < 2e-2          # (dead-reckoned from ESTIMATED poses: their mm-level errors enter the velocity)
+
+
+def test_backward_launch_that_projects_the_next_view_is_bit_identical(monkeypatch):
+    """slam_bwd_project_kernel (the backward projection + Adam step of mapping iteration k and the projection + binning of iteration k + 1
+    in one launch, the stepped parameters handed over in registers) against the two separate launches (MM3DGS_NO_FUSED_PROJECT): the same
+    arithmetic on the same values, so three SLAM frames must end with bit-identical maps, poses and statistics."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MM3DGS_NO_FUSED_PROJECT", flag)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 5}, mapping={"iters": 12, "kf_every": 1, "pruning_interval": 5})
+        seq = SyntheticSequence(cfg, 3, 6000, seed=6)
+        slam = SLAM(cfg, seq)
+        for i in range(3):
+            slam.step(i)
+        g = slam.gaussians
+        res.append((g._xyz.detach().clone(), g._opacity.detach().clone(), g._scaling.detach().clone(), g._rotation.detach().clone(),
+                    g._features_dc.detach().clone(), g.xyz_gradient_accum.clone(), g.max_radii2D.clone(),
+                    torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:3]])))
+    for a, b in zip(*res):
+        assert a.shape == b.shape and torch.equal(a, b)
