@@ -9,6 +9,12 @@
 // Reference quirk kept: the Gaussians' rotations are NOT composed with the camera rotation in this mode
 // (slam/renderer.py:152,171-173), i.e. the covariance stays in world orientation while the mean is in camera space.
 // Everything downstream (scan, scatter, sort, compositors) is the generic pipeline with C = 6.
+//
+// Floating-point contraction in this translation unit follows the SOURCE (a * b + c inside one expression is an fma, nothing else is):
+// hipcc's default lets the optimiser fuse across statements, and what it fuses then depends on the code around an inlined function --
+// the projection inlined behind the optimiser step (slam_bwd_project_kernel) rounded the conics of ~9 % of the splats one bit away from
+// the standalone projection kernel's, which Adam(eps = 1e-15) amplifies into visibly different maps within a few frames.
+#pragma clang fp contract(on)
 #include "mm3dgs_math.h"
 #include "fused_api.h"
 #include "composite_common.h"

@@ -950,37 +950,28 @@ def test_utmm_shaped_config_with_imu_runs_natively_and_tracks():
     assert (pred - seq.poses[4]).abs().max() < 2e-2          # (dead-reckoned from ESTIMATED poses: their mm-level errors enter the velocity)
 
 
-def test_backward_launch_that_projects_the_next_view_matches_the_separate_launches(monkeypatch):
+def test_backward_launch_that_projects_the_next_view_is_bit_identical(monkeypatch):
     """slam_bwd_project_kernel (the backward projection + Adam step of mapping iteration k and the projection + binning of iteration k + 1
-    in one launch, the stepped parameters handed over in registers) against the two separate launches (MM3DGS_NO_FUSED_PROJECT).  On the
-    first frame (isotropic identity Gaussians) the two are bit-identical; from the second frame on the projection inlined behind the
-    optimiser step rounds a few last bits differently from the standalone kernel, and Adam(eps=1e-15) turns a last-bit difference of a
-    near-zero gradient into an isolated +-lr step (cf. tests/test_gpu_rccl.py).  Asserted: frame 0 bit-identical; after three frames the
-    poses and >= 99.5 % of every parameter array to 1e-4, no element further apart than a few optimiser steps.  (The fused path itself
-    is deterministic and is the one tests/test_gpu_golden_slam.py holds to the reference's own classes.)"""
+    in one launch, the stepped parameters handed over in registers) against the two separate launches (MM3DGS_NO_FUSED_PROJECT): three SLAM
+    frames (tracking, keyframes, pruning, a window of several views), every parameter, statistic and pose bit for bit.  This only holds
+    because fused.hip pins floating-point contraction to the source (`#pragma clang fp contract(on)`): with hipcc's default the optimiser
+    fused differently around the inlined projection and ~9 % of the conics came out one bit away -- after three frames 3 % of the opacity
+    logits differed by more than 1e-5 (Adam with eps = 1e-15 turns last-bit noise of near-zero gradients into +-lr steps)."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
 
-    def run(flag, frames):
+    def run(flag):
         monkeypatch.setenv("MM3DGS_NO_FUSED_PROJECT", flag)
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 5}, mapping={"iters": 12, "kf_every": 1, "pruning_interval": 5})
         seq = SyntheticSequence(cfg, 3, 6000, seed=6)
         slam = SLAM(cfg, seq)
-        for i in range(frames):
+        for i in range(3):
             slam.step(i)
         g = slam.gaussians
         return dict(xyz=g._xyz.detach().clone(), op=g._opacity.detach().clone(), sc=g._scaling.detach().clone(), rot=g._rotation.detach().clone(),
                     fdc=g._features_dc.detach().clone(), acc=g.xyz_gradient_accum.clone(), rad=g.max_radii2D.clone(),
-                    poses=torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:frames]]))
-    a, b = run("1", 1), run("0", 1)
+                    poses=torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:3]]))
+    a, b = run("1"), run("0")
     for k in a:
-        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
-    a, b = run("1", 3), run("0", 3)
-    assert torch.allclose(a["poses"], b["poses"], rtol=1e-4, atol=1e-5), float((a["poses"] - b["poses"]).abs().max())
-    for k in ("xyz", "op", "sc", "fdc", "acc", "rad"):
-        assert a[k].shape == b[k].shape, k
-        d = (a[k] - b[k]).abs()
-        off = d > 1e-5 + 1e-4 * b[k].abs()
-        assert float(off.float().mean()) <= 5e-3, (k, float(off.float().mean()), float(d.max()))
-        assert float(d.max()) <= 0.2, (k, float(d.max()))
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
