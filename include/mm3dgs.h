@@ -293,6 +293,12 @@ int mm3dgs_seed_gaussians(int H, int W, const float* color /*[3,H,W]*/, const fl
 int mm3dgs_covisibility_ratio(int H, int W, const float* depth /*[H,W]*/, const float* silhouette /*[H,W]*/, const float* keyframe_pose,
                               const float* current_pose, float fx, float fy, float cx, float cy, uint32_t* counts /*[2]*/, void* stream);
 
+/* Constant-velocity pose prediction of the tracker (utils/pose_utils.py:203-216 propagate_const_vel, called at slam/tracker.py:200-206):
+ * out = pose of (W1 W2^-1) W1 for the world->camera poses of the last two frames, all three (qw,qx,qy,qz,tx,ty,tz) on the device;
+ * computed in double precision by one lane, so the frame's first tracking launch needs no pose on the host. */
+int mm3dgs_propagate_const_vel(const float* pose_m1 /*[7], frame idx-1*/, const float* pose_m2 /*[7], frame idx-2*/, float* out_pose /*[7]*/,
+                               void* stream);
+
 /* ---- optional per-kernel timing (HIP events recorded on the caller's stream around each launch) ------------
  * Used by bench.py's roofline leg.  mm3dgs_profile_read() waits for the recorded events, returns the number of
  * (timed) launches and their summed duration since the previous read, and resets the counters. */

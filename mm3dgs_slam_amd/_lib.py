@@ -73,6 +73,7 @@ class Mm3dgsSeedOutputs(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "mm3dgs_profile_event_overhead_ms": (C.c_double, [_P]),
+    "mm3dgs_propagate_const_vel": (C.c_int, [_P, _P, _P, _P]),
     "mm3dgs_covisibility_ratio": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "mm3dgs_prune_mask": (C.c_int, [C.c_int, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P]),
     "mm3dgs_compact_work_bytes": (C.c_size_t, [C.c_size_t]),

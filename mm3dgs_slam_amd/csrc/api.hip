@@ -569,6 +569,12 @@ int mm3dgs_covisibility_ratio(int H, int W, const float* depth, const float* sil
   return check_launch("covisibility_ratio");
 }
 
+int mm3dgs_propagate_const_vel(const float* pose_m1, const float* pose_m2, float* out_pose, void* stream) {
+  if (!pose_m1 || !pose_m2 || !out_pose) return fail(-1, "propagate_const_vel: NULL argument");
+  launch_propagate_const_vel(pose_m1, pose_m2, out_pose, (hipStream_t)stream);
+  return check_launch("propagate_const_vel");
+}
+
 int mm3dgs_prune_mask(int P, const float* opacity, const float* log_scales, const float* max_radii2D, float min_opacity, float max_scale,
                       float max_screen_size, uint8_t* keep, uint32_t* n_pruned_accum, void* stream) {
   if (P < 0) return fail(-1, "P < 0");

@@ -208,10 +208,62 @@ void launch_seed_gaussians(int H, int W, const float* color, const float* depth,
   hipLaunchKernelGGL(seed_gaussians_kernel, dim3((n + CB - 1) / CB), dim3(CB), 0, s, H, W, color, depth, keep, block_pre, pose, fx, fy, cx, cy,
                      row0, o);
 }
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
 void launch_covisibility_ratio(int H, int W, const float* depth, const float* sil, const float* kf_pose, const float* cur_pose, float fx, float fy,
                                float cx, float cy, uint32_t* counts, hipStream_t s) {
-  (void)hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s);
+  // (a two-word hipMemsetAsync goes through the runtime's fill path: ~75 us before the next kernel starts, measured; a one-wave launch: 5)
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, counts, 2);
   if (H * W <= 0) return;
   const int nb = std::min((H * W + CB - 1) / CB, 64);
   hipLaunchKernelGGL(covisibility_ratio_kernel, dim3(nb), dim3(CB), 0, s, H, W, depth, sil, kf_pose, cur_pose, fx, fy, cx, cy, counts);
+}
+
+// ---- constant-velocity pose prediction (utils/pose_utils.py:203-216 propagate_const_vel; :352-383 get_camera_from_tensor /
+// get_tensor_from_camera): W' = (W1 W2^-1) W1 for the last two world->camera poses, back to (q, t).  One lane, double precision (the
+// tracker used to read the two poses back and do this on the host: a device drain at the head of every frame).  Same algebra as
+// pose_utils.propagate_const_vel_np: normalised quaternion -> R, closed-form rigid inverse, best-conditioned matrix -> quaternion branch.
+__global__ void propagate_const_vel_kernel(const float* __restrict__ pm1, const float* __restrict__ pm2, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double R1[3][3], R2[3][3], t1[3], t2[3];
+  const float* src[2] = {pm1, pm2};
+  for (int v = 0; v < 2; v++) {
+    double (*R)[3] = v == 0 ? R1 : R2;
+    double* t = v == 0 ? t1 : t2;
+    double w = src[v][0], x = src[v][1], y = src[v][2], z = src[v][3];
+    const double n = sqrt(w * w + x * x + y * y + z * z);
+    w /= n; x /= n; y /= n; z /= n;
+    R[0][0] = 1.0 - 2.0 * (y * y + z * z); R[0][1] = 2.0 * (x * y - w * z); R[0][2] = 2.0 * (x * z + w * y);
+    R[1][0] = 2.0 * (x * y + w * z); R[1][1] = 1.0 - 2.0 * (x * x + z * z); R[1][2] = 2.0 * (y * z - w * x);
+    R[2][0] = 2.0 * (x * z - w * y); R[2][1] = 2.0 * (y * z + w * x); R[2][2] = 1.0 - 2.0 * (x * x + y * y);
+    t[0] = src[v][4]; t[1] = src[v][5]; t[2] = src[v][6];
+  }
+  // step = W1 W2^-1: rotation A = R1 R2^T, translation a = t1 - A t2;  W' = step W1: rotation A R1, translation A t1 + a
+  double A[3][3], a[3], m[3][3], tn[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i][j] = R1[i][0] * R2[j][0] + R1[i][1] * R2[j][1] + R1[i][2] * R2[j][2];
+  for (int i = 0; i < 3; i++) a[i] = t1[i] - (A[i][0] * t2[0] + A[i][1] * t2[1] + A[i][2] * t2[2]);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) m[i][j] = A[i][0] * R1[0][j] + A[i][1] * R1[1][j] + A[i][2] * R1[2][j];
+    tn[i] = A[i][0] * t1[0] + A[i][1] * t1[1] + A[i][2] * t1[2] + a[i];
+  }
+  const double four_sq[4] = {1.0 + m[0][0] + m[1][1] + m[2][2], 1.0 + m[0][0] - m[1][1] - m[2][2], 1.0 - m[0][0] + m[1][1] - m[2][2],
+                             1.0 - m[0][0] - m[1][1] + m[2][2]};
+  const double cand[4][4] = {{four_sq[0], m[2][1] - m[1][2], m[0][2] - m[2][0], m[1][0] - m[0][1]},
+                             {m[2][1] - m[1][2], four_sq[1], m[1][0] + m[0][1], m[0][2] + m[2][0]},
+                             {m[0][2] - m[2][0], m[1][0] + m[0][1], four_sq[2], m[1][2] + m[2][1]},
+                             {m[1][0] - m[0][1], m[2][0] + m[0][2], m[2][1] + m[1][2], four_sq[3]}};
+  int best = 0;
+  double mag = sqrt(fmax(four_sq[0], 0.0));
+  for (int k = 1; k < 4; k++) {
+    const double mk = sqrt(fmax(four_sq[k], 0.0));
+    if (mk > mag) { mag = mk; best = k; }       // (first maximum, like argmax)
+  }
+  const double den = 2.0 * fmax(mag, 0.1);
+  for (int k = 0; k < 4; k++) out[k] = (float)(cand[best][k] / den);
+  for (int k = 0; k < 3; k++) out[4 + k] = (float)tn[k];
+}
+void launch_propagate_const_vel(const float* pm1, const float* pm2, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(propagate_const_vel_kernel, dim3(1), dim3(64), 0, s, pm1, pm2, out);
 }

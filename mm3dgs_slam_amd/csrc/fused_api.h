@@ -87,3 +87,4 @@ void launch_seed_gaussians(int H, int W, const float* color, const float* depth,
 
 void launch_covisibility_ratio(int H, int W, const float* depth, const float* sil, const float* kf_pose, const float* cur_pose, float fx, float fy,
                                float cx, float cy, uint32_t* counts, hipStream_t s);
+void launch_propagate_const_vel(const float* pm1, const float* pm2, float* out, hipStream_t s);

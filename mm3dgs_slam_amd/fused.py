@@ -196,15 +196,32 @@ class FusedEngine:
         covers every iteration and every view of it.  Updates the capacity model from the LARGEST pair count seen, clears the
         sticky words, and returns False if any forward overflowed (its tile lists were clamped, so the loop's results are
         invalid: the caller restores its state and re-runs with the capacity this call has already raised)."""
-        h = self.img_state[:36].view(torch.int32).cpu()
+        token = self.check_capacity_begin()
+        torch.cuda.current_stream(self.dev).synchronize()
+        return self.check_capacity_end(token)
+
+    def check_capacity_begin(self):
+        """First half of check_capacity, without the synchronisation: the header is copied to pinned host memory and its sticky words
+        are cleared, in stream order.  A caller that is about to drain the stream anyway (the pruning step's 4-byte read-back) calls
+        this before and check_capacity_end after: one round trip instead of two, and nothing launched between the read-back and the
+        next run."""
+        if getattr(self, "_hdr_pin", None) is None:
+            self._hdr_pin = torch.empty(9, dtype=torch.int32).pin_memory()
+        self._hdr_pin.copy_(self.img_state[:36].view(torch.int32), non_blocking=True)
+        self.img_state[4:16].zero_()
+        self.img_state[32:36].zero_()
+        return (self.P, self.n_cap)
+
+    def check_capacity_end(self, token):
+        """Second half (host only): the stream must have been synchronised since check_capacity_begin."""
+        h = self._hdr_pin
+        P, n_cap = token
         overflow, n_max = int(h[1]), int(h[3])
         self.max_tile_len = int(h[2])
         self.max_group_records = max(getattr(self, "max_group_records", 0), int(h[8]))
-        self.img_state[4:16].zero_()
-        self.img_state[32:36].zero_()
-        self.ratio = max(self.ratio or 0.0, n_max / max(self.P, 1))
+        self.ratio = max(self.ratio or 0.0, n_max / max(P, 1))
         self.overflows = getattr(self, "overflows", 0) + (1 if overflow else 0)
-        self._checked_P, self._checked_cap = self.P, self.n_cap
+        self._checked_P, self._checked_cap = P, n_cap
         return not overflow
 
     def headroom(self):
@@ -330,11 +347,27 @@ class FusedMapper(Mapper):
         if not FusedEngine.eligible(self.cfg, self.gaussians):
             return super()._render_depth_sil(pose)
         eng = _engine(self.renderer)
+        if self._defer_render_check:
+            # keyframe test: its two counters are read back a moment later (covisibility_ratio_dense); the capacity header of this render
+            # rides on that read-back instead of draining the device a second time
+            eng.forward(pose.detach().float().contiguous(), self.gaussians)
+            self._pending_render_check = (eng.check_capacity_begin(), pose)
+            return eng.out[3], eng.out[4]
         for _ in range(4):
             eng.forward(pose.detach().float().contiguous(), self.gaussians)
             if eng.check_capacity():       # (the keyframe test synchronises on its result anyway)
                 return eng.out[3], eng.out[4]
         raise RuntimeError("mm3dgs: render kept overflowing its binning capacity")
+
+    _defer_render_check = False
+    _pending_render_check = None
+
+    def need_new_keyframe(self, idx, est_pose, gt_color, gt_depth=None, est_depth=None):
+        self._defer_render_check = hasattr(_engine(self.renderer), "check_capacity_begin") if FusedEngine.eligible(self.cfg, self.gaussians) else False
+        try:
+            return super().need_new_keyframe(idx, est_pose, gt_color, gt_depth, est_depth)
+        finally:
+            self._defer_render_check, self._pending_render_check = False, None
 
     def covisibility_ratio_dense(self, depth, sil, kf_pose, cur_pose):
         """The keyframe test's covisibility ratio (slam/mapper.py:141-216) as ONE kernel over the rendered depth / silhouette
@@ -349,6 +382,12 @@ class FusedMapper(Mapper):
         _lib.check(eng.lib.mm3dgs_covisibility_ratio(H, W, _p(depth), _p(sil), _p(kp), _p(cp), float(fx), float(fy), float(cx), float(cy),
                                                      _p(counts), _stream()))
         c = counts.cpu()                      # (the caller synchronises on the decision anyway)
+        pending, self._pending_render_check = self._pending_render_check, None
+        if pending is not None and not eng.check_capacity_end(pending[0]):
+            # the render these planes came from overflowed its binning capacity (now raised): render again, checked, and test that
+            self._defer_render_check = False
+            depth, sil = self._render_depth_sil(pending[1])
+            return self.covisibility_ratio_dense(depth, sil, kf_pose, cur_pose)
         return torch.tensor(float(c[0]) / max(float(c[1]), 1.0))
 
     def get_covisible_gaussians(self, keyframe_idx_list, curr_camera_tensor, min_kf=2):
@@ -613,15 +652,20 @@ class FusedMapper(Mapper):
                         nxt = _Views(view_of(pop()) for _ in range(run_length(iteration + 1)))
                         nxt.table = FusedEngine.view_table(nxt)
                         prepared = (iteration + 1, nxt)
-                    pruned = g.prune(m["min_opacity"], self.camera_extent, None if splatam else m["size_threshold"])
-                    if piggyback and hasattr(eng, "check_capacity"):
-                        # the pruning step has just synchronised on its 4-byte read-back: the capacity header (sticky: every forward
-                        # since the last read, the tracker's included) is read here for free
+                    # The capacity header (sticky: every forward since the last read, the tracker's included) rides on the pruning
+                    # step's read-back: its copy to pinned memory is enqueued before, parsed after -- no round trip of its own
+                    token = eng.check_capacity_begin() if (piggyback and hasattr(eng, "check_capacity_begin")) else None
+                    pruned = g.prune(m["min_opacity"], self.camera_extent, None if splatam else m["size_threshold"], lazy_mask=True)
+                    if token is not None:
+                        if not eng.check_capacity_end(token):
+                            self._late_overflow = True
+                        self._piggybacked = True
+                    elif piggyback and hasattr(eng, "check_capacity"):
                         if not eng.check_capacity():
                             self._late_overflow = True
                         self._piggybacked = True
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
-                        self._opt_mask = self._opt_mask[~pruned].contiguous()
+                        self._opt_mask = self._opt_mask[~pruned()].contiguous()
                 iteration += 1
 
     def _inline_adam(self, n=1):

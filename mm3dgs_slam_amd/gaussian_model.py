@@ -308,19 +308,21 @@ class GaussianModel:
         self.denom = torch.zeros((n, 1), device=dev)
         self.max_radii2D = torch.zeros((n,), device=dev)
 
-    def prune(self, min_opacity, extent, max_screen_size=None):
+    def prune(self, min_opacity, extent, max_screen_size=None, lazy_mask=False):
+        """Returns the mask of the pruned Gaussians; lazy_mask: a zero-argument callable that produces it (the native loop only needs it
+        under bundle adjustment, and an operator launched after the read-back delays the next run by its dispatch time)."""
         if self._native():
             # predicate, plan and compaction on the device (three small launches + a 4-byte read-back of the new size)
             keep = self.prune_mask_device(min_opacity, extent, max_screen_size)
             self.compact_device(keep)
-            return keep == 0
+            return (lambda: keep == 0) if lazy_mask else keep == 0
         mask = (self.get_opacity < min_opacity).squeeze(-1)
         big = self.get_scaling.max(dim=1).values > 0.1 * extent
         if max_screen_size is not None:
             big = torch.logical_or(big, self.max_radii2D > max_screen_size)
         mask = torch.logical_or(mask, big)
         self.prune_points(mask)
-        return mask
+        return (lambda: mask) if lazy_mask else mask
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1,

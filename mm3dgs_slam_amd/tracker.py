@@ -117,10 +117,14 @@ class Tracker:
         model = (self.dyn_model or "").lower()
         if model == "const_velocity":
             if idx - 2 >= 0:
-                # 7-float algebra: one device->host copy and host arithmetic instead of ~100 one-element device kernels
-                # (2.5 ms per frame on MI355X); run_frame moves the prediction back to the device
-                both = torch.stack([poses[idx - 1].detach(), poses[idx - 2].detach()]).cpu().numpy()
-                cam = torch.from_numpy(propagate_const_vel_np(both[0], both[1])).float()
+                if poses[idx - 1].is_cuda:
+                    # one single-lane launch (double precision): no pose on the host, so the frame's tracking loop is enqueued while
+                    # the GPU is still busy with the previous frame's mapping (the read-back drained the device once per frame)
+                    cam = self._predict_const_vel_device(poses[idx - 1], poses[idx - 2])
+                else:
+                    # 7-float algebra on the host instead of ~100 one-element torch kernels
+                    both = torch.stack([poses[idx - 1].detach(), poses[idx - 2].detach()]).cpu().numpy()
+                    cam = torch.from_numpy(propagate_const_vel_np(both[0], both[1])).float()
         elif model == "imu":
             assert imu_meas is not None, "IMU measurements must be provided"
             # 4x4 algebra over a handful of samples: on the host (one 7-float copy; ~100 one-element device kernels otherwise)
@@ -131,6 +135,17 @@ class Tracker:
         elif model:
             raise ValueError(f"Unknown dynamics model {self.dyn_model}")
         return cam
+
+    @staticmethod
+    def _predict_const_vel_device(pm1, pm2):
+        """mm3dgs_propagate_const_vel: utils/pose_utils.py:203-216 on the device (same algebra as propagate_const_vel_np, float64)."""
+        import ctypes as C
+        from . import _lib
+        from .rasterizer import _stream
+        a, b = pm1.detach().float().contiguous(), pm2.detach().float().contiguous()
+        out = torch.empty(7, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().mm3dgs_propagate_const_vel(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), _stream()))
+        return out
 
     def run_frame(self, idx, gt_color, gt_depth=None, est_depth=None, imu_meas=None):
         cam = self.predict_pose(idx, imu_meas).to(self.cfg["device"])

@@ -2,6 +2,7 @@
 torch-graph path built from the same (oracle-checked) generic rasterizer and the reference-mirroring torch losses."""
 import random
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -858,6 +859,29 @@ def test_covisible_gaussians_from_the_projection_stage_alone():
     assert a.dtype == torch.bool and a.shape == b.shape
     assert 1000 < int(b.sum()) < 20000
     assert int((a != b).sum()) <= 2          # (two float32 projection pipelines: a borderline radius may differ)
+
+
+def test_pose_prediction_kernel_matches_the_golden_pose_algebra():
+    """mm3dgs_propagate_const_vel (utils/pose_utils.py:203-216 on the device, one double-precision lane) against the reference's own
+    outputs (tests/golden/g1_pose.npz: propagate_const_vel on 32 pose pairs, generated by importing the reference) and against the float64 host
+    restatement the tracker used before (propagate_const_vel_np) on poses one tracking step apart, where it must agree to the last bit
+    of float32 almost everywhere (<= 1 ulp: both evaluate the same algebra in double)."""
+    from mm3dgs_slam_amd.pose_utils import propagate_const_vel_np
+    from mm3dgs_slam_amd.tracker import Tracker
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g1_pose.npz"))
+    poses = torch.from_numpy(d["poses"]).float()
+    got = torch.stack([Tracker._predict_const_vel_device(poses[i].to(DEV), poses[i + 1].to(DEV)) for i in range(32)]).cpu()
+    want = torch.from_numpy(d["const_vel"]).float()
+    # (q and -q are the same rotation: the golden vectors come from the reference's branch choice, the same one)
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), float((got - want).abs().max())      # (the bar of tests/test_golden_host.py)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(64):
+        a = torch.cat([torch.nn.functional.normalize(torch.randn(4, generator=gen), dim=0) * (1.0 + 0.01 * torch.randn(1, generator=gen)),
+                       torch.randn(3, generator=gen)])
+        b = a + torch.cat([0.004 * torch.randn(4, generator=gen), 0.01 * torch.randn(3, generator=gen)])
+        host = torch.from_numpy(propagate_const_vel_np(a.numpy(), b.numpy())).float()
+        dev = Tracker._predict_const_vel_device(a.to(DEV), b.to(DEV)).cpu()
+        assert float((host - dev).abs().max()) <= 2.4e-7 * max(1.0, float(host.abs().max())), (host, dev)
 
 
 def test_keyframe_covisibility_ratio_kernel_matches_the_torch_formulation():

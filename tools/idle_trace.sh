@@ -41,3 +41,34 @@ for k, (n, t) in sorted(ks.items(), key=lambda kv: -kv[1][1])[:22]:
     print(f"  {k:48s} n/frame {n/len(frames):7.1f}  avg {t/n/1e3:7.1f} us  total/frame {t/len(frames)/1e6:6.3f} ms")
 PY
 tail -2 /tmp/p_idle/bench.log
+# SEQ=1: the kernel sequence of one timed frame with the native loops collapsed (what the host does between them, and how long the GPU waits for it)
+if [ -n "$SEQ" ]; then python - <<'PY'
+import csv, glob
+f = glob.glob("/tmp/p_idle/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:70]) for r in csv.DictReader(open(f))))
+hot = ("composite", "slam_", "ssim_maps", "loss_finish", "sort_tiles")
+starts, last_track = [], -10**18
+for i, (s, e, k) in enumerate(rows):
+    if "fwd_bwd_track" in k:
+        if s - last_track > 2_000_000:
+            starts.append(i)
+        last_track = e
+a, b = starts[-4], starts[-3]
+t0 = rows[a][0]
+run, last_end = None, None
+for s, e, k in rows[a:b]:
+    gap = (s - last_end) / 1e3 if last_end else 0.0
+    if any(h in k for h in hot):
+        if run is None or gap > 5:
+            if run: print(f"   [{run[0]} hot kernels, {run[1]/1e3:.0f} us]")
+            run = [0, 0]
+            if gap > 5: print(f"  +{(s-t0)/1e3:9.1f} us  gap {gap:7.1f}  -> {k}")
+        run[0] += 1; run[1] += e - s
+    else:
+        if run: print(f"   [{run[0]} hot kernels, {run[1]/1e3:.0f} us]"); run = None
+        print(f"  +{(s-t0)/1e3:9.1f} us  gap {gap:7.1f}  {k}  ({(e-s)/1e3:.1f} us)")
+    last_end = e
+if run: print(f"   [{run[0]} hot kernels, {run[1]/1e3:.0f} us]")
+print(f"frame: {(rows[b][0]-t0)/1e6:.2f} ms")
+PY
+fi
