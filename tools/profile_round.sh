@@ -23,7 +23,7 @@ for r in csv.DictReader(open(f[0])):
 with open(f"{out}/slam_pmc_{c}.csv", "w") as fh:
     fh.write("kernel,launches,mean_counter_value\n")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-        if any(s in k for s in ("composite", "preprocess", "sort", "scatter", "scan", "ssim", "loss", "pose", "adam", "compact", "seed", "prune")):
+        if any(s in k for s in ("composite", "preprocess", "slam_", "sort", "scatter", "scan", "ssim", "loss", "pose", "adam", "compact", "seed", "prune", "covisibility", "propagate")):
             fh.write(f'"{k}",{len(v)},{sum(v)/len(v)}\n')
 print(open(f"{out}/slam_pmc_{c}.csv").read())
 PY
