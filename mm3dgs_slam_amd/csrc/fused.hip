@@ -253,13 +253,12 @@ struct PairCtx {           // what a lane needs to emit the pairs of ITS Gaussia
   MaskConsts mc; BlkRect br; uint32_t rec0; uint32_t khi, idbits; int minx, miny, w, area;   // rec0: first record (absolute)
   uint32_t trec0;            // per-tile record of the splat's first pair (absolute; pair k of the tile rectangle, row-major: trec0 + k); ~0u: none
 };
-__device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, uint32_t* hist, int gx, uint32_t cap, const BinView& b) {
-  const int ttx = c.minx + k % c.w, tty = c.miny + k / c.w;
+__device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, int ttx, int tty, uint32_t* hist, int gx, uint32_t cap, const BinView& b) {
   const int t = tty * gx + ttx;
   const uint32_t slot = atomicAdd(&hist[t], 1u);
   uint32_t mask = 0;
   if (slot < cap) {
-    mask = clip_mask_to_rect(tile_block_mask(c.mc, ttx, tty), ttx, tty, c.br);
+    mask = tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
     const uint32_t rec_local = c.rec0 + (uint32_t)((tty * 4 - c.br.by0) * c.br.bw + (ttx * 4 - c.br.bx0));
     const size_t at = (size_t)t * cap + slot;
     b.keys[at] = ((unsigned long long)c.khi << 32) | (unsigned long long)(c.idbits | slot);
@@ -337,7 +336,13 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   // went from 19 to 44 us over 100 frames of a run before).
   constexpr int OWN = 4;
   unsigned long long m64 = 0ull;
-  for (int k = 0; k < min(c.area, OWN); k++) m64 |= (unsigned long long)emit_pair(c, k, hist, cam.gx, cap, b) << (16 * k);
+  {   // (running tile coordinates: no division per pair)
+    int ttx = c.minx, tty = c.miny;
+    for (int k = 0; k < min(c.area, OWN); k++) {
+      m64 |= (unsigned long long)emit_pair(c, k, ttx, tty, hist, cam.gx, cap, b) << (16 * k);
+      if (++ttx == c.minx + c.w) { ttx = c.minx; tty++; }
+    }
+  }
   (void)m64;
   uint32_t incl = (uint32_t)max(c.area - OWN, 0);
 #pragma unroll
@@ -362,7 +367,8 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
       const int o = min(lo, 63);
       const uint32_t excl = o ? s_pref[wvi][o - 1] : 0u;
       const PairCtx oc = s_ctx[wvi][o];
-      emit_pair(oc, OWN + (int)(i - excl), hist, cam.gx, cap, b);
+      const int k = OWN + (int)(i - excl);
+      emit_pair(oc, k, oc.minx + k % oc.w, oc.miny + k / oc.w, hist, cam.gx, cap, b);
     }
   }
 }

@@ -234,7 +234,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       const uint32_t pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
       const BlkRect br = block_rect(A, B, r0, r1);
       const uint32_t rec0 = g.block_blk[id >> 8] + g.blkoff[id];
-      mask = clip_mask_to_rect(tile_block_mask(mask_consts(A, B), ttx, tty), ttx, tty, br);
+      mask = tile_block_mask_in_rect(mask_consts(A, B), ttx, tty, br);
       bw = (uint32_t)br.bw;
       // entry = {splat id, gradient record of (splat, block)}: row-major position of the block in the splat's rectangle
       recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
