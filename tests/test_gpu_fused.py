@@ -732,6 +732,39 @@ def test_binning_overflow_is_sticky_and_the_loops_recover(direct, monkeypatch):
     assert torch.equal(pa, pb) and torch.equal(xa, xb)
 
 
+def test_keyframe_test_with_deferred_capacity_check_recovers_from_an_overflowing_render():
+    """The keyframe test's render does not read its capacity header back on its own: the copy rides on the read-back of the covisibility
+    counters (FusedEngine.check_capacity_begin / _end).  If that render overflowed, covisibility_ratio_dense must notice, render again
+    with the raised capacity and return the ratio of the complete render -- the same number a healthy engine gives."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import _engine
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg2 = default_config(device=DEV, height=120, width=160, tracking={"iters": 4}, mapping={"iters": 4})
+    seq = SyntheticSequence(cfg2, 3, 8000, seed=2)
+    slam = SLAM(cfg2, seq)
+    slam.step(0); slam.step(1)
+    m, e = slam.mapper, _engine(slam.renderer)
+    kf_pose, cur_pose = m.keyframes[-1].pose, slam.estimate_pose_list[1]
+
+    def ratio():
+        m._defer_render_check = True
+        try:
+            with torch.no_grad():
+                depth, sil = m._render_depth_sil(kf_pose)
+                assert m._pending_render_check is not None          # (the check really was deferred)
+                return float(m.covisibility_ratio_dense(depth, sil, kf_pose, cur_pose))
+        finally:
+            m._defer_render_check, m._pending_render_check = False, None
+    healthy, before = ratio(), getattr(e, "overflows", 0)
+    assert 0.5 < healthy <= 1.0
+    e.MIN_PAIRS, e.ratio, e.n_cap, e.max_tile_len = 64, 0.02, 0, 1       # capacity model claims ~0 pairs per Gaussian -> tiny buffers
+    starved = ratio()
+    assert getattr(e, "overflows", 0) == before + 1
+    assert starved == healthy, (starved, healthy)
+    assert e.check_capacity()                                            # nothing left pending in the header
+
+
 @pytest.mark.parametrize("pearson", [False, True])
 def test_mapping_loss_via_forward_rows_matches_the_standalone_loss_kernels(pearson, monkeypatch):
     """Three forms of the mapping loss inside mm3dgs_slam_map, same per-pixel arithmetic, different launch structure:

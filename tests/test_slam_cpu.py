@@ -249,6 +249,68 @@ def test_native_mapper_restores_and_reruns_after_a_binning_overflow(monkeypatch)
     assert mp.mapping_iter_count == 20
 
 
+def test_native_mapper_with_ample_headroom_reads_the_header_only_at_pruning_steps(monkeypatch):
+    """Round 3: with ample headroom (FusedEngine.headroom() >= 1.5) the mapper takes no snapshot, reads the capacity header only where a
+    pruning step drains the device anyway (check_capacity_begin before the step's read-back, check_capacity_end after it) and skips the
+    end-of-loop read-back; an overflow reported there cannot be rolled back (no snapshot): it is counted and warned about."""
+    import warnings
+    import torch
+    from mm3dgs_slam_amd import fused
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.gaussian_model import GaussianModel
+
+    class FakeEngine:
+        H, W = 24, 32
+        dev = "cpu"
+        def __init__(self, overflow_at=None):
+            self.calls, self.grads, self.overflow_at, self.ends = [], {}, overflow_at, 0
+        def _ensure(self, P, need_grads):
+            pass
+        def headroom(self):
+            return 2.0
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+            self.calls.append(("map_loop", len(views)))
+        def check_capacity_begin(self):
+            self.calls.append(("begin",))
+            return ("token",)
+        def check_capacity_end(self, token):
+            assert token == ("token",)
+            self.calls.append(("end",))
+            self.ends += 1
+            return self.ends != self.overflow_at
+        def check_capacity(self):
+            self.calls.append(("check",))
+            return True
+
+    snaps = []
+    monkeypatch.setattr(GaussianModel, "snapshot", lambda self: snaps.append(1) or {})
+    for overflow_at in (None, 2):
+        cfg = default_config(device="cpu", height=24, width=32, mapping={"iters": 12, "densify_from_iter": 0, "densify_until_iter": 100, "pruning_interval": 5})
+        g = GaussianModel(cfg); g.training_setup()
+        n = 50
+        g.densification_postfix(torch.randn(n, 3), torch.randn(n, 1, 3), torch.zeros(n, 0, 3), torch.zeros(n, 1), torch.full((n, 3), -3.0),
+                                torch.tensor([[1.0, 0, 0, 0]]).repeat(n, 1), torch.rand(n, 3))
+        eng = FakeEngine(overflow_at)
+        monkeypatch.setattr(fused.FusedEngine, "eligible", staticmethod(lambda cfg, gaussians: True))
+        monkeypatch.setattr(fused, "_engine", lambda renderer: eng)
+        monkeypatch.setattr(GaussianModel, "_native", lambda self: False)
+        mp = fused.FusedMapper(cfg, g, renderer=None, estimate_pose_list=[None])
+        mp.camera_extent = 10.0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            mp.optimize_map(3, 12, [-1], None, torch.tensor([1.0, 0, 0, 0, 0, 0, 0]), torch.rand(3, 24, 32), torch.rand(24, 32), torch.rand(24, 32))
+        # iterations 0, 5, 10 prune: [gradient-only call, begin, (prune), end], runs of 4, 4 and 1 iterations between; no ("check",) at the end
+        want = [("map_loop", 1), ("begin",), ("end",), ("map_loop", 4), ("map_loop", 1), ("begin",), ("end",), ("map_loop", 4),
+                ("map_loop", 1), ("begin",), ("end",), ("map_loop", 1)]
+        assert eng.calls == want, eng.calls
+        assert not snaps
+        if overflow_at is None:
+            assert getattr(mp, "unrecovered_overflows", 0) == 0 and not w
+        else:
+            assert mp.unrecovered_overflows == 1 and any("overflowed" in str(x.message) for x in w)
+        assert mp.mapping_iter_count == 12
+
+
 def test_rel_pose_loss_safe_variant_is_finite_at_the_start_and_literal_elsewhere():
     import torch
     from mm3dgs_slam_amd.loss_utils import rel_pose_loss
