@@ -454,7 +454,7 @@ def main():
         "num_rendered_pairs": N,
     }
     # ---- roofline: the three compositing kernels of the timed region, each against the algorithmic bytes of SURVEY.md 8d with the
-    # measured N (HIP events recorded on the launch stream inside the library, every 16th launch); `roofline` is the one with the
+    # measured N (HIP events recorded on the launch stream inside the library, every 64th launch); `roofline` is the one with the
     # largest total time, the others follow in `roofline_other`
     T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     r_passes = -(-(32 + max(T_tiles - 1, 1).bit_length()) // 8)

@@ -313,7 +313,7 @@ int mm3dgs_propagate_const_vel(const float* pose_m1 /*[7], frame idx-1*/, const 
 #define MM3DGS_PROF_COMPOSITE_BWD_TRACK 8 /* the tracking-mode backward compositor of the fused SLAM path (COMPOSITE_BWD: every other form) */
 #define MM3DGS_PROF_TRACK_FWD_BWD 9 /* sort + forward + backward compositing of a tracking iteration in one launch */
 #define MM3DGS_PROF_KERNELS 10
-void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 16th launch of the forward (sort +) compositor and of the backward compositors only */
+void mm3dgs_profile_enable(int mode); /* 0 off, 1 every kernel, 2 every 64th launch of the forward (sort +) compositor and of the backward compositors only */
 int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 /* what the event pair adds to an interval it brackets (measured on empty kernels: 2 T(1 launch) - T(2 launches)); synchronises the stream */
 double mm3dgs_profile_event_overhead_ms(void* stream);

@@ -139,7 +139,7 @@ PROF_KERNELS = ("preprocess_fwd", "scan", "bin_sort", "composite_fwd", "composit
 
 
 def profile_enable(mode):
-    """0/False off, 1/True every kernel, 2 only the compositors (forward, backward mapping / generic, backward tracking), every 16th launch."""
+    """0/False off, 1/True every kernel, 2 only the compositors (forward, backward mapping / generic, backward tracking), every 64th launch."""
     load().mm3dgs_profile_enable(int(mode))
 
 

@@ -35,13 +35,13 @@ static std::mutex g_prof_mu;
 static int g_prof_on = 0;
 struct ProfScope {
   int k; hipStream_t s; hipEvent_t e1 = nullptr; bool on;
-  // g_prof_on: 0 off, 1 every kernel, 2 only the compositors (the roofline kernels) and only every 16th launch of
-  // it: an event pair around EVERY launch costs ~4 % of the SLAM frame rate (measured), a 1-in-16 sample nothing
+  // g_prof_on: 0 off, 1 every kernel, 2 only the compositors (the roofline kernels) and only every 64th launch of
+  // it: an event pair around EVERY launch costs ~4 % of the SLAM frame rate (measured), a 1-in-16 sample 0.7 % (measured, round 3), 1-in-64 0.2 %
   ProfScope(int k_, hipStream_t s_) : k(k_), s(s_), on(g_prof_on == 1 || (g_prof_on == 2 && (k_ == MM3DGS_PROF_COMPOSITE_BWD || k_ == MM3DGS_PROF_COMPOSITE_BWD_TRACK ||
                                                                                      k_ == MM3DGS_PROF_COMPOSITE_FWD || k_ == MM3DGS_PROF_TRACK_FWD_BWD))) {
     if (on && g_prof_on == 2) {
       static unsigned long long sample[MM3DGS_PROF_KERNELS] = {};
-      on = (sample[k_]++ & 15ull) == 0ull;
+      on = (sample[k_]++ & 63ull) == 0ull;
     }
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
