@@ -101,7 +101,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
 }
 
 const char* mm3dgs_last_error(void) { return g_err; }
-int mm3dgs_version(void) { return 201; }   // 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields
+int mm3dgs_version(void) { return 202; }   // 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
 
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
