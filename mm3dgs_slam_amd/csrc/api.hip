@@ -246,6 +246,15 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
   return d;
 }
 
+// The SLAM loops refresh image_state's load-balanced workgroup -> tile table (binning.hip) once per call, from the list lengths of the
+// last render; the compositors honour it while the header says it matches the grid (persistent state only: a per-call memset clears it).
+static bool slam_tile_table(int flags) { return (flags & MM3DGS_FWD_STATE_CLEAN) && !env_flag("MM3DGS_NO_TILE_ORDER", 0); }
+static void slam_refresh_tile_order(const Mm3dgsCamera* cam, void* image_state, int flags, void* stream) {
+  if (!cam || !image_state || !slam_tile_table(flags) || cam->image_height <= 0 || cam->image_width <= 0) return;
+  const CamDev cd = cam_dev(cam);
+  launch_tile_order(cd.gx * cd.gy, image_view(image_state, cd.H, cd.W), (hipStream_t)stream);
+}
+
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                              void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
                              const TrackLoss* tl, float* track_dsub = nullptr, bool projected = false) {
@@ -262,6 +271,7 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   cd.sort_single = (flags & MM3DGS_FWD_SHORT_LISTS) ? 1 : 0;
   cd.bg_extras = 1;
   cd.state_clean = (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0;
+  cd.tile_table = slam_tile_table(flags) ? 1 : 0;
   // persistent clean state + a tile grid that fits two LDS words per tile: fold the scan into the scatter workgroups
   cd.fused_scan = ((flags & MM3DGS_FWD_STATE_CLEAN) && P > 0 && cd.gx * cd.gy <= MAX_FUSED_SCAN_TILES && !env_flag("MM3DGS_NO_FUSED_SCAN", 0)) ? 1 : 0;
   // short lists (the SLAM regime): the per-tile sort runs inside the forward compositing launch
@@ -323,6 +333,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   BinView b = bin_view((void*)binning_state, N_capacity);
   BwdView bw = bwd_view(backward_scratch, P, N_capacity);
   cd.bg_extras = 1;
+  cd.tile_table = slam_tile_table(flags) ? 1 : 0;
   const DirectBins db_bwd = slam_direct_bins(flags, cd, P, N_capacity);
   cd.trec_cap = db_bwd.on ? db_bwd.trec_cap : 0u;
   SlamGrads sg = {};
@@ -450,6 +461,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   if (fuse_track) {
     track_dsub = bwd_view(backward_scratch, P, N_capacity).dsub;
   }
+  if (n_iter > 0) slam_refresh_tile_order(cam, image_state, fwd_flags, stream);
   for (int it = 0; it < n_iter; it++) {
     int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr, track_dsub);
     if (rc) return rc;
@@ -504,6 +516,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   // in-kernel Adam, neither view steps its pose); MM3DGS_NO_FUSED_PROJECT keeps the two launches apart (tests compare both, bit for bit)
   const int no_fuse_proj = env_flag("MM3DGS_NO_FUSED_PROJECT", 0);
   bool projected = false;
+  if (n_iter > 0) slam_refresh_tile_order(cam, image_state, fwd_flags, stream);
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
     if (loss_cfg->w_pearson != 0.f && !views[it].ref_depth_or_null) return fail(-2, "view %d: Pearson term needs a reference depth", it);

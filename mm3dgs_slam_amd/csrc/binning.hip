@@ -264,3 +264,60 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
     hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap, 0, cam.bg_extras);
   }
 }
+
+// ---- load-balanced workgroup -> tile table for the SLAM compositors ----------------------------------------------------------------
+// The compositors launch one 256-lane workgroup per tile, and a 640x480 grid (1200 tiles) fits the chip in ONE round: measured placement
+// (tools/ubench/placement.hip): workgroup b runs on XCD b % 8; inside an XCD the k-th of its workgroups goes to CU slot k % 32, so with
+// 150 workgroups per XCD 22 CUs hold five tiles and 10 hold four -- and the launch ends when the CUs with five are done (per-CU work
+// max / mean 1.19 on the benchmark scene, tools/list_balance.py).  This kernel keeps every XCD's contiguous span of tiles (its L2
+// locality) but deals the tiles of the span to the XCD's workgroup slots by load: the heaviest tiles to the CU slots that hold one tile
+// less, the rest serpentine over the others (max / mean ~1.04).  Load = the wave steps of the tile's last render (a wave's four rows
+// advance together: sum over the four 8x8 sub-tiles of the longest of their four block lists) -- from whatever view was rendered last;
+// the table is a permutation whatever the loads are, so a stale or meaningless load only costs speed.  One workgroup per XCD.
+#define ORDER_MAX_PER 160     // five rounds of 32 CU slots: beyond that the workgroups of a launch are placed dynamically
+__global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T) {
+  __shared__ uint32_t load[ORDER_MAX_PER];
+  const int per = (T + 7) >> 3, x = blockIdx.x, tid = threadIdx.x;
+  const int j = tid;                                   // tile x * per + j of this XCD's span (j >= n: no such tile, load 0)
+  uint32_t mine = 0;
+  const int tile = x * per + j;
+  if (j < per && tile < T) {
+    const uint4* sc = (const uint4*)(iv.subcount + (size_t)tile * NLIST);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint4 q = sc[w];
+      mine += max(max(q.x, q.y), max(q.z, q.w));
+    }
+    mine += 1u;                                        // (a real tile outranks the padding)
+  }
+  if (j < per) load[j] = mine;
+  __syncthreads();
+  if (j >= per) return;
+  int rank = 0;                                        // descending load, ties by index: a permutation of [0, per)
+  for (int k = 0; k < per; k++) {
+    const uint32_t o = load[k];
+    rank += (o > mine || (o == mine && k < j)) ? 1 : 0;
+  }
+  const int R = (per + 31) >> 5;                       // rounds; CU slots c < full hold R workgroups, the others R - 1
+  const int full = per - (R - 1) * 32, L = 32 - full, n_light = L * (R - 1);
+  int r, c;
+  if (rank < n_light) {                                // heaviest tiles: the slots with one workgroup less, serpentine over their R - 1 rounds
+    r = rank / L;
+    const int pos = rank - r * L;
+    c = full + ((r & 1) ? L - 1 - pos : pos);
+  } else {
+    const int q = rank - n_light;
+    r = q / full;
+    const int pos = q - r * full;
+    c = (r & 1) ? full - 1 - pos : pos;
+  }
+  const int i = r * 32 + c;                            // index of the workgroup inside the XCD: blockIdx = 8 i + x
+  iv.tile_order[(size_t)i * 8 + x] = tile < T ? (uint32_t)tile + 1u : 0u;
+  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = (uint32_t)T;
+}
+bool launch_tile_order(int T, ImageView iv, hipStream_t s) {
+  const int per = (T + 7) >> 3;
+  if (T < 64 || per > ORDER_MAX_PER) return false;     // (tiny grids: nothing to balance; big ones: several rounds of placement)
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, iv, T);
+  return true;
+}

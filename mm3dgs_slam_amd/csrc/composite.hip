@@ -187,7 +187,7 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   __shared__ double red[4][12];
   static_assert(sizeof(smem) >= 2048 * sizeof(unsigned long long), "LDS union too small for the key array");
   const int T = cam.gx * cam.gy;
-  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
   sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap, slot_bits, 1);
   if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
@@ -740,7 +740,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   constexpr size_t NEED = BWD_STG_BYTES > LOSS_BYTES ? BWD_STG_BYTES : LOSS_BYTES;
   __shared__ __align__(16) unsigned char smem_raw[NEED > MIN_BYTES ? NEED : MIN_BYTES];
   const int T = cam.gx * cam.gy;
-  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
   composite_bwd_body<C, MODE>(tile, cam, g, iv, b, N_cap, dL_dout, dsub, has_tl, tl, dl_planes, smem_raw);
 }
@@ -757,7 +757,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   __shared__ double red[4][12];
   static_assert(BWD_STG_BYTES >= sizeof(float4) * 2 * 4 * 3 * STG_N, "LDS union too small for the forward staging buffers");
   const int T = cam.gx * cam.gy;
-  const int tile = xcd_tile(blockIdx.x, T, cam.tilemap);
+  const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
   sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits, 1);
   __syncthreads();

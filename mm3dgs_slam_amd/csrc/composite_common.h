@@ -47,6 +47,17 @@ __device__ __forceinline__ int xcd_tile(int bid, int T, int mode) {
   return (bid & 7) * per + (bid >> 3);
 }
 
+// SLAM kernels over persistent state: the load-balanced workgroup -> tile table of binning.hip's tile_order_kernel when it is valid
+// for this grid (one scalar load; any permutation of the tiles is correct, only the speed depends on it)
+__device__ __forceinline__ int slam_tile(const CamDev& cam, const ImageView& iv, int bid, int T) {
+  int tile = xcd_tile(bid, T, cam.tilemap);
+  if (cam.tile_table && iv.hdr->tile_order_tiles == (uint32_t)T) {
+    const uint32_t o = iv.tile_order[bid];
+    tile = o ? (int)o - 1 : T;       // (0: a workgroup beyond the grid's tiles)
+  }
+  return tile;
+}
+
 // identical instruction sequence in forward and backward so both take the same skip decisions
 __device__ __forceinline__ float splat_power(float dx, float dy, float ca, float cb, float cc) {
   return fmaf(-0.5f, fmaf(ca * dx, dx, cc * dy * dy), -cb * dx * dy);

@@ -70,6 +70,7 @@ struct ImageView {
   uint32_t* subcount;    // [16T]
   float* final_T;        // [H*W]
   uint32_t* n_contrib;   // [H*W]
+  uint32_t* tile_order;  // [8 * ceil(T / 8)]: workgroup -> tile + 1 (valid while hdr->tile_order_tiles == T): binning.hip tile_order_kernel
   size_t zero_bytes;     // hdr + tile_count: cleared at the start of every forward
 };
 static inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
@@ -77,7 +78,7 @@ static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +
-         align_up(px * 4, 256) + align_up(px * 4, 256);
+         align_up(px * 4, 256) + align_up(px * 4, 256) + align_up(((T + 7) / 8) * 8 * 4, 256);
 }
 static inline ImageView image_view(void* base, int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
@@ -90,7 +91,8 @@ static inline ImageView image_view(void* base, int H, int W) {
   v.cursor = (uint32_t*)c;      c += align_up(T * 4, 256);
   v.subcount = (uint32_t*)c;    c += align_up(T * NLIST * 4, 256);
   v.final_T = (float*)c;        c += align_up(px * 4, 256);
-  v.n_contrib = (uint32_t*)c;
+  v.n_contrib = (uint32_t*)c;   c += align_up(px * 4, 256);
+  v.tile_order = (uint32_t*)c;
   return v;
 }
 
@@ -198,6 +200,7 @@ struct CamDev {
   float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
   int sh_degree;
   int tilemap;  // 0: tile = workgroup id; 1 (default): contiguous tile span per XCD
+  int tile_table; // SLAM entry points with persistent state: honour image_state's load-balanced workgroup -> tile table when it is valid
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
   int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
@@ -229,6 +232,7 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.sort_single = 0;
   d.bg_extras = 0;
   d.state_clean = 0;
+  d.tile_table = 0;
   d.trec_cap = 0;
   d.fused_scan = 0;
   d.bg = c->bg; d.view = c->viewmatrix; d.proj = c->projmatrix; d.campos = c->campos;
@@ -240,6 +244,7 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
                            const float* colors, const float* opac, const float* scales, const float* rots,
                            const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, int sticky = 0);
+bool launch_tile_order(int T, ImageView iv, hipStream_t s);   // load-balanced workgroup -> tile table of the SLAM compositors (binning.hip)
 void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
                          const int32_t* radii_or_null, hipStream_t s, bool scatter_only = false);
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,

@@ -732,6 +732,45 @@ def test_binning_overflow_is_sticky_and_the_loops_recover(direct, monkeypatch):
     assert torch.equal(pa, pb) and torch.equal(xa, xb)
 
 
+def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed(monkeypatch):
+    """The SLAM loops deal the tiles of every XCD's span to its workgroup slots by the list lengths of the last render (binning.hip
+    tile_order_kernel; MM3DGS_NO_TILE_ORDER=1 keeps the arithmetic workgroup -> tile map).  The table must be a permutation of the grid's
+    tiles (+ zeros for the workgroups beyond it), and three SLAM frames must end bit-identical with and without it -- every per-tile
+    result lands at an address that depends on the tile alone."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import _engine
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+
+    def run(flag, H, W):
+        monkeypatch.setenv("MM3DGS_NO_TILE_ORDER", flag)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = default_config(device=DEV, height=H, width=W, tracking={"iters": 5}, mapping={"iters": 12, "kf_every": 1, "pruning_interval": 5})
+        seq = SyntheticSequence(cfg, 3, 6000, seed=6)
+        slam = SLAM(cfg, seq)
+        for i in range(3):
+            slam.step(i)
+        g, e = slam.gaussians, _engine(slam.renderer)
+        torch.cuda.synchronize()
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        up = lambda v: (v + 255) // 256 * 256
+        off = 256 + up(T * 4) + up((T + 1) * 4) + up(T * 4) + up(T * 16 * 4) + 2 * up(H * W * 4)
+        n = (T + 7) // 8 * 8
+        table = e.img_state[off:off + 4 * n].view(torch.int32).cpu().numpy()
+        valid = int(e.img_state[36:40].view(torch.int32).cpu()[0])
+        state = dict(xyz=g._xyz.detach().clone(), op=g._opacity.detach().clone(), sc=g._scaling.detach().clone(), fdc=g._features_dc.detach().clone(),
+                     acc=g.xyz_gradient_accum.clone(), poses=torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:3]]))
+        return state, table, valid, T
+    for H, W in ((208, 320), (120, 170)):          # 260 tiles (33 per XCD: two rounds of CU slots) and 88 (below the 64-tile floor? no: 11 per XCD)
+        a, table, valid, T = run("0", H, W)
+        assert valid == T
+        assert sorted(int(v) for v in table if v) == list(range(1, T + 1)), "not a permutation of the tiles"
+        assert int((table == 0).sum()) == len(table) - T
+        b, _, valid_off, _ = run("1", H, W)
+        assert valid_off == 0                        # (fresh engine, never written)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (H, W, k)
+
+
 def test_keyframe_test_with_deferred_capacity_check_recovers_from_an_overflowing_render():
     """The keyframe test's render does not read its capacity header back on its own: the copy rides on the read-back of the covisibility
     counters (FusedEngine.check_capacity_begin / _end).  If that render overflowed, covisibility_ratio_dense must notice, render again

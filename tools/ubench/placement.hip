@@ -9,7 +9,7 @@
 #include <algorithm>
 
 __global__ void __launch_bounds__(256) probe(uint32_t* out, int spin) {
-  __shared__ float pad[26 * 256];
+  __shared__ float pad[30 * 256];      // 30 KB: five workgroups per CU, like the compositors (26 KB + their register budget)
   uint32_t hw, xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -49,7 +49,7 @@ int main() {
   // within XCC 0: index i = b / 8 of the workgroups of each CU
   int shown = 0;
   for (auto& kv : by_cu)
-    if (kv.first.first == 0 && shown++ < 12) {
+    if (kv.first.first == 0 && shown++ < 40) {
       printf("  XCC 0 cu %03x:", kv.first.second);
       for (int b : kv.second) printf(" %d", b / 8);
       printf("\n");
