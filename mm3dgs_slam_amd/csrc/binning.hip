@@ -286,7 +286,11 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T) {
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       const uint4 q = sc[w];
+#if defined(MM3DGS_ORDER_ROWSTEPS)                      // developer experiment (tools/build_variant.sh): load = row steps instead of wave steps
+      mine += q.x + q.y + q.z + q.w;
+#else
       mine += max(max(q.x, q.y), max(q.z, q.w));
+#endif
     }
     mine += 1u;                                        // (a real tile outranks the padding)
   }
@@ -299,7 +303,15 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T) {
     rank += (o > mine || (o == mine && k < j)) ? 1 : 0;
   }
   const int R = (per + 31) >> 5;                       // rounds; CU slots c < full hold R workgroups, the others R - 1
+#if defined(MM3DGS_ORDER_PLAIN)                          // developer experiment: plain serpentine over all 32 slots (ignores which slots hold one workgroup less)
+  const int full = 32, L = 0, n_light = 0;
+  if (rank >= per) return;
+#else
   const int full = per - (R - 1) * 32, L = 32 - full, n_light = L * (R - 1);
+#endif
+#if defined(MM3DGS_ORDER_REVERSED)                       // developer experiment: the LIGHTEST tiles to the slots with one workgroup less (should lose)
+  rank = per - 1 - rank;
+#endif
   int r, c;
   if (rank < n_light) {                                // heaviest tiles: the slots with one workgroup less, serpentine over their R - 1 rounds
     r = rank / L;
