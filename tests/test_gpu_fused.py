@@ -760,7 +760,9 @@ def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed
         state = dict(xyz=g._xyz.detach().clone(), op=g._opacity.detach().clone(), sc=g._scaling.detach().clone(), fdc=g._features_dc.detach().clone(),
                      acc=g.xyz_gradient_accum.clone(), poses=torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:3]]))
         return state, table, valid, T
-    for H, W in ((208, 320), (120, 170)):          # 260 tiles (33 per XCD: two rounds of CU slots) and 88 (below the 64-tile floor? no: 11 per XCD)
+    # 260 tiles (33 per XCD: two rounds of CU slots), 88 (11 per XCD: one round), the TUM grid (1200: 150 per XCD, five rounds) and the UTMM grid
+    # (840: 105 per XCD, four rounds)
+    for H, W in ((208, 320), (120, 170), (480, 640), (330, 640)):
         a, table, valid, T = run("0", H, W)
         assert valid == T
         assert sorted(int(v) for v in table if v) == list(range(1, T + 1)), "not a permutation of the tiles"
