@@ -54,7 +54,11 @@ typedef struct Mm3dgsHeader {
   uint32_t num_rendered; /* N = sum of tiles touched (the reference lineage's `num_rendered`) */
   uint32_t overflow;     /* 1 if N exceeded the binning capacity of a call (output then incomplete).  STICKY in the fused
                             SLAM path (persistent state, MM3DGS_FWD_STATE_CLEAN): set by any forward since the host last
-                            cleared it, so one read after a whole optimisation loop sees an overflow of ANY iteration */
+                            cleared it, so one read after a whole optimisation loop sees an overflow of ANY iteration.
+                            While it is set the SLAM backward entry points take NO optimiser step (map Adam, pose Adam), write
+                            zero gradients and leave the densification statistics alone: an overflowing forward dropped pairs
+                            without writing their gradient records, so its iteration -- and every later one of the loop, until
+                            the host clears the word -- is void rather than wrong */
   uint32_t max_tile_len; /* longest per-tile list (fused SLAM path: maximum since the host last cleared it) */
   uint32_t max_num_rendered; /* fused SLAM path: maximum N since the host last cleared it (capacity model) */
   /* diagnostics, only counted when the environment variable MM3DGS_STATS=1 (adds atomics; not for timing runs) */

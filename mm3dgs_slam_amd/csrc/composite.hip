@@ -344,8 +344,10 @@ struct SepReduce {
 //     afterwards pixel row y holds the column sums (over y) of two (one) of the values.
 //   X stage: up to three x-weighted copies per row ( 1 | dx | dx^2 ), full butterfly over the four lanes of the bank (quad_perm).
 // 27 (mapping) / 18 (tracking) instructions per (row, splat) step instead of 33 / 27.  The masked adds are inline assembly (the compiler's
-// DPP combiner does not form them); `s_nop 1` covers the VALU-write -> DPP-read hazard at the head of the block, inside it every
-// register is read at least two instructions after it was written.  Summation order differs from SepReduce in the last bit only.
+// DPP combiner does not form them); `s_nop 1` covers the VALU-write -> DPP-read hazard at the head of the block (2 wait states = TWO
+// instructions between the write and the DPP read); inside the mapping block every register is DPP-read at least three instructions
+// after its last write, the shorter tracking block needs one `s_nop 0` (r0 / r1 had only one instruction between).
+// Summation order differs from SepReduce in the last bit only.
 template <bool RGB>
 struct SepReduce2 {
   // record position of the value lane q ends up with (-1: nothing to store); layouts as SepReduce
@@ -397,6 +399,7 @@ struct SepReduce2 {
           "v_add_f32_dpp %1, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"     //            u dy
           "v_add_f32_dpp %0, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"      // rows 1, 3: u dy^2
           "v_add_f32_dpp %1, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"      //            cz
+          "s_nop 0\n\t"       // r0's second write is TWO instructions back only with this (a DPP read needs 2 wait states = 2 intervening instructions after a VALU write; the hazard recognizer does not see inside inline asm)
           "v_add_f32_dpp %2, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"      // rows 0, 1 keep r0: U | U2
           "v_add_f32_dpp %2, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"      // rows 2, 3 keep r1: U1 | cz
           : "=&v"(r0), "=&v"(r1), "=&v"(sy)

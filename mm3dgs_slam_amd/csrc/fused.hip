@@ -448,8 +448,13 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 template <bool TRACK, bool DIRECT>
 __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
                                               uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
-                                              const MapAdam& ma, RawGaussian* stepped) {
+                                              const MapAdam& ma, RawGaussian* stepped, const uint32_t* __restrict__ ovf) {
   const int idx = blockIdx.x * SLAM_BWD_FB + threadIdx.x;
+  // A forward that ran out of capacity (sticky header word, set by this iteration's binning / sort or by any earlier one of the loop)
+  // dropped pairs WITHOUT writing their per-tile records: the sums below would read stale scratch.  Such an iteration is void -- no
+  // gradient, no statistics, no optimiser step (zero gradients would still move the parameters by their momentum) -- so a loop whose
+  // header is only read at a later drained point (fused.py: lazy checks) leaves the map exactly as the last complete iteration left it.
+  const bool skip = ovf != nullptr && *ovf != 0u;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(in.pose);
@@ -474,14 +479,14 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
 #pragma unroll
       for (int k = 0; k < 4; k++) q_raw[k] = in.rotation[(size_t)idx * 4 + k];
       op_raw = in.opacity[idx];
-      rad = radii[idx];
+      rad = skip ? 0 : radii[idx];
       r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
       toff = g.tileoff[idx];
       if (!DIRECT) btile = g.block_tiles[idx >> 8];
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
       sA = spl[0]; sB = spl[1];
     }
-    if (r1 != r0) {   // <=> radii > 0
+    if (r1 != r0 && !skip) {   // <=> radii > 0
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       // first per-tile record of this Gaussian's pairs (contiguous, row-major over its tile rectangle): direct bins -- inside its
       // projection workgroup's span; packed bins -- its Gaussian-major pair index
@@ -637,6 +642,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       const float keepg = (ma.opt_mask && ma.opt_mask[idx] == 0) ? 0.f : 1.f;     // bundle adjustment: masked-out Gaussians get a zero gradient
       const float gr14[14] = {keepg * dxyz[0], keepg * dxyz[1], keepg * dxyz[2], keepg * dfd[0], keepg * dfd[1], keepg * dfd[2], keepg * dlogit,
                               keepg * dls[0], keepg * dls[1], keepg * dls[2], keepg * dqr[0], keepg * dqr[1], keepg * dqr[2], keepg * dqr[3]};
+      if (!skip) {
 #pragma unroll
       for (int gq = 0; gq < 5; gq++)
 #pragma unroll
@@ -650,6 +656,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
           ap[q] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
           ma.p[gq][off] = ap[q];
         }
+      }
       if (stepped) {      // AG layout: xyz 0-2 | f_dc 3-5 | opacity 6 | scaling 7-9 | rotation 10-13
 #pragma unroll
         for (int k = 0; k < 3; k++) { stepped->x[k] = ap[k]; stepped->fd[k] = ap[3 + k]; stepped->ls[k] = ap[7 + k]; }
@@ -681,8 +688,9 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
 template <bool TRACK, bool DIRECT>
 __global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma) {
-  slam_bwd_body<TRACK, DIRECT>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr);
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
+                           const uint32_t* __restrict__ ovf) {
+  slam_bwd_body<TRACK, DIRECT>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 // A mapping iteration's backward projection + Adam step and the NEXT iteration's projection + binning in one launch (direct bins, in-kernel
@@ -703,7 +711,7 @@ slam_bwd_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
   const int idx = blockIdx.x * FB + tid;
   RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
-  slam_bwd_body<false, true>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg);
+  slam_bwd_body<false, true>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg, &iv.hdr->overflow);
   const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g);
   slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
 }
@@ -722,7 +730,8 @@ void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t
 // R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
 // betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
 __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
-                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4) {
+                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4,
+                                        const uint32_t* __restrict__ ovf) {
   // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
   // added in a fixed order (deterministic, double precision)
   __shared__ double part[64][16];
@@ -857,7 +866,8 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       if (l4) l4[0] += ad.prior_w_t * t_l + ad.prior_w_q * ang;    // after the image terms were written (same stream)
     }
     if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
-    if (ad.pose) {
+    // (an iteration whose forward overflowed its capacity is void, see slam_bwd_body: the pose keeps its value AND its Adam state)
+    if (ad.pose && !(ovf != nullptr && *ovf != 0u)) {
       const int t = step0 + 1;
       *ad.step = t;
       // scalars in double, rounded once to float (torch.optim.Adam does this arithmetic on Python floats)
@@ -879,7 +889,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4, bool direct) {
+                                const PoseLossScale* pls, float* loss4, bool direct, const uint32_t* ovf) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
@@ -887,7 +897,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
     const bool map = out.d_xyz || ma.on;
     auto kern = map ? (direct ? slam_preprocess_bwd_kernel<false, true> : slam_preprocess_bwd_kernel<false, false>)
                     : (direct ? slam_preprocess_bwd_kernel<true, true> : slam_preprocess_bwd_kernel<true, false>);
-    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma);
+    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
   }
   if (want_pose)
   {
@@ -895,7 +905,7 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
     // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds
     //  twice as many float rows)
     hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? (P + SLAM_BWD_FB - 1) / SLAM_BWD_FB : 0, in.pose, dpose, ad,
-                       pls ? *pls : none, loss4);
+                       pls ? *pls : none, loss4, ovf);
   }
 }
 

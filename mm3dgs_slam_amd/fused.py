@@ -531,7 +531,9 @@ class FusedMapper(Mapper):
         # The snapshot (~24 device copies: every parameter, moment and statistic) is only taken when an overflow is conceivable: after
         # the map changed size (a keyframe seeded, a step pruned), on fresh buffers, or when the largest demand seen is within 1.5x
         # of a capacity (a frame's 150 Adam steps at the shipped learning rates cannot grow a tile list by that much).  Should a loop
-        # overflow without one, its iterations composited clamped tile lists (a few dropped (tile, splat) pairs): counted in
+        # overflow without one, the kernels void every iteration from the first overflowing forward on (the backward projection and
+        # the pose step read the sticky header word and skip gradients, statistics and optimiser steps: csrc/fused.hip slam_bwd_body),
+        # so the map stays as the last complete iteration left it -- the rest of the loop is lost, not corrupted: counted in
         # `unrecovered_overflows`, warned about, capacity raised for the next frame.
         eng._ensure(int(g._xyz.shape[0]), True)
         need_snap = self.always_snapshot or getattr(eng, "headroom", lambda: 0.0)() < 1.5 or (self.window is not None and self.window._collective)
@@ -552,8 +554,8 @@ class FusedMapper(Mapper):
             if snap is None:
                 import warnings
                 self.unrecovered_overflows = getattr(self, "unrecovered_overflows", 0) + 1
-                warnings.warn("mm3dgs: a mapping loop overflowed its binning capacity without a snapshot to restore (clamped tile lists "
-                              "in some of its iterations); capacity raised")
+                warnings.warn("mm3dgs: a mapping loop overflowed its binning capacity without a snapshot to restore (its iterations from the "
+                              "first overflowing forward on were skipped on the device: no optimiser step taken); capacity raised")
                 break
             self.loop_reruns = getattr(self, "loop_reruns", 0) + 1
             g.restore(snap)

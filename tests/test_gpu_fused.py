@@ -732,6 +732,84 @@ def test_binning_overflow_is_sticky_and_the_loops_recover(direct, monkeypatch):
     assert torch.equal(pa, pb) and torch.equal(xa, xb)
 
 
+@pytest.mark.parametrize("direct", [False, True])
+def test_an_overflowing_iteration_is_void_not_garbage(direct, monkeypatch):
+    """a forward that overflows drops pairs WITHOUT writing their per-tile gradient records; with the lazy capacity
+    checks nothing restores the map afterwards.  The backward entry points therefore read the sticky overflow word and take no
+    optimiser step at all while it is set (csrc/fused.hip slam_bwd_body, slam_pose_finish_kernel): parameters, Adam moments,
+    statistics and the tracked pose must come out of a starved loop bit-identical to what went in -- and move again once the word is
+    cleared and the capacity raised."""
+    from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
+    from mm3dgs_slam_amd import _lib
+    monkeypatch.setattr(FusedEngine, "DIRECT_BINS", direct)
+    cfg, g, R, pose, color, depth = _setup(P=12000, H=120, W=160, seed=9)
+    eng = FusedEngine(R)
+    eng.forward(pose, g, need_grads=True)
+    assert eng.check_capacity()
+    with torch.no_grad():
+        gt = eng.out[:3].clone().contiguous(); ref = eng.out[3].clone().contiguous()
+    opt = g.optimizer
+    names = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+
+    def adam(n):
+        ma = _lib.Mm3dgsMapAdam()
+        for i, name in enumerate(names):
+            group = next(gr for gr in opt.param_groups if gr["name"] == name)
+            p_ = group["params"][0]
+            st = opt.state[p_]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0); st["exp_avg"] = torch.zeros_like(p_); st["exp_avg_sq"] = torch.zeros_like(p_)
+            ma.param[i], ma.exp_avg[i], ma.exp_avg_sq[i] = p_.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            ma.lr[i] = float(group["lr"]) if float(group["lr"]) > 0 else 1e-3
+        ma.beta1, ma.beta2, ma.eps, ma.step = 0.9, 0.999, 1e-15, 1
+        return ma
+
+    def state():
+        out = [t.detach().clone() for t in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation, g.max_radii2D, g.xyz_gradient_accum, g.denom)]
+        for name in names:
+            st = opt.state[next(gr for gr in opt.param_groups if gr["name"] == name)["params"][0]]
+            out += [st["exp_avg"].clone(), st["exp_avg_sq"].clone()]
+        return out
+
+    lcfg = _loss_cfg(eng.H, eng.W, 0.8, 0.2, 0.05, 0, 2, 0, 0.5)
+    view = (pose + torch.tensor([0.0, 0.002, -0.001, 0.001, 0.01, -0.005, 0.004], device=DEV)).contiguous()
+    views = [(view, gt, ref)] * 4
+    stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom)
+    ma = adam(4)
+    before = state()
+    # starve the engine: tiny buffers -> every forward of the run overflows (flagged sticky), no host check in between
+    eng.MIN_PAIRS = 64
+    eng.ratio, eng.n_cap, eng.max_tile_len = 0.01, 0, 1
+    eng.map_loop(views, g, lcfg, stats, ma)
+    torch.cuda.synchronize()
+    assert int(eng.img_state[:8].view(torch.int32).cpu()[1]) == 1
+    for a, b in zip(before, state()):
+        assert torch.equal(a, b)
+    # tracking: the pose and its Adam state stay put as well
+    p0 = view.clone(); m_, v_ = torch.zeros(7, device=DEV), torch.zeros(7, device=DEV); step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ad = _lib.Mm3dgsPoseAdam()
+    ad.pose, ad.m, ad.v, ad.step = p0.data_ptr(), m_.data_ptr(), v_.data_ptr(), step.data_ptr()
+    ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = 0.003, 0.001, 0.9, 0.999, 1e-8
+    eng.track_loop(3, p0, g, _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.0, 1, 0, 1, 0.99), gt, None, ad)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, view) and int(step.cpu()[0]) == 0 and float(m_.abs().max()) == 0.0
+    # the host reads the header (clears the word, raises the capacity): the same calls now do their work
+    assert not eng.check_capacity()
+    for _ in range(4):      # (the capacity model may need more than one overflowing call to learn every one of its three limits)
+        eng.map_loop(views, g, lcfg, stats, ma)
+        torch.cuda.synchronize()
+        if eng.check_capacity():
+            break
+    else:
+        raise AssertionError("capacity never sufficed")
+    eng.track_loop(3, p0, g, _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.0, 1, 0, 1, 0.99), gt, None, ad)
+    torch.cuda.synchronize()
+    assert eng.check_capacity()
+    after = state()
+    assert not torch.equal(before[0], after[0]) and all(torch.isfinite(t).all() for t in after)
+    assert not torch.equal(p0, view) and int(step.cpu()[0]) == 3
+
+
 def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed(monkeypatch):
     """The SLAM loops deal the tiles of every XCD's span to its workgroup slots by the list lengths of the last render (binning.hip
     tile_order_kernel; MM3DGS_NO_TILE_ORDER=1 keeps the arithmetic workgroup -> tile map).  The table must be a permutation of the grid's
