@@ -122,7 +122,7 @@ def prewarm(dev, H, W, n_gaussians, frac):
                          mapping={"iters": 8, "kf_every": 2, "min_covisibility": 2.0, "densify_until_iter": 4, "pruning_interval": 2,
                                   "densification_interval": 2, "seed_fraction": frac})
     seq = SyntheticSequence(cfg, 6, n_gaussians, seed=1)
-    SLAM(cfg, seq).run()
+    SLAM(cfg, seq).run(reraise=True)
     torch.cuda.synchronize()
 
 

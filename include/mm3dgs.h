@@ -71,8 +71,8 @@ typedef struct Mm3dgsHeader {
   uint32_t max_group_records; /* direct bins: most gradient records of one projection workgroup (256 Gaussians) since the host
                                  last cleared it (sticky); every workgroup owns 16 * N_capacity / ceil(P / 256) records of the
                                  backward scratch, a workgroup that needs more sets `overflow` */
-  uint32_t tile_order_tiles;  /* 0: workgroup -> tile by arithmetic; T: image_state holds a load-balanced workgroup -> tile table for
-                                 this T-tile grid, written by the SLAM loop entry points from the list lengths of the last render
+  uint32_t tile_order_tiles;  /* 0: workgroup -> tile by arithmetic; H << 16 | W: image_state holds a load-balanced workgroup -> tile table
+                                 for an H x W image, written by the SLAM loop entry points from the list lengths of the last render
                                  (any permutation of the tiles renders the same image; only the speed depends on it) */
 } Mm3dgsHeader;
 

@@ -252,7 +252,7 @@ static bool slam_tile_table(int flags) { return (flags & MM3DGS_FWD_STATE_CLEAN)
 static void slam_refresh_tile_order(const Mm3dgsCamera* cam, void* image_state, int flags, void* stream) {
   if (!cam || !image_state || !slam_tile_table(flags) || cam->image_height <= 0 || cam->image_width <= 0) return;
   const CamDev cd = cam_dev(cam);
-  launch_tile_order(cd.gx * cd.gy, image_view(image_state, cd.H, cd.W), (hipStream_t)stream);
+  launch_tile_order(cd.gx * cd.gy, cd.H, cd.W, image_view(image_state, cd.H, cd.W), (hipStream_t)stream);
 }
 
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,

@@ -231,12 +231,12 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
 // ---- 4. per-tile sort (body in sort_tile.h) --------------------------------------------------------------------------
 template <int CAP, bool GLOBAL_TAIL>
 __global__ void __launch_bounds__(256)
-sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean, int tile_table) {
+sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean, int write_pair_index) {
   __shared__ unsigned long long sk[CAP];
   __shared__ SortShared sh;
   const int tile = blockIdx.x;
   if (tile >= T) return;
-  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, 0, 0, 0, DIRECT_SLOT_BITS_MAX, tile_table);
+  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, 0, 0, 0, DIRECT_SLOT_BITS_MAX, write_pair_index);
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)
@@ -275,7 +275,7 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
 // advance together: sum over the four 8x8 sub-tiles of the longest of their four block lists) -- from whatever view was rendered last;
 // the table is a permutation whatever the loads are, so a stale or meaningless load only costs speed.  One workgroup per XCD.
 #define ORDER_MAX_PER 160     // five rounds of 32 CU slots: beyond that the workgroups of a launch are placed dynamically
-__global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T) {
+__global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, uint32_t key) {
   __shared__ uint32_t load[ORDER_MAX_PER];
   const int per = (T + 7) >> 3, x = blockIdx.x, tid = threadIdx.x;
   const int j = tid;                                   // tile x * per + j of this XCD's span (j >= n: no such tile, load 0)
@@ -325,11 +325,11 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T) {
   }
   const int i = r * 32 + c;                            // index of the workgroup inside the XCD: blockIdx = 8 i + x
   iv.tile_order[(size_t)i * 8 + x] = tile < T ? (uint32_t)tile + 1u : 0u;
-  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = (uint32_t)T;
+  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
 }
-bool launch_tile_order(int T, ImageView iv, hipStream_t s) {
+bool launch_tile_order(int T, int H, int W, ImageView iv, hipStream_t s) {
   const int per = (T + 7) >> 3;
-  if (T < 64 || per > ORDER_MAX_PER) return false;     // (tiny grids: nothing to balance; big ones: several rounds of placement)
-  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, iv, T);
+  if (T < 64 || per > ORDER_MAX_PER || tile_order_key(H, W) == 0u) return false;     // (tiny grids: nothing to balance; big ones: several rounds of placement)
+  hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, iv, T, tile_order_key(H, W));
   return true;
 }

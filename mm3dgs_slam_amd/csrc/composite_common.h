@@ -51,7 +51,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int T, int mode) {
 // for this grid (one scalar load; any permutation of the tiles is correct, only the speed depends on it)
 __device__ __forceinline__ int slam_tile(const CamDev& cam, const ImageView& iv, int bid, int T) {
   int tile = xcd_tile(bid, T, cam.tilemap);
-  if (cam.tile_table && iv.hdr->tile_order_tiles == (uint32_t)T) {
+  if (cam.tile_table && iv.hdr->tile_order_tiles == tile_order_key(cam.H, cam.W)) {
     const uint32_t o = iv.tile_order[bid];
     tile = o ? (int)o - 1 : T;       // (0: a workgroup beyond the grid's tiles)
   }

@@ -96,6 +96,12 @@ static inline ImageView image_view(void* base, int H, int W) {
   return v;
 }
 
+// what Mm3dgsHeader.tile_order_tiles holds while image_state's workgroup -> tile table is valid: the image size it was built for (the
+// table sits behind final_T / n_contrib, so its offset depends on H * W, not on the tile count alone); 0 = no table
+static inline __host__ __device__ uint32_t tile_order_key(int H, int W) {
+  return (H > 0 && W > 0 && H < 65536 && W < 65536) ? (((uint32_t)H << 16) | (uint32_t)W) : 0u;
+}
+
 struct BinView {
   unsigned long long* keys;  // [N_cap]
   uint2* sublist;            // [16*N_cap]
@@ -244,7 +250,7 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
                            const float* colors, const float* opac, const float* scales, const float* rots,
                            const float* cov3d, int32_t* radii, GeomView g, ImageView iv, hipStream_t s);
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, int sticky = 0);
-bool launch_tile_order(int T, ImageView iv, hipStream_t s);   // load-balanced workgroup -> tile table of the SLAM compositors (binning.hip)
+bool launch_tile_order(int T, int H, int W, ImageView iv, hipStream_t s);   // load-balanced workgroup -> tile table of the SLAM compositors (binning.hip)
 void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, BinView b, size_t N_cap,
                          const int32_t* radii_or_null, hipStream_t s, bool scatter_only = false);
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap,

@@ -53,7 +53,7 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX, int tile_table = 0) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX, int write_pair_index = 0) {
   const uint32_t slot_mask = (1u << slot_bits) - 1u;
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
@@ -242,7 +242,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       else mask = 0;   // only on capacity overflow (flagged in the header)
       // the compositor's per-tile combine (SLAM modes) finds every pair of the bin by its position: mask, block-rectangle width, first
       // block record, and the pair's per-tile record = its Gaussian-major pair index
-      if (tile_table) {
+      if (write_pair_index) {   // (SLAM entry points)
         b.payload[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)min(bw, 0xffffu) << 16) | ((unsigned long long)recT << 32);
         b.trec[start + (uint32_t)i] = pidx < N_cap ? pidx : 0xffffffffu;
       }

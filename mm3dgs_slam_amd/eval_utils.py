@@ -30,6 +30,21 @@ def align_umeyama(model: np.ndarray, data: np.ndarray, known_scale: bool = False
     return s, R, t
 
 
+def align_horn(model: np.ndarray, data: np.ndarray):
+    """Closed-form rigid alignment of Horn (reference ``utils/eval_utils.py:193-228``): R, t with data ~ R model + t for 3 x n point
+    sets, and the per-point residual norms."""
+    mu_m, mu_d = model.mean(1, keepdims=True), data.mean(1, keepdims=True)
+    Wm = (model - mu_m) @ (data - mu_d).T                   # sum of outer(model_i, data_i)
+    U, _, Vh = np.linalg.svd(Wm.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vh) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vh
+    t = mu_d - R @ mu_m
+    err = R @ model + t - data
+    return R, t, np.sqrt((err * err).sum(0))
+
+
 def evaluate_ate_rmse(est_poses, gt_poses, method: str = "umeyama"):
     assert len(est_poses) == len(gt_poses), "Estimated trajectory and GT trajectory must have equal length"
     est = est_poses.detach().cpu().numpy() if isinstance(est_poses, torch.Tensor) else np.asarray(est_poses)
@@ -42,10 +57,13 @@ def evaluate_ate_rmse(est_poses, gt_poses, method: str = "umeyama"):
         aligned[:, :4] = q.numpy()
         aligned[:, 4:] = (s * (R @ est_traj.T) + t).T
         ate = np.linalg.norm(aligned[:, 4:] - gt_traj, axis=1)
-    elif method.lower() in ("none", "raw"):
+    elif method.lower() == "horn":       # rigid (no scale), utils/eval_utils.py:249-266
+        R, t, ate = align_horn(est_traj.T, gt_traj.T)
+        q = rotation2quad(torch.matmul(torch.tensor(R).float(), quad2rotation(torch.as_tensor(est[:, :4]).float()).float()))
+        aligned[:, :4] = q.numpy()
+        aligned[:, 4:] = (R @ est_traj.T + t).T
+    else:                                # (the reference's fall-through: no alignment)
         ate = np.linalg.norm(est_traj - gt_traj, axis=1)
-    else:
-        raise ValueError(f"unknown alignment {method!r} (umeyama | none)")
     rmse = float(np.sqrt(np.dot(ate, ate) / len(ate)))
     if isinstance(est_poses, torch.Tensor):
         aligned = torch.tensor(aligned)

@@ -195,10 +195,14 @@ class SLAM:
         self.mapper.run_frame(idx, color, depth, depth)
         self.gt_pose_list[idx] = gt_pose.detach().clone()
 
-    def run(self, progress=None):
+    def run(self, progress=None, reraise=False):
         """slam/SLAM.py:375-503: every frame; `save_iterations` checkpoints on the way; with an `outputdir` the final map (as
-        iteration <last_idx>) and results.npz at the end -- also when a frame raised, like the reference's try / finally."""
+        iteration <last_idx>) and results.npz at the end -- also when a frame raised: the reference catches the exception, prints it
+        ("SLAM failed. Saving map and results.") and goes on to its `finally` (slam/SLAM.py:494-503).  Same here; the exception is kept
+        in `self.failure`, and `reraise=True` raises it again AFTER the outputs were written (a failure while writing them never masks
+        it: it is printed and the original one is raised)."""
         last_idx = 0
+        self.failure = None
         try:
             for idx in range(len(self.seq)):
                 self.step(idx)
@@ -207,11 +211,22 @@ class SLAM:
                 if "outputdir" in self.cfg and idx in self.cfg.get("save_iterations", ()):
                     self.save_map(idx)
                 last_idx += 1
+        except Exception as e:      # noqa: BLE001 -- the reference's behaviour
+            self.failure = e
+            print(e)
+            print("\nSLAM failed. Saving map and results.\n")
         finally:
             if "outputdir" in self.cfg and last_idx > 0:
-                with torch.no_grad():
-                    self.save_map(last_idx)
-                    self.save_results(last_idx)
+                try:
+                    with torch.no_grad():
+                        self.save_map(last_idx)
+                        self.save_results(last_idx)
+                except Exception as e2:      # noqa: BLE001
+                    if self.failure is None:
+                        raise
+                    print(f"(while saving after the failure above: {e2!r})")
+        if self.failure is not None and reraise:
+            raise self.failure
 
     # ---- outputs in the reference's formats ------------------------------------------------------------------------------------
     def save_map(self, iteration):

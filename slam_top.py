@@ -15,6 +15,7 @@ from that checkpoint (map, poses, keyframes, covisibility graph), like the refer
 """
 import argparse
 import os
+import sys
 import random
 import time
 
@@ -71,6 +72,8 @@ def main():
     slam.run(progress)          # checkpoints, the final map and results.npz are written inside (reference formats)
     res = np.load(os.path.join(outdir, "results.npz"), allow_pickle=True)
     print(f"Average Trajectory Error RMSE: {float(res['ate_rmse'])} m; {1.0 / np.mean(times[1:]):.2f} frames/s after frame 0; outputs in {outdir}")
+    if slam.failure is not None:      # (the reference prints the exception and saves what it has, slam/SLAM.py:494-503; the exit code says so too)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,13 @@ def main():
             aligned, rmse = evaluate_ate_rmse(est, gt, method="umeyama")
             out[f"ate{k}_est"], out[f"ate{k}_gt"] = est.numpy(), gt.numpy()
             out[f"ate{k}_aligned"], out[f"ate{k}_rmse"] = np.asarray(aligned), np.float64(rmse)
+            # the rigid alignment of Horn (utils/eval_utils.py:193-228,249-266).  `align` calls `numpy.linalg.linalg.svd`, an alias that numpy 2
+            # no longer has: bound back to numpy.linalg for the call (the arithmetic is the reference's own)
+            import numpy.linalg as _la
+            if not hasattr(_la, "linalg"):
+                _la.linalg = _la
+            aligned_h, rmse_h = evaluate_ate_rmse(est, gt, method="horn")
+            out[f"ate{k}_horn_aligned"], out[f"ate{k}_horn_rmse"] = np.asarray(aligned_h), np.float64(rmse_h)
         # save_results on a stand-in self
         est, gt = trajectories(7, 9)
         last_idx = 7                                     # the reference truncates both pose lists to the frames processed

@@ -197,6 +197,18 @@ def test_g10_ate_rmse_matches_the_reference_umeyama_alignment():
         assert np.allclose(np.abs((a[:, :4] * b[:, :4]).sum(1)), 1.0, atol=1e-5)
 
 
+def test_g10_ate_rmse_matches_the_reference_horn_alignment():
+    """method="horn" (utils/eval_utils.py:193-228,249-266): rigid alignment, no scale -- on the same three trajectories."""
+    from mm3dgs_slam_amd.eval_utils import evaluate_ate_rmse
+    F = np.load(os.path.join(HERE, "golden", "g10_results.npz"))
+    for k in range(3):
+        aligned, rmse = evaluate_ate_rmse(torch.from_numpy(F[f"ate{k}_est"]), torch.from_numpy(F[f"ate{k}_gt"]), method="horn")
+        assert abs(rmse - float(F[f"ate{k}_horn_rmse"])) < 1e-6 * max(1.0, float(F[f"ate{k}_horn_rmse"])), (k, rmse, F[f"ate{k}_horn_rmse"])
+        a, b = np.asarray(aligned), F[f"ate{k}_horn_aligned"]
+        assert np.allclose(a[:, 4:], b[:, 4:], atol=1e-5)
+        assert np.allclose(np.abs((a[:, :4] * b[:, :4]).sum(1)), 1.0, atol=1e-5)
+
+
 def test_g10_save_results_writes_the_reference_key_set_and_values(tmp_path):
     """This repository's SLAM.save_results on the state the reference's own save_results was run on: same keys in the same order,
     same shapes / dtypes / values, keyframe dicts that slam/mapper.py:65-71 could read back (KeyFrame(**kf))."""

@@ -842,7 +842,7 @@ def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed
     # (840: 105 per XCD, four rounds)
     for H, W in ((208, 320), (120, 170), (480, 640), (330, 640)):
         a, table, valid, T = run("0", H, W)
-        assert valid == T
+        assert valid == (H << 16 | W)
         assert sorted(int(v) for v in table if v) == list(range(1, T + 1)), "not a permutation of the tiles"
         assert int((table == 0).sum()) == len(table) - T
         b, _, valid_off, _ = run("1", H, W)
