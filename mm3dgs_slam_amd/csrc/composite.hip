@@ -559,6 +559,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   if (MODE != 0 && !SEP_REDUCE2) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
   // this lane's component of record 0; the list entries carry the record index of their (splat, block)
   float* const my_rec = dsub + (my_slot >= 0 ? my_slot : 0);
+  const uint32_t my_slot_bytes = (uint32_t)(my_slot >= 0 ? my_slot : 0) * 4u;
+  (void)my_slot_bytes;
   uint32_t n_visit = 0, n_red = 0;
 
   // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
@@ -649,7 +651,21 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
+#ifdef MM3DGS_REC_OFF32
+      // (variant: 32-bit byte offset = two shift-adds + an SGPR base instead of v_mad_u64_u32; needs 16 N_cap RECF 4 < 2^32)
+      if (my_slot >= 0 && row_on && !(cam.exp & 1)) {
+        // (inline asm: left to the compiler, the shift-adds are folded back into a v_mad_u64_u32)
+        uint32_t off;
+        if constexpr (RECF == 10) {       // 5 ti, then 40 ti + 4 slot
+          asm("v_lshl_add_u32 %0, %1, 2, %1\n\tv_lshl_add_u32 %0, %0, 3, %2" : "=&v"(off) : "v"(ti), "v"(my_slot_bytes));
+        } else if constexpr (RECF == 7) { // 8 ti - ti, then 28 ti + 4 slot
+          asm("v_lshlrev_b32 %0, 3, %1\n\tv_sub_u32 %0, %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(off) : "v"(ti), "v"(my_slot_bytes));
+        } else off = ti * (uint32_t)(RECF * 4) + my_slot_bytes;
+        *(float*)((char*)dsub + off) = tot;
+      }
+#else
       if (my_slot >= 0 && row_on && !(cam.exp & 1)) my_rec[(size_t)ti * RECF] = tot;
+#endif
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
@@ -786,6 +802,9 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
   static const int pad = env_flag("MM3DGS_BWD_LDS_PAD", 0);
   hipLaunchKernelGGL((composite_bwd_kernel<C, 0>), dim3(grid), dim3(256), (size_t)pad, s, cam, g, iv, b, ncap, dL, dsub, 0, none, C);
 }
+// MM3DGS_SLAM_LDS_PAD (developer experiment): bytes of never-touched dynamic LDS added to the SLAM compositor launches -- it only lowers
+// how many workgroups share a CU (occupancy sensitivity of the kernels; results are unaffected)
+static size_t slam_lds_pad() { static const int pad = env_flag("MM3DGS_SLAM_LDS_PAD", 0); return (size_t)pad; }
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
@@ -793,9 +812,9 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
   if (tracking)
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
   else
-    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 1>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
 }
 
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
@@ -804,7 +823,7 @@ void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, Bin
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
   TrackLoss none = {};
-  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks, direct_cap, slot_bits);
+  hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks, direct_cap, slot_bits);
 }
 
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
@@ -812,7 +831,7 @@ void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageVie
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), 0, s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
+  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
 }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,

@@ -69,18 +69,55 @@ def trajectory_moving(n, step_t=0.014, step_r=0.014):
     return out
 
 
+def trajectory_desk(n, step_t=0.014, step_r_deg=0.8):
+    """A hand-held sweep at TUM fr1/desk's pace (the bench's `moving` line since round 4): the camera pans back and forth over the scene --
+    yaw +-10 degrees at up to `step_r_deg` per frame (0.8), pitch +-4 degrees at up to 0.4 per frame -- while it translates sideways
+    +-0.25 m at up to `step_t` m per frame (1.4 cm) and bobs a few centimetres.  At that pace the view shares less than
+    `mapping.min_covisibility` (0.95) of the last keyframe within two or three frames, so `mapping.kf_every: 5` is what spaces the
+    keyframes (slam/mapper.py:141-173, configs/TUM.yml:45-50) except at the turning points of the sweep.  The sequence needs a scene
+    wider than the first view: SyntheticSequence(motion="desk") seeds its ground-truth map from a 1.8x wider / taller virtual frame.
+    Returns n 4x4 world->camera matrices."""
+    out = []
+    ay, ap, ax = math.radians(10.0), math.radians(4.0), 0.25
+    wy, wp, wx = math.radians(step_r_deg) / ay, math.radians(0.5 * step_r_deg) / ap, step_t / ax
+    for i in range(n):
+        yaw = ay * math.sin(wy * i)
+        pitch = ap * math.sin(wp * i + 0.5)
+        roll = math.radians(1.5) * math.sin(0.11 * i + 0.4)
+        x = ax * math.sin(wx * i)
+        y = 0.04 * math.sin(0.6 * wx * i + 0.7)
+        z = 0.05 * (1.0 - math.cos(0.5 * wx * i))
+        cy_, sy_, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+        Ry = torch.tensor([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = torch.tensor([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = torch.tensor([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        c2w = torch.eye(4)
+        c2w[:3, :3] = (Ry @ Rx @ Rz).float()
+        c2w[:3, 3] = torch.tensor([x, y, z])
+        out.append(torch.linalg.inv(c2w))
+    return out
+
+
 class SyntheticSequence:
     """RGB-D frames rendered from a fixed ground-truth Gaussian map along ``trajectory`` (built once, untimed).
-    The ground-truth map is the seeded first frame of ``synthetic.rgbd_frame``."""
+    The ground-truth map is the seeded first frame of ``synthetic.rgbd_frame`` -- for ``motion="desk"`` a 1.8x wider and taller
+    virtual first frame with the same focal length (the sweep looks past the edges of the first view), seeded at the same density."""
 
     def __init__(self, cfg, n_frames, n_gaussians, seed=0, renderer=None, motion="bounded"):
         dev = cfg["device"]
         H, W = int(cfg["desired_height"]), int(cfg["desired_width"])
         c = cfg["cam"]
-        color, depth = synthetic.rgbd_frame(H, W, seed=seed)
-        G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], n_gaussians, seed=seed)
+        if motion == "desk":
+            Hg, Wg = int(round(1.8 * H)), int(round(1.8 * W))
+            color, depth = synthetic.rgbd_frame(Hg, Wg, seed=seed, n_boxes=14)
+            G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"] + 0.5 * (Wg - W), c["cy"] + 0.5 * (Hg - H),
+                                         int(n_gaussians * (Hg * Wg) / (H * W)), seed=seed)
+        else:
+            color, depth = synthetic.rgbd_frame(H, W, seed=seed)
+            G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], n_gaussians, seed=seed)
         self.seed_params = {k: v.to(dev) for k, v in G.items()}
-        self.poses = [get_tensor_from_camera(M).to(dev) for M in (trajectory_moving if motion == "moving" else trajectory)(n_frames)]
+        traj = {"moving": trajectory_moving, "desk": trajectory_desk}.get(motion, trajectory)
+        self.poses = [get_tensor_from_camera(M).to(dev) for M in traj(n_frames)]
         self.frames = []
         renderer = renderer or Renderer(cfg)
         gt = _FixedMap(self.seed_params, cfg, opaque=True)

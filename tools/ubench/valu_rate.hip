@@ -20,6 +20,12 @@ __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed
   if (threadIdx.x < 256) lds[threadIdx.x] = make_float4(seed, seed, seed, seed);
   __syncthreads();
   float4 acc4 = make_float4(0, 0, 0, 0);
+  unsigned long long q[8];
+  unsigned u[8];
+  for (int i = 0; i < 8; i++) { q[i] = threadIdx.x + i; u[i] = threadIdx.x * 3 + i; }
+  const unsigned iseed = (unsigned)(seed * 1000.f) + threadIdx.x, iseed2 = 40u;
+  const unsigned lane_addr4 = (threadIdx.x & 63) * 4u, row_addr4 = (threadIdx.x & 15) * 4u, perm_addr = ((threadIdx.x ^ 4) & 63) * 4u;
+  const unsigned rec_addr4 = ((threadIdx.x >> 4) & 3) * 40u + (threadIdx.x & 15) * 4u;
   unsigned lane_addr = (threadIdx.x & 63) * 16u, bc_addr = (threadIdx.x >> 6) * 16u;
   long long t0 = clock64();
   for (int it = 0; it < REP; it++) {
@@ -89,6 +95,43 @@ __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed
 #define S(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pseed));
       OP32(S)
 #undef S
+    } else if (KIND == 17) {  // 32 x 32 -> 64-bit multiply-add (the compositor's record address)
+#define S(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(iseed), "v"(iseed2) : "vcc");
+      OP32(S)
+#undef S
+    } else if (KIND == 18) {
+#define S(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(u[i]) : "v"(iseed));
+      OP32(S)
+#undef S
+    } else if (KIND == 19) {
+#define S(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(iseed));
+      OP32(S)
+#undef S
+    } else if (KIND == 20) {  // LDS float atomic add, no return, every lane its own address
+#define S(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*256" : : "v"(lane_addr4), "v"(seed) : "memory");
+      OP32(S)
+#undef S
+      asm volatile("s_waitcnt lgkmcnt(0)");
+    } else if (KIND == 21) {  // LDS float atomic add, the four 16-lane rows hit the SAME sixteen addresses
+#define S(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*256" : : "v"(row_addr4), "v"(seed) : "memory");
+      OP32(S)
+#undef S
+      asm volatile("s_waitcnt lgkmcnt(0)");
+    } else if (KIND == 22) {
+#define S(i) asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(r[i]) : "v"(perm_addr));
+      OP32(S)
+#undef S
+    } else if (KIND == 23) {
+#define S(i) asm volatile("s_nop 1\n v_permlane16_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[(i + 1) & 7]));
+      OP32(S)
+#undef S
+    } else if (KIND == 24) {  // LDS float atomic add, 10 of every 16 lanes active (a gradient record), rows on different records
+      if ((threadIdx.x & 15) < 10) {
+#define S(i) asm volatile("ds_add_f32 %0, %1 offset:" #i "*256" : : "v"(rec_addr4), "v"(seed) : "memory");
+      OP32(S)
+#undef S
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)");
     } else if (KIND == 13) {  // cndmask with an SGPR-pair mask (VOP3)
       unsigned long long m = 0x5555555555555555ull;
 #define S(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(seed), "s"(m));
@@ -98,7 +141,7 @@ __global__ void __launch_bounds__(1024) k(float* out, long long* cyc, float seed
   }
   long long t1 = clock64();
   float s = acc4.x + acc4.y;
-  for (int i = 0; i < 8; i++) s += r[i] + p[i].x + p[i].y;
+  for (int i = 0; i < 8; i++) s += r[i] + p[i].x + p[i].y + (float)q[i] + (float)u[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -136,6 +179,14 @@ int main() {
   run<9>("ds_read_b128 broadcast", out, cyc);
   run<10>("ds_read_b128 per-lane", out, cyc);
   run<11>("fma -> dependent dpp (pairs)", out, cyc);
+  run<17>("v_mad_u64_u32", out, cyc);
+  run<18>("v_lshl_add_u32", out, cyc);
+  run<19>("v_mul_lo_u32", out, cyc);
+  run<20>("ds_add_f32 distinct addresses", out, cyc);
+  run<21>("ds_add_f32 4 rows same addresses", out, cyc);
+  run<24>("ds_add_f32 10/16 lanes, 4 records", out, cyc);
+  run<22>("ds_bpermute + wait", out, cyc);
+  run<23>("s_nop1 + v_permlane16_swap", out, cyc);
   run<14>("v_pk_fma_f32", out, cyc);
   run<15>("v_pk_mul_f32", out, cyc);
   run<16>("v_pk_add_f32", out, cyc);
