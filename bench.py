@@ -63,8 +63,8 @@ def parse():
                     help="slam, 1 GPU: a second run with the reference-faithful seeding (one Gaussian per valid frame-0 pixel, ~292 k), "
                          "this many timed frames, reported as `full_seed` (0 = skip)")
     ap.add_argument("--moving-frames", type=int, default=60,
-                    help="slam, 1 GPU: a further run on a camera that keeps moving (cumulative ~1 cm / 0.45 deg per frame, peaks 1.4 cm / 0.65 deg: a keyframe "
-                         "every few frames, seeding, a growing map, a filling window), this many timed frames, reported as `moving` (0 = skip)")
+                    help="slam, 1 GPU: a further run on a hand-held sweep at TUM fr1/desk's pace (up to 1.4 cm / 0.8 deg per frame: a keyframe every 5 frames, "
+                         "seeding, a growing map, a filling window), this many timed frames, reported as `moving` (0 = skip)")
     ap.add_argument("--window-batch", type=int, default=1, help="views per rank and optimiser step in the mapping window (SURVEY 8e)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
@@ -168,16 +168,18 @@ def cpu_baseline(args):
             "sec_per_iteration": sec}
 
 
-def pmc_traffic(match):
-    """HBM bytes per launch of the kernel whose name contains every string in `match`, from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_*.csv, produced by tools/profile_round.sh over this same bench command: FETCH_SIZE and WRITE_SIZE in separate
-    passes, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950).  None when no such summary
-    is committed."""
+def pmc_traffic(match, workload="slam"):
+    """Fabric bytes per launch (L2 misses + write-backs: FETCH_SIZE / WRITE_SIZE count the requests the XCD L2s send to the Infinity
+    Fabric, Infinity-Cache hits included -- MI355X_MICROARCH.md, section HBM) of the kernel whose name contains every string in `match`,
+    from the committed rocprofv3 PMC passes OF THIS WORKLOAD (profiles/*_<workload>_pmc_*.csv, produced by tools/profile_round.sh over
+    the same bench command: FETCH_SIZE and WRITE_SIZE in separate passes, KB units, FETCH_SIZE doubled as the guide prescribes for
+    16-B/lane reads on gfx950).  None when no summary of this workload is committed (round 3 replayed the configs[1] counters into
+    the c3 / c4 lines)."""
     import csv
     import glob
     vals, used = {}, []
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_slam_pmc_{c}.csv")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_{c}.csv")))
         if not files:
             return None, None
         rows = [r for r in csv.DictReader(open(files[-1])) if all(m in r["kernel"] for m in match)]
@@ -288,12 +290,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def finish(out):
+    def finish(out, failures=()):
         if rank == 0:
             print(json.dumps(out))
         if collective:
             dist.barrier()
             dist.destroy_process_group()
+        if failures:           # a multi-GPU line whose self-check failed must not look like a measurement
+            log("MULTI-GPU SELF-CHECK FAILED: " + "; ".join(failures))
+            sys.exit(3)
+
+    def rank_failures(info):
+        """What makes an N-rank line invalid: a process group of another size than --gpus, an all-reduce that does not sum over all
+        ranks, replicas that drifted apart."""
+        bad = []
+        if info is None:
+            return bad
+        if info["ranks_seen"] != args.gpus:
+            bad.append(f"process group has {info['ranks_seen']} ranks, --gpus {args.gpus}")
+        if abs(info["allreduce_checksum"] - info["allreduce_expected"]) > 1e-9:
+            bad.append(f"all-reduce of rank + 1 gave {info['allreduce_checksum']}, expected {info['allreduce_expected']}")
+        if info.get("replicas_identical") is False:
+            bad.append("the replicas do not hold identical maps")
+        return bad
 
     def verify_ranks(slam_=None):
         """Self-check of the multi-GPU run for the line's reader: how many ranks the process group really has, an all-reduce whose
@@ -332,6 +351,7 @@ def main():
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        c5_check = verify_ranks()
         ev_us = float(_lib.load().mm3dgs_profile_event_overhead_ms(None)) * 1e3      # the bracketing event pair's own share of an interval
         kus = {k: max(v[1] / v[0] * 1e3 - ev_us, 0.0) for k, v in prof.items() if v[0]}
         gpu_s = sum(kus.values()) * 1e-6
@@ -340,7 +360,7 @@ def main():
                "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": info["workload"], "gaussians": info["P"], "image": [H, W],
-                          "multi_gpu": {"description": "independent views of the same map, one per rank; no data-path collective", **(verify_ranks() or {})} if collective else "single GPU"},
+                          "multi_gpu": {"description": "independent views of the same map, one per rank; no data-path collective", **(c5_check or {})} if collective else "single GPU"},
                "kernel_us": kus, "event_overhead_us": ev_us,
                "roofline": {"bound": "hbm", "kernel": "whole forward + backward pass (sum of its kernels)",
                             "achieved": (info["alg_fwd"] + info["alg_bwd"]) / gpu_s / 1e9 if gpu_s else None, "peak": 8000.0, "unit": "GB/s",
@@ -348,7 +368,12 @@ def main():
                             "algorithmic_bytes_fwd": info["alg_fwd"], "algorithmic_bytes_bwd": info["alg_bwd"],
                             "note": "algorithmic bytes per SURVEY.md 8d (forward incl. the contract's 6-pass global radix sort term) with the measured "
                                     "Pv and N; duration = sum of the HIP-event kernel times of one pass"}}
-        finish(out)
+        out["roofline"]["traffic"], src = pmc_traffic(("",), "c5_pass")
+        if out["roofline"]["traffic"]:
+            out["roofline"]["traffic_source"] = src
+            out["roofline"]["traffic_kind"] = "L2-miss (fabric) bytes of the whole pass: HBM + Infinity-Cache hits"
+            out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / (info["alg_fwd"] + info["alg_bwd"])
+        finish(out, rank_failures(c5_check))
         return
 
     # the reference seeds one Gaussian per valid frame-0 pixel (~292k at 640x480); BASELINE.json's configs[1] is quoted
@@ -379,6 +404,8 @@ def main():
         seq = SyntheticSequence(cfg, n_frames, n_target, seed=0, motion=motion)        # untimed: builds the RGB-D frames on the GPU
         window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives)
                   if (world > 1 or args.window_batch > 1 or args.force_collectives) else None)
+        if window is not None:
+            window.timing = True
         return SLAM(cfg, seq, render_mode=args.render_mode, window=window)
 
     log("process warm-up (6-frame SLAM run with a few iterations per frame: loads every operator once)")
@@ -416,6 +443,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rank_check = verify_ranks(slam)
+    if rank_check is not None and slam.mapper.window is not None:
+        st = slam.mapper.window.allreduce_stats()
+        # the gradient all-reduce sits between an iteration's backward projection and its Adam launch, with nothing to overlap it (the
+        # next projection needs the stepped parameters): this is time added to every optimiser step
+        rank_check["allreduce_calls"], rank_check["allreduce_ms_per_step"] = st["calls"], st["ms_per_call"]
+        rank_check["allreduce_bytes_per_step"] = st["bytes_per_call"]
+        rank_check["optimiser_note"] = (f"N > 1 changes the optimiser, not only the speed: every mapping step sums the gradients of {world * args.window_batch} views "
+                                        "(the reference takes ONE view per Adam step, slam/mapper.py:803-807); `value` counts those views as frame-equivalents")
 
     P_now = int(slam.gaussians.get_xyz.shape[0])
     # measured N (tile-splat pairs) of a representative render, for the algorithmic-bytes figure
@@ -498,12 +533,14 @@ def main():
         for r_ in recs:
             for pre, match in pmc_names.items():
                 if r_["kernel"].startswith(pre):
-                    r_["traffic"], r_["traffic_source"] = pmc_traffic(match)
+                    r_["traffic"], r_["traffic_source"] = pmc_traffic(match, args.workload)
                     if r_["traffic"]:
-                        # the same duration against the bytes the kernel really moved (counters): what `frac` would be if the contract's
-                        # algorithmic bytes were exactly what goes over the HBM pins (above 1x: re-reads / records; below: bytes of the
-                        # contract that this design never moves, e.g. the 6-pass global radix sort)
-                        r_["traffic_frac"] = r_["traffic"] / (r_["avg_launch_us"] * 1e-6) / 1e9 / 8000.0
+                        # the counters see what leaves the XCDs' L2s for the Infinity Fabric -- HBM *or* the 256 MiB Infinity Cache, and an
+                        # iteration's working set (~200 MB) fits the latter: this is L2-miss traffic, NOT bytes over the HBM pins, so the rate
+                        # below is reported as a fabric rate and never as a fraction of the HBM roofline.  Above 1x the
+                        # algorithmic bytes: re-reads / records; below: bytes of the contract this design never moves (the 6-pass radix sort)
+                        r_["traffic_kind"] = "L2-miss (fabric) bytes: HBM + Infinity-Cache hits"
+                        r_["fabric_GBps"] = r_["traffic"] / (r_["avg_launch_us"] * 1e-6) / 1e9
                         r_["traffic_over_algorithmic"] = r_["traffic"] / r_["algorithmic_bytes_per_launch"]
             if r_["kernel"].startswith("composite_bwd_kernel<6,1>"):
                 # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any early-out, ~25 flop + 1 exp
@@ -563,7 +600,7 @@ def main():
         slam = None
         torch.cuda.empty_cache()
         n_mv = 3 + args.moving_frames
-        slam3 = build(frac, n_mv, args.gaussians, motion="moving")
+        slam3 = build(frac, n_mv, args.gaussians, motion="desk")
         slam3.step(0)
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         for i in (1, 2):
@@ -580,15 +617,16 @@ def main():
                          "gaussians_start": P0, "gaussians_end": int(slam3.gaussians.get_xyz.shape[0]), "keyframes_start": kf0,
                          "keyframes_end": len(slam3.mapper.keyframes), "final_translation_error_cm": errs[-1] * 100.0,
                          "rmse_translation_error_cm": float(np.sqrt(np.mean(np.square(errs)))) * 100.0,
-                         "note": "same scene, map size and iteration budget on a camera that keeps moving (mm3dgs_slam_amd.slam.trajectory_moving: lateral sweep "
-                                 "past the scene, cumulative ~1 cm / 0.45 deg per frame): keyframe insertion, seeding of the newly seen regions, map growth and a "
-                                 "mapping window of several keyframes are inside the timed frames (the headline trajectory is a bounded +-3 cm wobble)"}
+                         "note": "same iteration budget on a hand-held sweep at TUM fr1/desk's pace (mm3dgs_slam_amd.slam.trajectory_desk: pan +-10 deg at up to "
+                                 "0.8 deg / frame, sideways +-0.25 m at up to 1.4 cm / frame; mean 0.94 cm / 0.61 deg per frame) over a scene 1.8x wider than the first "
+                                 "view: mapping.kf_every = 5 spaces the keyframes (slam/mapper.py:141-173), every keyframe seeds the newly seen region, the map and "
+                                 "the mapping window keep growing inside the timed frames (round 3's `moving` line ran a gentler trajectory: a keyframe every ~15 frames)"}
         del slam3
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")
         out["cpu_baseline"] = cpu_baseline(args)
         log("done")
-    finish(out)
+    finish(out, rank_failures(rank_check))
 
 
 if __name__ == "__main__":

@@ -28,6 +28,10 @@ class WindowParallel:
         # always_reduce: issue the collectives even with a single rank (an all-reduce over one rank is the identity): runs the
         # whole multi-GPU orchestration -- gradient-output loops, flat buffer, RCCL launch, separate Adam -- on a 1-GPU box
         self.always_reduce = bool(always_reduce)
+        # timing (bench.py): every `sample`-th gradient all-reduce is bracketed by events on the current stream (the collective is
+        # ordered after / before the work enqueued there, so the interval is the time the optimiser step waits for it)
+        self.timing = False
+        self._timed, self._calls, self._sample = [], 0, 8
 
     @property
     def _collective(self):
@@ -111,10 +115,37 @@ class WindowParallel:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return bool(int(t.item()))
 
+    def take_all(self, pop):
+        """(all `world * batch` ids of the step -- identical on every rank --, this rank's `batch` of them)."""
+        ids = [pop() for _ in range(self.world * self.batch)]
+        return ids, ids[self.rank * self.batch:(self.rank + 1) * self.batch]
+
+    def reduce_small(self, t):
+        """Sum of a small tensor over the ranks (bundle adjustment: the window's pose gradients), in place."""
+        if self._collective:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def reduce_flat(self, flat, rmax=None):
         """Native-loop variant: `flat` is (a prefix of) the engine's single gradient+statistics buffer (sum), `rmax` the radii
         (max; None outside the densification phase, when neither the statistics columns nor the radii are consumed)."""
         if self._collective:
+            ev = None
+            if self.timing and flat.is_cuda:
+                self._calls += 1
+                if self._calls % self._sample == 1:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if rmax is not None:
                 dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                self._timed.append((ev, flat.numel() * flat.element_size()))
+
+    def allreduce_stats(self):
+        """{calls, sampled, ms_per_call, bytes_per_call} of the gradient all-reduces since timing was switched on (synchronises)."""
+        if not self._timed:
+            return {"calls": self._calls, "sampled": 0, "ms_per_call": None, "bytes_per_call": None}
+        torch.cuda.synchronize()
+        ms = [e[0].elapsed_time(e[1]) for e, _ in self._timed]
+        return {"calls": self._calls, "sampled": len(ms), "ms_per_call": sum(ms) / len(ms), "bytes_per_call": sum(b for _, b in self._timed) / len(self._timed)}

@@ -98,6 +98,7 @@ class CpuEngine:
         self.grads = None
         self.P = -1
         self.calls = []
+        self.view_log = []
 
     # ---- what fused.py uses of FusedEngine --------------------------------------------------------------------------------------
     def _ensure(self, P, need_grads):
@@ -199,3 +200,4 @@ class CpuEngine:
                     p.grad = None
             self.out = out6.detach()
         self.calls.append(("map", len(views), stats is not None, map_adam is not None))
+        self.view_log.append(tuple(round(float(v[1].double().sum()), 4) for v in views))      # which views (by their colour target) this call rendered

@@ -33,6 +33,20 @@ import make_golden as mg          # noqa: E402  (puts /root/reference first on s
 
 H, W, N_FRAMES, N_SEED = 48, 64, 5, 2500
 SHORT = {"no_transform": 3, "sh2_python": 3, "white_bg": 3}          # frames of the short variants
+PREFIX = "g9"
+# --large (round 4): the same runs at 160x120 -- 80 tiles instead of 12, ~18 k Gaussians (one per valid pixel of frame 0, as the reference
+# seeds), 8 frames, keyframes 0 / 2 / 4 / 6 -- so that the native kernels' machinery (direct bins, XCD tile map, load-balanced tile table,
+# tile lists of hundreds of splats) is held to the reference's own classes through whole loops, not only through single renders.  Written
+# as g9L_*.npz.  The inputs are stored the way a dataset stores them -- 8-bit colour, 16-bit depth at TUM's png_depth_scale 5000
+# (configs/TUM.yml:88), float16 monocular stand-ins -- and both sides read the dequantised values; of the final map only per-column
+# quantiles are kept (the consumers compare populations, not rows).
+LARGE = "--large" in sys.argv
+if LARGE:
+    sys.argv.remove("--large")
+    H, W, N_FRAMES, N_SEED = 120, 160, 8, 16000
+    SHORT = {"no_transform": 4, "sh2_python": 4, "white_bg": 4}
+    PREFIX = "g9L"
+QS = [0.02, 0.1, 0.25, 0.5, 0.75, 0.9, 0.98]
 _MAP = {"iters": 14, "kf_every": 2, "min_covisibility": 0.999, "densify_until_iter": 9, "pruning_interval": 4, "min_opacity": 0.4625,
         "size_threshold": 20}
 VARIANTS = {
@@ -88,12 +102,24 @@ def make_frames():
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     seq = SyntheticSequence(cfg, N_FRAMES, N_SEED, seed=3, renderer=OurRenderer(cfg, rasterizer_cls=RefRasterizer, mode="reference"))
     frames = [(c.clone(), d.clone()) for c, d in seq.frames]
+    if LARGE:
+        frames = [((c.clamp(0, 1) * 255.0).round().to(torch.uint8).float() / 255.0, (d * 5000.0).round().clamp(0, 65535).to(torch.int32).float() / 5000.0)
+                  for c, d in frames]
     gt_poses = torch.stack([p.clone() for p in seq.poses])
     imu = torch.stack([seq.imu(i) if i else torch.zeros_like(seq.imu(1)) for i in range(N_FRAMES)])     # synthetic 100 Hz rows per frame interval
     # stand-ins for the monocular network's output (inverse-depth-like, arbitrary scale) and for its rescaled version
     yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
     est = [1000.0 / (d + 0.5 + 0.05 * torch.sin(xx / 5.0 + i)) for i, (_, d) in enumerate(frames)]
     est_scaled = [torch.where(d > 0, d * (1.0 + 0.03 * torch.sin(xx / 9.0 + 0.3 * i) * torch.cos(yy / 7.0)), torch.full_like(d, 2.0)) for i, (_, d) in enumerate(frames)]
+    if LARGE:
+        est = [e.half().float() for e in est]
+        est_scaled = [e.half().float() for e in est_scaled]
+        np.savez_compressed(os.path.join(HERE, f"{PREFIX}_frames.npz"), H=H, W=W,
+                            color_u8=np.stack([(mg.t2n(c) * 255.0).round().astype(np.uint8) for c, _ in frames]),
+                            depth_u16=np.stack([(mg.t2n(d) * 5000.0).round().astype(np.uint16) for _, d in frames]), gt_poses=mg.t2n(gt_poses), imu=mg.t2n(imu),
+                            tstamps=np.array(seq.tstamps, dtype=np.float64), est_f16=np.stack([mg.t2n(e).astype(np.float16) for e in est]),
+                            est_scaled_f16=np.stack([mg.t2n(e).astype(np.float16) for e in est_scaled]))
+        return frames, gt_poses, imu, list(seq.tstamps), est, est_scaled
     np.savez_compressed(os.path.join(HERE, "g9_frames.npz"), H=H, W=W, color=np.stack([mg.t2n(c) for c, _ in frames]),
                         depth=np.stack([mg.t2n(d) for _, d in frames]), gt_poses=mg.t2n(gt_poses), imu=mg.t2n(imu),
                         tstamps=np.array(seq.tstamps, dtype=np.float64), est=np.stack([mg.t2n(e) for e in est]),
@@ -138,9 +164,12 @@ def run_reference(name, overrides, frames, gt_poses, imu, tstamps, mono, mono_sc
         out = dict(est_poses=mg.t2n(est), per_frame=np.stack(per_frame), keyframes=np.array([",".join(map(str, k)) for k in kf_lists]),
                    keyframe_poses=np.stack([mg.t2n(kf.pose) for kf in mapper.keyframes]),
                    graph=np.array([",".join(map(str, sorted(mapper.covisibility_graph[k]))) for k in range(len(mapper.keyframes))]),
-                   xyz=mg.t2n(g._xyz), opacity=mg.t2n(g._opacity), scaling=mg.t2n(g._scaling), rotation=mg.t2n(g._rotation), f_dc=mg.t2n(g._features_dc),
+                   **({name_: mg.t2n(torch.quantile(t_.detach().reshape(t_.shape[0], -1).float(), torch.tensor(QS), dim=0)) for name_, t_ in
+                       (("q_xyz", g._xyz), ("q_opacity", g._opacity), ("q_scaling", g._scaling), ("q_rotation", g._rotation), ("q_f_dc", g._features_dc))}
+                      if LARGE else
+                      dict(xyz=mg.t2n(g._xyz), opacity=mg.t2n(g._opacity), scaling=mg.t2n(g._scaling), rotation=mg.t2n(g._rotation), f_dc=mg.t2n(g._features_dc))),
                    rng_after=np.array([random.random(), float(np.random.rand()), float(torch.rand(1))]), overrides=np.array(repr(overrides)))
-    path = os.path.join(HERE, f"g9_{name}.npz")
+    path = os.path.join(HERE, f"{PREFIX}_{name}.npz")
     np.savez_compressed(path, **out)
     print("written", path, os.path.getsize(path), "bytes")
 

@@ -22,7 +22,7 @@ DEV = "cuda:0"
 
 class _Frames:
     def __init__(self, F, n):
-        self.frames = [(torch.from_numpy(c).to(DEV), torch.from_numpy(d).to(DEV)) for c, d in zip(F["color"][:n], F["depth"][:n])]
+        self.frames = [(torch.from_numpy(np.ascontiguousarray(c)).to(DEV), torch.from_numpy(np.ascontiguousarray(d)).to(DEV)) for c, d in zip(F["color"][:n], F["depth"][:n])]
         self.poses = [torch.from_numpy(p).to(DEV) for p in F["gt_poses"][:n]]
         self.imu_rows = torch.from_numpy(F["imu"][:n])
         self.tstamps = [float(t) for t in F["tstamps"][:n]]
@@ -35,13 +35,15 @@ class _Frames:
         return self.frames[i][0], self.frames[i][1], self.poses[i]
 
 
-def run_variant(variant, verbose=False):
-    """Drives the native loops over the fixture's frames; returns the per-frame measurements (also used by tools/g9_native_check.py)."""
+def run_variant(variant, verbose=False, prefix="g9"):
+    """Drives the native loops over the fixture's frames; returns the per-frame measurements (also used by tools/g9_native_check.py).
+    prefix "g9": the 64x48 fixtures; "g9L": the 160x120 ones (80 tiles, ~8.6 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6)."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor as M
     from mm3dgs_slam_amd.slam import SLAM
-    F = np.load(os.path.join(HERE, "golden", "g9_frames.npz"))
-    G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
+    from tests import g9_util
+    F = g9_util.load_frames(prefix)
+    G = g9_util.load_variant(prefix, variant)
     overrides = eval(str(G["overrides"]), {"__builtins__": {}})          # a dict literal written by the generator
     cfg = default_config(device=DEV, height=int(F["H"]), width=int(F["W"]), **overrides)
     n = G["est_poses"].shape[0]
@@ -89,10 +91,12 @@ def run_variant(variant, verbose=False):
 # optical axis is barely constrained, and the reference's own arithmetic re-run by the torch-graph loops on CPU drifts from it by 6e-3 there.
 
 
+@pytest.mark.parametrize("prefix", ["g9", "g9L"])
 @pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"])
-def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
+def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, prefix):
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
-    slam, G, rows = run_variant(variant)
+    from tests import g9_util
+    slam, G, rows = run_variant(variant, prefix=prefix)
     want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
     aligned = True
     for r in rows:
@@ -114,13 +118,10 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant):
         assert d < (1e-2 if variant == "ba" else 5e-4), (kf.idx, float(d))
     # the final map as a population (rows are no longer aligned once a single pruning decision differs)
     g = slam.gaussians
-    qs = torch.tensor([0.02, 0.1, 0.25, 0.5, 0.75, 0.9, 0.98])
     for name, t in (("xyz", g._xyz), ("opacity", g._opacity), ("scaling", g._scaling), ("rotation", g._rotation), ("f_dc", g._features_dc)):
-        ref = torch.from_numpy(G[name])
-        t = t.detach().cpu()
-        for col in range(t.reshape(t.shape[0], -1).shape[1]):
-            a = torch.quantile(t.reshape(t.shape[0], -1)[:, col], qs)
-            b = torch.quantile(ref.reshape(ref.shape[0], -1)[:, col], qs)
+        got, ref = g9_util.final_quantiles(G, name, t)
+        for col in range(got.shape[1]):
+            a, b = got[:, col], ref[:, col]
             assert (a - b).abs().max() < 0.02 * max(1.0, float(b.abs().max())), (name, col, a, b)
     # the three RNG streams were consumed exactly as the reference consumes them
     after = np.array([random.random(), float(np.random.rand()), float(torch.rand(1))])

@@ -1,5 +1,5 @@
 """Prints, per frame, how the NATIVE loops (HIP kernels) follow the G9 reference trajectories (the measurements that
-tests/test_gpu_golden_slam.py asserts on).  GPU box:   python tools/g9_native_check.py [variant ...]"""
+tests/test_gpu_golden_slam.py asserts on).  GPU box:   python tools/g9_native_check.py [--large] [variant ...]"""
 import os
 import random
 import sys
@@ -11,9 +11,12 @@ import torch
 from tests.test_gpu_golden_slam import run_variant
 
 if __name__ == "__main__":
+    prefix = "g9"
+    if "--large" in sys.argv:
+        sys.argv.remove("--large"); prefix = "g9L"
     for variant in (sys.argv[1:] or ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"]):
         try:
-            slam, G, rows = run_variant(variant, verbose=True)
+            slam, G, rows = run_variant(variant, verbose=True, prefix=prefix)
         except Exception as e:      # keep going: this is a survey
             print(f"  {variant}: FAILED {type(e).__name__}: {e}")
             continue
