@@ -229,6 +229,10 @@ typedef struct Mm3dgsMapView {
   /* bundle adjustment (mapping.do_BA, slam/mapper.py:718-795,931-942): when set, the pose gradient of this view is reduced and
    * the Adam step of ITS pose is taken on the device (pose_adam->pose must be `pose`; per-keyframe moments and step counter). */
   const Mm3dgsPoseAdam* pose_adam_or_null;
+  /* bundle adjustment with a sharded mapping window (pose gradients are summed over the ranks before a common step):
+   * when set (and pose_adam_or_null is NULL), the view's pose gradient [7] = dL/d(qw, qx, qy, qz, tx, ty, tz) is written here and
+   * no pose step is taken. */
+  float* dpose_out_or_null;
 } Mm3dgsMapView;
 int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in,
                     float* out_color, int32_t* radii, void* geom_state, void* image_state, void* binning_state,

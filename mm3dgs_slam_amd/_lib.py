@@ -47,7 +47,8 @@ class Mm3dgsPoseAdam(C.Structure):
 
 
 class Mm3dgsMapView(C.Structure):
-    _fields_ = [("pose", C.c_void_p), ("gt_color", C.c_void_p), ("ref_depth_or_null", C.c_void_p), ("pose_adam_or_null", C.c_void_p)]
+    _fields_ = [("pose", C.c_void_p), ("gt_color", C.c_void_p), ("ref_depth_or_null", C.c_void_p), ("pose_adam_or_null", C.c_void_p),
+                ("dpose_out_or_null", C.c_void_p)]
 
 
 class Mm3dgsLossConfig(C.Structure):

@@ -101,7 +101,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
 }
 
 const char* mm3dgs_last_error(void) { return g_err; }
-int mm3dgs_version(void) { return 202; }   // 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
+int mm3dgs_version(void) { return 203; }   // 203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations void; 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
 
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
@@ -536,10 +536,11 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       rc = check_launch("loss");
       if (rc) return rc;
       tl.dmaps = fold_grad ? dmaps : nullptr;
+      if (views[it].pose_adam_or_null && views[it].dpose_out_or_null) return fail(-2, "view %d: either a pose step or a pose-gradient output", it);
       const float* next_pose = (!no_fuse_proj && map_adam && it + 1 < n_iter && !views[it].pose_adam_or_null && !views[it + 1].pose_adam_or_null &&
-                                views[it + 1].pose) ? views[it + 1].pose : nullptr;
+                                !views[it].dpose_out_or_null && views[it + 1].pose) ? views[it + 1].pose : nullptr;
       projected = false;
-      rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, nullptr,
+      rc = slam_backward_impl(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg, views[it].dpose_out_or_null,
                               views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream, fold_grad ? &tl : nullptr, nullptr, 4, false,
                               next_pose, &projected);
     } else {
@@ -548,7 +549,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
       rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
       if (rc) return rc;
       rc = mm3dgs_slam_backward(cam, P, &si, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &sg,
-                                nullptr, views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream);
+                                views[it].dpose_out_or_null, views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream);
     }
     if (rc) return rc;
     ad.step++;

@@ -180,6 +180,8 @@ class FusedEngine:
             arr[i].pose, arr[i].gt_color, arr[i].ref_depth_or_null = pose.data_ptr(), gt_color.data_ptr(), (ref.data_ptr() if ref is not None else None)
             if len(view) > 3 and view[3] is not None:        # bundle adjustment: this view's pose takes an Adam step on the device
                 arr[i].pose_adam_or_null = C.addressof(view[3])
+            if len(view) > 4 and view[4] is not None:        # ... or (sharded window) hands its pose gradient out for the reduce
+                arr[i].dpose_out_or_null = view[4].data_ptr()
         return arr
 
     def visibility(self, pose, g, seen):
@@ -443,8 +445,7 @@ class FusedMapper(Mapper):
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]
         do_ba = bool(m["do_BA"]) and idx > 0
-        if (num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians)
-                or (do_ba and self.window is not None and self.window.sharded)):     # (BA with a sharded window: torch-graph loop)
+        if num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians):
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
@@ -498,6 +499,11 @@ class FusedMapper(Mapper):
             # the intended behaviour (every window pose stepped when its view is rendered).
             if not do_ba or (k != -1 and not m.get("ba_optimize_keyframes", False)):
                 return buf, gt_color.contiguous(), ref
+            if multi:
+                # sharded window (round 4): the view hands its pose gradient out; the gradients of a step's views are summed over the
+                # ranks and every replica takes the identical pose step (_ba_window_step below) -- the state was created up front
+                st = ba_state[k]
+                return st[0], gt_color.contiguous(), ref, None, st[6]
             # pose Adam of slam/mapper.py:742-752: Adam(lr=0, eps=1e-15), groups cam_rot (cam_q_lr) / cam_pos (cam_t_lr); a pose is
             # only stepped in the iterations that render its view (torch skips parameters without a gradient), hence per-view state
             buf = buf.clone()
@@ -523,6 +529,21 @@ class FusedMapper(Mapper):
                     om = om | new_gaussians_mask
                 self._opt_mask = om.to(torch.uint8).contiguous()
         multi = self.window is not None and self.window.sharded
+        self._ba_ids = []
+        if do_ba and multi:
+            # bundle adjustment with a sharded window, natively: pose, moments, step counter and a gradient slot for EVERY optimisable
+            # pose of the window, created on every rank in the same order (the views a rank renders differ, the state must not)
+            def ba_init():
+                ba_state.clear()
+                ids = sorted(set(k for k in keyframe_idx_list if k == -1 or m.get("ba_optimize_keyframes", False)))
+                self._ba_ids = ids
+                self._ba_grad = torch.zeros(max(len(ids), 1), 7, device=eng.dev)
+                for k in ids:
+                    pose = curr_camera_tensor if k == -1 else self.keyframes[k].pose
+                    buf = pose.detach().float().contiguous().clone()
+                    ba_state[k] = (buf, torch.zeros(7, device=eng.dev), torch.zeros(7, device=eng.dev), [0], None, pose, torch.zeros(7, device=eng.dev))
+            ba_init()
+            self._ba_state, self._ba_init = ba_state, ba_init
         # overflow recovery: a forward whose (tile, splat) pairs exceed the binning capacity renders clamped lists (flagged
         # sticky in the header).  The loop below is read back once, at its end; if any of its forwards overflowed, the map,
         # the optimiser, the statistics and the keyframe-pick RNG are put back and the loop is re-run (capacity raised).
@@ -562,6 +583,8 @@ class FusedMapper(Mapper):
             _random.setstate(rng_state)
             stack = None
             view_cache.clear(); ba_state.clear()       # (pose buffers and their Adam state start over)
+            if do_ba and multi:
+                self._ba_init()
             if do_ba:
                 with torch.no_grad():
                     om = self.get_covisible_gaussians(keyframe_idx_list, curr_camera_tensor, 2)
@@ -572,8 +595,8 @@ class FusedMapper(Mapper):
             raise RuntimeError("mm3dgs: mapping loop kept overflowing its binning capacity")
         if do_ba:      # the optimised window poses go back where the reference's in-place Adam leaves them
             with torch.no_grad():
-                for k, (buf, _m, _v, _s, _ad, pose) in ba_state.items():
-                    pose.data.copy_(buf)
+                for k, st in ba_state.items():
+                    st[5].data.copy_(st[0])
         if self.cfg["debug"]["get_runtime_stats"]:
             if eng.dev.type == "cuda":
                 torch.cuda.synchronize(eng.dev)
@@ -612,7 +635,7 @@ class FusedMapper(Mapper):
                     iteration += n
                     continue
                 # one optimiser step over this rank's share of the window batch (a single view without a window)
-                ids = self.window.take(pop) if self.window is not None else [pop()]
+                all_ids, ids = self.window.take_all(pop) if self.window is not None else (None, [pop()])
                 P = int(g._xyz.shape[0])
                 eng._ensure(P, True)
                 prune_now = prune_at(iteration)
@@ -622,8 +645,12 @@ class FusedMapper(Mapper):
                     # every parameter gradient and, while densifying, the statistics tail [14P, 16P) (+ a max-reduce of the radii)
                     if densify:
                         eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
+                    if self._ba_ids:
+                        self._ba_grad.zero_()
                     for j, k in enumerate(ids):
                         eng.map_loop([view_of(k)], g, lcfg, eng.stat_delta if densify else None, None, grads=eng.grads)
+                        if k in self._ba_ids:      # this view's pose gradient (its slot is overwritten by the pose's next view)
+                            self._ba_grad[self._ba_ids.index(k)] += self._ba_state[k][6]
                         if len(ids) > 1:
                             if j == 0:
                                 eng.acc[:14 * P].copy_(eng.flat[:14 * P])
@@ -638,7 +665,13 @@ class FusedMapper(Mapper):
                         g.denom += eng.stat_delta[2]
                     else:
                         self.window.reduce_flat(eng.flat[:14 * P])
+                    if self._ba_ids:
+                        self._ba_window_step(eng, m, all_ids, ids)
                     if not prune_now:
+                        if self._opt_mask is not None:       # bundle adjustment: Gaussians outside the covisible set keep a zero gradient (slam/mapper.py:931-938)
+                            keep = self._opt_mask.to(eng.flat.dtype)
+                            for t in eng.grads.values():
+                                t.mul_(keep.view(-1, *([1] * (t.dim() - 1))))
                         self._adam_step(eng)
                 else:
                     # a pruning iteration: gradients + statistics only (the reference prunes BEFORE optimizer.step(): the
@@ -669,6 +702,28 @@ class FusedMapper(Mapper):
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
                         self._opt_mask = self._opt_mask[~pruned()].contiguous()
                 iteration += 1
+
+    def _ba_window_step(self, eng, m, all_ids, my_ids):
+        """Bundle adjustment with a sharded window: this rank's views wrote their pose gradients out (Mm3dgsMapView.dpose_out_or_null)
+        and the loop summed them per pose (a pose rendered twice in a step gets both gradients, like autograd accumulates them);
+        here they are all-reduced over the ranks, then every replica steps -- with mm3dgs_adam: Adam(eps=1e-15), cam_q_lr / cam_t_lr,
+        slam/mapper.py:742-752 -- exactly the poses SOME rank rendered in this step (known on every rank from the shared keyframe
+        stack: no flags travel), so a pose nobody rendered keeps its moments and step counter, as torch skips parameters without a
+        gradient (the torch-graph window does the same through WindowParallel.reduce_pose_grads)."""
+        st_all, order = self._ba_state, self._ba_ids
+        gbuf = self._ba_grad           # (this rank's views added their gradients as they were rendered)
+        self.window.reduce_small(gbuf)
+        for k in sorted(set(i for i in all_ids if i in st_all)):
+            buf, mom, var, step, _ad, _pose, _slot = st_all[k]
+            step[0] += 1
+            gk = gbuf[order.index(k)]
+            table = (_lib.Mm3dgsAdamGroup * 8)()
+            for j, (lo, hi, lr) in enumerate(((0, 4, float(m["cam_q_lr"])), (4, 7, float(m["cam_t_lr"])))):
+                e = table[j]
+                e.param, e.grad = buf[lo:hi].data_ptr(), gk[lo:hi].data_ptr()
+                e.exp_avg, e.exp_avg_sq = mom[lo:hi].data_ptr(), var[lo:hi].data_ptr()
+                e.n, e.lr = hi - lo, lr
+            _lib.check(eng.lib.mm3dgs_adam(table, 2, step[0], 0.9, 0.999, 1e-15, _stream()))
 
     def _inline_adam(self, n=1):
         """Mm3dgsMapAdam over the optimiser's own state tensors (created like torch.optim.Adam would on its first step);

@@ -161,8 +161,9 @@ class CpuEngine:
         for i, view in enumerate(views):
             pose_buf, gt_color, ref = view[:3]
             pad = view[3] if len(view) > 3 else None
+            dpose_out = view[4] if len(view) > 4 else None        # Mm3dgsMapView.dpose_out_or_null: the pose gradient is written out, no step
             with torch.enable_grad():
-                pose = pose_buf.clone().requires_grad_(pad is not None)
+                pose = pose_buf.clone().requires_grad_(pad is not None or dpose_out is not None)
                 out6, res = self._render(g, pose)
                 loss = loss_from_config(lcfg, out6, gt_color, ref)
                 for p in params:
@@ -190,6 +191,9 @@ class CpuEngine:
                 elif grads is not None:
                     for name, gk in zip(("xyz", "f_dc", "opacity", "scaling", "rotation"), gr):
                         grads[name].copy_(gk.reshape(grads[name].shape))
+                if dpose_out is not None:
+                    assert pad is None
+                    dpose_out.copy_(pose.grad)
                 if pad is not None:
                     pb, m, v, step = _view(pad.pose, 7), _view(pad.m, 7), _view(pad.v, 7), _view(pad.step, 1, C.c_int32)
                     t = int(step[0]) + 1

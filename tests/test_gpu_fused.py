@@ -1100,6 +1100,48 @@ def test_native_bundle_adjustment_follows_the_torch_graph_loop():
     assert (c[1][1:] - c[3][1:]).abs().max() > 1e-4                        # the flag: window keyframe poses move too
 
 
+def test_native_bundle_adjustment_with_a_window_batch_follows_the_torch_graph_window():
+    """Round 4: do_BA with a sharded mapping window on the HIP loops (two views per optimiser step: Mm3dgsMapView.dpose_out_or_null hands
+    each view's pose gradient out, fused.py sums them per pose and steps the poses that were rendered with mm3dgs_adam) against the
+    torch-graph window loop (slam/mapper.py:742-760,803-825,944-948 with WindowParallel batch 2): the refined current pose, the untouched
+    keyframe poses (the reference's quirk), the map."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    results = {}
+    for name, native, kf_opt in (("torch", False, False), ("native", True, False), ("native_kf", True, True)):
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 10},
+                             mapping={"iters": 12, "do_BA": True, "ba_optimize_keyframes": kf_opt})
+        seq = SyntheticSequence(cfg, 5, 8000, seed=4)
+        slam = SLAM(cfg, seq, native_loops=native, window=WindowParallel(0, 1, batch=2))
+        slam.step(0)
+        mp = slam.mapper
+        off = torch.tensor([0.0, 0.002, -0.001, 0.001, 0.004, -0.003, 0.005], device=DEV)
+        for i in (1, 2):
+            color, depth, gt_pose = seq[i]
+            mp.add_keyframe(i, (gt_pose + off * i).clone(), color, depth, depth)
+        start_kf = torch.stack([kf.pose for kf in mp.keyframes]).detach().cpu().clone()
+        color, depth, gt_pose = seq[3]
+        cur = (gt_pose - off).clone()
+        start_cur = cur.detach().cpu().clone()
+        slam.estimate_pose_list[3] = cur
+        random.seed(7)
+        mp.optimize_map(3, 12, [0, 1, 2, -1], None, cur, color, depth, depth)
+        torch.cuda.synchronize()
+        if native:
+            assert type(mp).__name__ == "FusedMapper" and mp._ba_ids, "the native window loop must have handled the bundle adjustment"
+        results[name] = (cur.detach().cpu(), torch.stack([kf.pose for kf in mp.keyframes]).detach().cpu(), slam.gaussians._xyz.detach().cpu(),
+                         start_kf, start_cur)
+    a, b, c = results["torch"], results["native"], results["native_kf"]
+    assert a[2].shape == b[2].shape
+    assert torch.equal(a[1], a[3]) and torch.equal(b[1], b[3])
+    assert (a[0] - a[4]).abs().max() > 1e-4
+    assert (a[0] - b[0]).abs().max() < 5e-4, (a[0], b[0])
+    assert pu.rel_l2(b[2], a[2]) < 2e-3
+    assert (c[1][1:] - c[3][1:]).abs().max() > 1e-4
+
+
 def test_utmm_shaped_config_with_imu_runs_natively_and_tracks():
     """BASELINE.json configs[2] in miniature: configs/UTMM.yml settings (isotropic Gaussians, IMU dead-reckoning for the pose prediction
     over the synthetic IMU rows, Pearson term, IMU relative-pose residual) through the native loops; the trajectory stays on the ground
