@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--moving-frames", type=int, default=60,
                     help="slam, 1 GPU: a further run on a hand-held sweep at TUM fr1/desk's pace (up to 1.4 cm / 0.8 deg per frame: a keyframe every 5 frames, "
                          "seeding, a growing map, a filling window), this many timed frames, reported as `moving` (0 = skip)")
+    ap.add_argument("--mono-frames", type=int, default=20,
+                    help="slam, 1 GPU: a further run WITHOUT sensor depth (use_gt_depth: false, what configs/TUM.yml:8 ships): every frame renders the map once "
+                         "more and fits a synthetic monocular estimate to it by least squares (slam/SLAM.py:411-448), reported as `mono_depth` (0 = skip)")
     ap.add_argument("--window-batch", type=int, default=1, help="views per rank and optimiser step in the mapping window (SURVEY 8e)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
@@ -392,14 +395,14 @@ def main():
         frac = args.seed_fraction or 1.0      # the reference's seeding: ~0.78 M Gaussians from frame 0, growing with every keyframe
         steady = 0
 
-    def build(frac_, n_frames, n_target, motion="bounded"):
+    def build(frac_, n_frames, n_target, motion="bounded", top=None):
         if c3:
             from mm3dgs_slam_amd.config import utmm_config
             cfg = utmm_config(device=dev, tracking={"iters": args.track_iters, "use_imu_loss": True, "imu_T_weight": 1.0, "imu_q_weight": 0.1},
                               mapping={"iters": args.map_iters, "seed_fraction": frac_})
         else:
             cfg = default_config(device=dev, height=args.height, width=args.width, tracking={"iters": args.track_iters},
-                                 mapping={"iters": args.map_iters, "seed_fraction": frac_})
+                                 mapping={"iters": args.map_iters, "seed_fraction": frac_}, **(top or {}))
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         seq = SyntheticSequence(cfg, n_frames, n_target, seed=0, motion=motion)        # untimed: builds the RGB-D frames on the GPU
         window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives)
@@ -622,6 +625,29 @@ def main():
                                  "view: mapping.kf_every = 5 spaces the keyframes (slam/mapper.py:141-173), every keyframe seeds the newly seen region, the map and "
                                  "the mapping window keep growing inside the timed frames (round 3's `moving` line ran a gentler trajectory: a keyframe every ~15 frames)"}
         del slam3
+    if extras and args.mono_frames and not c3 and not c4:
+        log("run without sensor depth (per-frame depth alignment)")
+        slam = None
+        torch.cuda.empty_cache()
+        n_mo = 3 + args.mono_frames
+        slam4 = build(frac, n_mo, args.gaussians, top={"use_gt_depth": False})
+        slam4.step(0)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        for i in (1, 2):
+            slam4.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, n_mo):
+            slam4.step(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["mono_depth"] = {"frames": args.mono_frames, "value": args.mono_frames / el, "unit": "frames/s", "ms_per_frame": el / args.mono_frames * 1e3,
+                             "gaussians": int(slam4.gaussians.get_xyz.shape[0]), "keyframes": len(slam4.mapper.keyframes),
+                             "note": "use_gt_depth: false as configs/TUM.yml:8 ships it: the tracker gets a synthetic monocular estimate (inverse-depth-like, arbitrary "
+                                     "scale, 3 % smooth error; the network itself is out of scope), every frame renders the map once more at the tracked pose and fits "
+                                     "the estimate to it by least squares (slam/SLAM.py:411-448, depth_utils.scale_depth_estimate), the mapper seeds from and regresses "
+                                     "(Pearson term) on the rescaled estimate; the headline line runs with sensor depth, where that render + fit do not exist"}
+        del slam4
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         log("cpu baseline (oracle on the host cores)")
         out["cpu_baseline"] = cpu_baseline(args)

@@ -275,27 +275,96 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
 // advance together: sum over the four 8x8 sub-tiles of the longest of their four block lists) -- from whatever view was rendered last;
 // the table is a permutation whatever the loads are, so a stale or meaningless load only costs speed.  One workgroup per XCD.
 #define ORDER_MAX_PER 160     // five rounds of 32 CU slots: beyond that the workgroups of a launch are placed dynamically
+// Round 4: the eight spans are cut by LOAD, not by tile count.  On a camera that moves, keyframes seed the newly seen side of the image and
+// the tile lists there grow: with equal-count spans one XCD carried 1.05 - 1.11 x the mean wave steps (tools/xcd_balance.py, the bench's
+// `moving` scenario; 1.02 - 1.03 on the bounded trajectory) and the launch ends when IT is done.  The spans stay contiguous in tile order
+// (L2 locality) but hold equal wave steps (max / mean 1.005); a span may then hold up to TILE_SPAN_SLOTS tiles, the compositors launch
+// 8 x TILE_SPAN_SLOTS workgroups and the ones beyond an XCD's span leave at once.  Every workgroup of this kernel reads all T loads (5 KB).
 __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, uint32_t key) {
-  __shared__ uint32_t load[ORDER_MAX_PER];
-  const int per = (T + 7) >> 3, x = blockIdx.x, tid = threadIdx.x;
-  const int j = tid;                                   // tile x * per + j of this XCD's span (j >= n: no such tile, load 0)
-  uint32_t mine = 0;
-  const int tile = x * per + j;
-  if (j < per && tile < T) {
-    const uint4* sc = (const uint4*)(iv.subcount + (size_t)tile * NLIST);
+  __shared__ uint32_t pre[8 * ORDER_MAX_PER + 1];        // inclusive prefix of the loads in tile order, pre[-1] = 0 at pre[0]
+  __shared__ uint32_t load[TILE_SPAN_SLOTS];
+  __shared__ uint32_t wsum[4];
+  __shared__ int cut[9];
+  const int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // loads of all tiles: thread t owns the CH consecutive tiles [t CH, (t + 1) CH)
+  const int CH = (T + 255) >> 8;
+  uint32_t mine_sum = 0;
+  uint32_t l5[(8 * ORDER_MAX_PER + 255) / 256];
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const uint4 q = sc[w];
+  for (int u = 0; u < (8 * ORDER_MAX_PER + 255) / 256; u++) {
+    const int tile = tid * CH + u;
+    uint32_t m = 0;
+    if (u < CH && tile < T) {
+      const uint4* sc = (const uint4*)(iv.subcount + (size_t)tile * NLIST);
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint4 q = sc[w];
 #if defined(MM3DGS_ORDER_ROWSTEPS)                      // developer experiment (tools/build_variant.sh): load = row steps instead of wave steps
-      mine += q.x + q.y + q.z + q.w;
+        m += q.x + q.y + q.z + q.w;
 #else
-      mine += max(max(q.x, q.y), max(q.z, q.w));
+        m += max(max(q.x, q.y), max(q.z, q.w));
+#endif
+      }
+      m += 1u;                                         // (a real tile outranks the padding; an unrendered grid cuts into equal spans)
+    }
+    l5[u] = m;
+    mine_sum += m;
+  }
+  // exclusive scan of the per-thread sums over the workgroup
+  uint32_t incl = mine_sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += y;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t base = incl - mine_sum;
+  for (int q = 0; q < wv; q++) base += wsum[q];
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) pre[0] = 0u;
+  {
+    uint32_t run = base;
+#pragma unroll
+    for (int u = 0; u < (8 * ORDER_MAX_PER + 255) / 256; u++) {
+      const int tile = tid * CH + u;
+      run += l5[u];
+      if (u < CH && tile < T) pre[tile + 1] = run;
+    }
+  }
+  __syncthreads();
+  // cut k = first tile index whose prefix reaches k / 8 of the total (binary search; every workgroup computes all nine identically)
+  if (tid < 9) {
+    int c = tid == 8 ? T : 0;
+    if (tid > 0 && tid < 8) {
+#if defined(MM3DGS_ORDER_EQUAL_SPANS)                  // developer experiment: round 3's equal-count spans
+      c = min(T, tid * ((T + 7) >> 3));
+#else
+      const unsigned long long want = (unsigned long long)total * (unsigned)tid;      // pre[c] * 8 >= total * k
+      int lo = 0, hi = T;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned long long)pre[mid] * 8ull >= want) hi = mid; else lo = mid + 1;
+      }
+      c = lo;
 #endif
     }
-    mine += 1u;                                        // (a real tile outranks the padding)
+    cut[tid] = c;
   }
-  if (j < per) load[j] = mine;
   __syncthreads();
+  // a span that would not fit its XCD's workgroup slots: fall back to equal-count spans (the same decision in every workgroup)
+  bool fits = true;
+  for (int k = 0; k < 8; k++) fits = fits && (cut[k + 1] - cut[k] <= TILE_SPAN_SLOTS) && (cut[k + 1] >= cut[k]);
+  const int per_eq = (T + 7) >> 3;
+  const int lo_t = fits ? cut[x] : min(T, x * per_eq), hi_t = fits ? cut[x + 1] : min(T, (x + 1) * per_eq);
+  const int per = hi_t - lo_t;                        // tiles of this XCD's span
+  const int j = tid;                                  // tile lo_t + j of the span
+  const uint32_t mine = j < per ? pre[lo_t + j + 1] - pre[lo_t + j] : 0u;
+  load[j] = mine;
+  __syncthreads();
+  // the slots of this XCD beyond its span: no tile
+  for (int i = per + tid; i < TILE_SPAN_SLOTS; i += 256) iv.tile_order[(size_t)i * 8 + x] = 0u;
+  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
   if (j >= per) return;
   int rank = 0;                                        // descending load, ties by index: a permutation of [0, per)
   for (int k = 0; k < per; k++) {
@@ -305,7 +374,6 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   const int R = (per + 31) >> 5;                       // rounds; CU slots c < full hold R workgroups, the others R - 1
 #if defined(MM3DGS_ORDER_PLAIN)                          // developer experiment: plain serpentine over all 32 slots (ignores which slots hold one workgroup less)
   const int full = 32, L = 0, n_light = 0;
-  if (rank >= per) return;
 #else
   const int full = per - (R - 1) * 32, L = 32 - full, n_light = L * (R - 1);
 #endif
@@ -324,8 +392,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
     c = (r & 1) ? full - 1 - pos : pos;
   }
   const int i = r * 32 + c;                            // index of the workgroup inside the XCD: blockIdx = 8 i + x
-  iv.tile_order[(size_t)i * 8 + x] = tile < T ? (uint32_t)tile + 1u : 0u;
-  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
+  iv.tile_order[(size_t)i * 8 + x] = (uint32_t)(lo_t + j) + 1u;
 }
 bool launch_tile_order(int T, int H, int W, ImageView iv, hipStream_t s) {
   const int per = (T + 7) >> 3;

@@ -809,7 +809,7 @@ void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, Ima
                                float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
-  int grid = ((T + 7) / 8) * 8;
+  int grid = slam_grid(cam, T);
   TrackLoss none = {};
   if (tracking)
     hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
@@ -821,7 +821,7 @@ void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, Bin
                                 const TrackLoss* tl, int direct_blocks, uint32_t direct_cap, int slot_bits) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
-  int grid = ((T + 7) / 8) * 8;
+  int grid = slam_grid(cam, T);
   TrackLoss none = {};
   hipLaunchKernelGGL((sort_composite_fwd_kernel<6>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl ? 1 : 0, tl ? *tl : none, direct_blocks, direct_cap, slot_bits);
 }
@@ -830,7 +830,7 @@ void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageVie
                                          hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap, int slot_bits) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
-  int grid = ((T + 7) / 8) * 8;
+  int grid = slam_grid(cam, T);
   hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
 }
 

@@ -50,12 +50,18 @@ __device__ __forceinline__ int xcd_tile(int bid, int T, int mode) {
 // SLAM kernels over persistent state: the load-balanced workgroup -> tile table of binning.hip's tile_order_kernel when it is valid
 // for this grid (one scalar load; any permutation of the tiles is correct, only the speed depends on it)
 __device__ __forceinline__ int slam_tile(const CamDev& cam, const ImageView& iv, int bid, int T) {
-  int tile = xcd_tile(bid, T, cam.tilemap);
+  // (the launch may hold more workgroups than tiles: slam_grid() -- those beyond the arithmetic map's range leave)
+  int tile = bid < ((T + 7) >> 3) * 8 ? xcd_tile(bid, T, cam.tilemap) : T;
   if (cam.tile_table && iv.hdr->tile_order_tiles == tile_order_key(cam.H, cam.W)) {
     const uint32_t o = iv.tile_order[bid];
-    tile = o ? (int)o - 1 : T;       // (0: a workgroup beyond the grid's tiles)
+    tile = o ? (int)o - 1 : T;       // (0: a workgroup slot beyond its XCD's span)
   }
   return tile;
+}
+// workgroups of a SLAM compositor launch: with the tile table every XCD gets TILE_SPAN_SLOTS slots (its load-cut span may hold more than T / 8 tiles)
+static inline int slam_grid(const CamDev& cam, int T) {
+  const int n = ((T + 7) / 8) * 8;
+  return (cam.tile_table && T >= 64 && (T + 7) / 8 <= 160) ? 8 * TILE_SPAN_SLOTS : n;
 }
 
 // identical instruction sequence in forward and backward so both take the same skip decisions

@@ -78,7 +78,7 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
 
 // Projection of one Gaussian (lane): pose transform, activations, EWA, SH degree 0 -> RGB, [z, 1, z^2], tile rectangle, block
 // rectangle.  Writes the splat record, depth, clamp bits, radii and rect; returns what the binning half of the kernels needs.
-struct Projected { uint32_t r0, r1, nblk; float4 sA, sB; BlkRect br; float z; int32_t rad; };
+struct Projected { uint32_t r0, r1, nblk; float4 sA, sB; BlkRect br; float z; int32_t rad; uint32_t cl; };
 // raw parameters of one Gaussian, as the projection consumes them
 struct RawGaussian { float x[3], q[4], ls[3], fd[3], op; };
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
     for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * rg.x[0] + ps.R[i][1] * rg.x[1] + ps.R[i][2] * rg.x[2] + ps.t[i];
   }
   Projected o;
-  o.r0 = 0; o.r1 = 0; o.nblk = 0; o.rad = 0; o.z = 0.f;
+  o.r0 = 0; o.r1 = 0; o.nblk = 0; o.rad = 0; o.z = 0.f; o.cl = 0;
   o.sA = make_float4(0.f, 0.f, 0.f, 0.f); o.sB = o.sA;
   o.br.bx0 = 0; o.br.by0 = 0; o.br.bw = 0; o.br.bh = 0;
   if (live && p[2] > 0.2f) {
@@ -128,7 +128,8 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         o.r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
         const float* fd = fd_raw;
         float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
-        g.clamped[idx] = (c0 < 0.f ? 1 : 0) | (c1 < 0.f ? 2 : 0) | (c2 < 0.f ? 4 : 0);
+        o.cl = (c0 < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u);
+        g.clamped[idx] = (uint8_t)o.cl;
         const float z = p[2];
         const float op = 1.f / (1.f + expf(-op_raw));
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
@@ -253,12 +254,13 @@ struct PairCtx {           // what a lane needs to emit the pairs of ITS Gaussia
   MaskConsts mc; BlkRect br; uint32_t rec0; uint32_t khi, idbits; int minx, miny, w, area;   // rec0: first record (absolute)
   uint32_t trec0;            // per-tile record of the splat's first pair (absolute; pair k of the tile rectangle, row-major: trec0 + k); ~0u: none
 };
-__device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, int ttx, int tty, uint32_t* hist, int gx, uint32_t cap, const BinView& b) {
+__device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, int ttx, int tty, uint32_t* hist, int gx, uint32_t cap, const BinView& b,
+                                              bool have_mask = false, uint32_t mask_in = 0u) {
   const int t = tty * gx + ttx;
   const uint32_t slot = atomicAdd(&hist[t], 1u);
   uint32_t mask = 0;
   if (slot < cap) {
-    mask = tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
+    mask = have_mask ? mask_in : tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
     const uint32_t rec_local = c.rec0 + (uint32_t)((tty * 4 - c.br.by0) * c.br.bw + (ttx * 4 - c.br.bx0));
     const size_t at = (size_t)t * cap + slot;
     b.keys[at] = ((unsigned long long)c.khi << 32) | (unsigned long long)(c.idbits | slot);
@@ -312,10 +314,32 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
       if (tot > iv.hdr->max_group_records) atomicMax(&iv.hdr->max_group_records, tot);   // (rare: the maximum is sticky)
     }
   }
-  // sweep 1: count (cheap per pair; a rectangle of more than 32 tiles is spread over the wave)
+  // sweep 1: count (a rectangle of more than 32 tiles is spread over the wave).  Round 4: the block masks of a lane's OWN pairs (the first
+  // four of its splat: all the pairs of nearly every splat of a SLAM map) are evaluated here already, and a pair whose mask is EMPTY -- the
+  // 3-sigma tile rectangle the reference prescribes for `radii` / tiles touched reaches further than the { alpha >= 1/255 } region that can
+  // contribute: 15 % of the pairs at frame 8 of the benchmark run, 18 % after 100 frames -- takes no slot in its tile's bin: no key to sort,
+  // no payload, no per-tile gradient record.  Bit k of `empty4` marks it; the backward projection finds the bits in clamped[idx] >> 4 and
+  // skips the record (it would be all zeros).  Splats of more than 32 tiles and the pairs beyond the fourth are listed as before.
+  constexpr int OWN = 4;
   unsigned long long big = __ballot(c.area > 32);
-  if (c.area > 0 && c.area <= 32)
-    for (int k = 0; k < c.area; k++) atomicAdd(&hist[(c.miny + k / c.w) * cam.gx + c.minx + k % c.w], 1u);
+  unsigned long long m64 = 0ull;
+  uint32_t empty4 = 0u;
+  const bool droppable = c.area > 0 && c.area <= 32;
+  if (droppable) {
+    int ttx = c.minx, tty = c.miny;
+    for (int k = 0; k < c.area; k++) {
+      bool count = true;
+      if (k < OWN) {
+        const uint32_t mk = tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
+        m64 |= (unsigned long long)mk << (16 * k);
+        count = mk != 0u;
+        empty4 |= count ? 0u : (1u << k);
+      }
+      if (count) atomicAdd(&hist[tty * cam.gx + ttx], 1u);
+      if (++ttx == c.minx + c.w) { ttx = c.minx; tty++; }
+    }
+  }
+  if (live) g.clamped[idx] = (uint8_t)(pr.cl | (empty4 << 4));
   for (unsigned long long bb = big; bb; bb &= bb - 1) {
     const int src = __ffsll((long long)bb) - 1;
     const int sminx = __builtin_amdgcn_readlane(c.minx, src), sminy = __builtin_amdgcn_readlane(c.miny, src);
@@ -334,16 +358,13 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   // 16k..16k+15).  The pairs beyond the fourth form the wave's flat work list, cut into equal shares: the few 20-90 pixel
   // splats that grow in a map would otherwise keep one lane busy for dozens of iterations while its wave waits (this kernel
   // went from 19 to 44 us over 100 frames of a run before).
-  constexpr int OWN = 4;
-  unsigned long long m64 = 0ull;
   {   // (running tile coordinates: no division per pair)
     int ttx = c.minx, tty = c.miny;
     for (int k = 0; k < min(c.area, OWN); k++) {
-      m64 |= (unsigned long long)emit_pair(c, k, ttx, tty, hist, cam.gx, cap, b) << (16 * k);
+      if (!((empty4 >> k) & 1u)) emit_pair(c, k, ttx, tty, hist, cam.gx, cap, b, droppable, (uint32_t)(m64 >> (16 * k)) & 0xffffu);
       if (++ttx == c.minx + c.w) { ttx = c.minx; tty++; }
     }
   }
-  (void)m64;
   uint32_t incl = (uint32_t)max(c.area - OWN, 0);
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -398,7 +419,8 @@ void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t
 // are summed by their own lane, four records in flight, in ascending pair order; a bigger one is read by the whole wave (lane-strided,
 // then a fixed-order DPP reduction) -- deterministic either way.  Mapping records: 10 floats, tracking: 7 (composite_common.h).
 template <bool TRACK>
-__device__ __forceinline__ void gather_tile_records(int area, uint32_t first, const float* __restrict__ dtile, float4& acc0, float4& acc1, float4& acc2) {
+__device__ __forceinline__ void gather_tile_records(int area, uint32_t first, const float* __restrict__ dtile, float4& acc0, float4& acc1, float4& acc2,
+                                                    uint32_t skip4) {
   constexpr int RECF = TRACK ? REC_TRACK_F : REC_MAP_F;
   const int lane = threadIdx.x & 63;
   const bool big = area > 16;
@@ -408,7 +430,7 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
     bool on[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      on[u] = k0 + u < n_own;
+      on[u] = k0 + u < n_own && !((skip4 >> (k0 + u)) & 1u);      // (skip4: pairs the binning kernel listed nowhere -- their records were never written)
       const float* r = dtile + (on[u] ? (size_t)(first + (uint32_t)(k0 + u)) * RECF : (size_t)0);
       a[u] = ld4u(r); b4[u] = ld4u(r + 4);
       c4[u] = TRACK ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4u(r + 8);
@@ -424,10 +446,12 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
     const int src = __ffsll((long long)bigs) - 1;
     const int sarea = __builtin_amdgcn_readlane(area, src);
     const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
+    const uint32_t sskip = (uint32_t)__builtin_amdgcn_readlane((int)skip4, src);
     float v[RECF];
 #pragma unroll
     for (int f = 0; f < RECF; f++) v[f] = 0.f;
     for (int k = lane; k < sarea; k += 64) {
+      if (k < 4 && ((sskip >> k) & 1u)) continue;        // (an empty own pair of a 17..32-tile splat: its record was never written)
       const float* r = dtile + (size_t)(sfirst + (uint32_t)k) * RECF;
 #pragma unroll
       for (int f = 0; f < RECF; f++) v[f] += r[f];
@@ -463,6 +487,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
   for (int k = 0; k < NPOSE; k++) cg[k] = 0.f;
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   int rad = 0;
+  uint32_t cl_bits = 0;     // clamped[idx]: SH clamp bits 0-2 | (direct bins) empty-pair bits 4-7
   float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;   // first 32 bytes of this Gaussian's splat record (xy, conic, opacity)
   float px3[3] = {0.f, 0.f, 0.f}, q_raw[4] = {1.f, 0.f, 0.f, 0.f}, ls_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
   {
@@ -470,8 +495,9 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
     int area = 0;
     // one round of independent loads for everything the gather needs (this kernel is a chain of memory latencies: every
     // dependent step costs ~2 us).  A culled Gaussian has rect = 0 (and an unwritten splat record, read but never used).
-    uint32_t r0 = 0, r1 = 0, toff = 0, btile = 0;
+    uint32_t r0 = 0, r1 = 0, toff = 0, btile = 0, clb = 0;
     if (idx < P) {
+      clb = g.clamped[idx];
       // the Gaussian's own parameters depend on nothing but idx: requested with the first round, they land while the records are
       // gathered (the chain rule below used to start with a memory round trip of its own)
 #pragma unroll
@@ -494,7 +520,8 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       const bool fits = DIRECT ? (toff + (uint32_t)area <= cam.trec_cap) : true;
       if (!fits || (size_t)first + (size_t)area > (size_t)N_cap) area = 0;      // beyond the capacity (flagged by the forward): nothing was written
     }
-    gather_tile_records<TRACK>(area, first, dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F, acc0, acc1, acc2);
+    gather_tile_records<TRACK>(area, first, dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F, acc0, acc1, acc2, DIRECT ? (clb >> 4) : 0u);
+    cl_bits = clb;
   }
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -586,7 +613,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       if (out.d_xyz || ma.on) {
 #pragma unroll
         for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2];
-        const uint8_t cl = g.clamped[idx];
+        const uint32_t cl = cl_bits;
         dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;
         dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
         dfd[2] = (cl & 4) ? 0.f : SH_C0F * dc2;

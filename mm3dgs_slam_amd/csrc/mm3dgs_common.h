@@ -70,15 +70,19 @@ struct ImageView {
   uint32_t* subcount;    // [16T]
   float* final_T;        // [H*W]
   uint32_t* n_contrib;   // [H*W]
-  uint32_t* tile_order;  // [8 * ceil(T / 8)]: workgroup -> tile + 1 (valid while hdr->tile_order_tiles == T): binning.hip tile_order_kernel
+  uint32_t* tile_order;  // [max(8 * ceil(T / 8), 8 * TILE_SPAN_SLOTS)]: workgroup -> tile + 1 (valid while hdr->tile_order_tiles == tile_order_key(H, W)): binning.hip tile_order_kernel
   size_t zero_bytes;     // hdr + tile_count: cleared at the start of every forward
 };
 static inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+// SLAM compositors with the load-balanced tile table: every XCD owns TILE_SPAN_SLOTS workgroup slots (blockIdx = 8 i + x, i < TILE_SPAN_SLOTS),
+// of which its load-cut span of tiles fills the first ones (binning.hip tile_order_kernel)
+#define TILE_SPAN_SLOTS 256
+static inline size_t tile_order_words(size_t T) { size_t n = ((T + 7) / 8) * 8; return n > 8 * TILE_SPAN_SLOTS ? n : (size_t)8 * TILE_SPAN_SLOTS; }
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +
-         align_up(px * 4, 256) + align_up(px * 4, 256) + align_up(((T + 7) / 8) * 8 * 4, 256);
+         align_up(px * 4, 256) + align_up(px * 4, 256) + align_up(tile_order_words(T) * 4, 256);
 }
 static inline ImageView image_view(void* base, int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;

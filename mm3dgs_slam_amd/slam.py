@@ -132,6 +132,7 @@ class SyntheticSequence:
         self.tstamps = [i * self.dt_cam for i in range(n_frames)]
         self.tf = {"c2i": torch.eye(4)}          # camera and IMU frames coincide in the synthetic rig
         self._imu = {}
+        self._est = {}
 
     def __len__(self):
         return len(self.frames)
@@ -139,6 +140,17 @@ class SyntheticSequence:
     def __getitem__(self, i):
         color, depth = self.frames[i]
         return color, depth, self.poses[i]
+
+    def est(self, i):
+        """A stand-in for the monocular network's output on frame i (slam/SLAM.py:392-396): inverse-depth-like, arbitrary scale and
+        offset, a smooth multiplicative error of a few percent -- what the per-frame least-squares alignment has to undo."""
+        if i not in self._est:
+            _, d = self.frames[i]
+            H, W = d.shape
+            yy, xx = torch.meshgrid(torch.arange(H, device=d.device).float(), torch.arange(W, device=d.device).float(), indexing="ij")
+            wobble = 1.0 + 0.03 * torch.sin(xx / 37.0 + 0.3 * i) * torch.cos(yy / 29.0)
+            self._est[i] = (1000.0 / (torch.where(d > 0, d, torch.full_like(d, 3.0)) * wobble + 0.5)).contiguous()
+        return self._est[i]
 
     def imu(self, i):
         """Synthetic IMU rows for the interval (frame i-1, frame i], in the layout utils/pose_utils.py:179-180 reads (angular
@@ -220,16 +232,26 @@ class SLAM:
                 self.mapper.update_covisibility_graph(k)
 
     def step(self, idx):
-        """Track + map one frame (the unit the headline metric counts)."""
+        """Track + map one frame (the unit the headline metric counts).  Without sensor depth (`use_gt_depth: false`, configs/TUM.yml:8)
+        and with a sequence that provides a monocular estimate (`sequence.est(idx)`: the network is out of scope, its output is an input),
+        the frame follows slam/SLAM.py:392-463: the tracker gets the raw estimate, then the map is rendered once at the tracked pose and
+        the estimate is fitted to it by least squares (depth_utils.scale_depth_estimate); the mapper seeds from / regresses on that."""
         color, depth, gt_pose = self.seq[idx]
+        mono = (not self.cfg["use_gt_depth"]) and hasattr(self.seq, "est")
+        est = self.seq.est(idx) if mono else depth
         if idx == 0 or self.cfg["tracking"]["use_gt_pose"]:
             self.estimate_pose_list[idx] = gt_pose.clone()
         else:
             imu = self.seq.imu(idx) if (self.cfg["tracking"].get("dynamics_model") or "").lower() == "imu" else None
-            self.tracker.run_frame(idx, color, depth, depth, imu_meas=imu)
+            self.tracker.run_frame(idx, color, depth, est, imu_meas=imu)
+        est_scaled = depth
+        if mono:
+            from .depth_utils import scale_depth_estimate
+            est_scaled = scale_depth_estimate(self.cfg, idx, est, depth, lambda: self.mapper._render_depth_sil(self.estimate_pose_list[idx]),
+                                              resumed="iteration" in self.cfg)
         if idx == 0:
-            self.mapper.camera_extent = float(depth.max()) / self.cfg["scene_radius_depth_ratio"]
-        self.mapper.run_frame(idx, color, depth, depth)
+            self.mapper.camera_extent = float((est_scaled if mono else depth).max()) / self.cfg["scene_radius_depth_ratio"]
+        self.mapper.run_frame(idx, color, depth, est_scaled)
         self.gt_pose_list[idx] = gt_pose.detach().clone()
 
     def run(self, progress=None, reraise=False):

@@ -240,3 +240,23 @@ def test_g10_save_results_writes_the_reference_key_set_and_values(tmp_path):
     for kf, c, p, d, none in zip(kf_read, F["sr_kf_gt_color"], F["sr_kf_est_pose"], F["sr_kf_gt_depth"], F["sr_kf_est_depth_is_none"]):
         assert torch.is_tensor(kf["gt_color"]) and np.array_equal(kf["gt_color"].numpy(), c) and np.array_equal(kf["est_pose"].numpy(), p)
         assert np.array_equal(kf["gt_depth"].numpy(), d) and (kf["est_depth"] is None) == bool(none)
+
+
+# ---- G11: per-frame depth alignment (utils/depth_utils.py:44-99 executed by tests/golden/make_golden_depth.py) -------------------------
+def test_g11_depth_alignment_matches_the_reference_least_squares():
+    """`use_gt_depth: false` (configs/TUM.yml:8): slam/SLAM.py:411-448 fits the monocular estimate to the rendered depth every frame.
+    depth_utils.get_scale_shift_LS (masked normal equations, nothing leaves the device) against the reference's gather + torch.inverse
+    version: scale and shift to 2e-4 relative (both are float32 solves of a 2 x 2 system with condition number ~1e6), the scaled
+    depth image they produce to 1e-3."""
+    from mm3dgs_slam_amd.depth_utils import get_scale_shift_LS
+    F = np.load(os.path.join(HERE, "golden", "g11_depth_align.npz"))
+    for k in range(3):
+        est, depth, mask = (torch.from_numpy(F[f"c{k}_{n}"]) for n in ("est", "depth", "mask"))
+        scale, shift = get_scale_shift_LS(est, depth, mask)
+        rs, rt = float(F[f"c{k}_scale"].reshape(-1)[0]), float(F[f"c{k}_shift"].reshape(-1)[0])
+        assert abs(float(scale) - rs) <= 2e-4 * abs(rs), (k, float(scale), rs)
+        assert abs(float(shift) - rt) <= 2e-4 * abs(rt) + 1e-6, (k, float(shift), rt)
+        scaled = 1.0 / (scale * est + shift)
+        ref = torch.from_numpy(F[f"c{k}_scaled"])
+        ok = mask & torch.isfinite(ref) & (ref.abs() < 50)
+        assert ((scaled - ref).abs()[ok] <= 1e-3 * ref.abs()[ok] + 1e-4).all(), k

@@ -832,7 +832,7 @@ def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed
         T = ((W + 15) // 16) * ((H + 15) // 16)
         up = lambda v: (v + 255) // 256 * 256
         off = 256 + up(T * 4) + up((T + 1) * 4) + up(T * 4) + up(T * 16 * 4) + 2 * up(H * W * 4)
-        n = (T + 7) // 8 * 8
+        n = max((T + 7) // 8 * 8, 8 * 256)          # (round 4: every XCD owns 256 workgroup slots, its load-cut span fills the first ones)
         table = e.img_state[off:off + 4 * n].view(torch.int32).cpu().numpy()
         valid = int(e.img_state[36:40].view(torch.int32).cpu()[0])
         state = dict(xyz=g._xyz.detach().clone(), op=g._opacity.detach().clone(), sc=g._scaling.detach().clone(), fdc=g._features_dc.detach().clone(),
@@ -845,6 +845,12 @@ def test_load_balanced_tile_table_is_a_permutation_and_changes_nothing_but_speed
         assert valid == (H << 16 | W)
         assert sorted(int(v) for v in table if v) == list(range(1, T + 1)), "not a permutation of the tiles"
         assert int((table == 0).sum()) == len(table) - T
+        # every XCD's span is contiguous in tile order, the spans follow each other, and each fills its XCD's first slots
+        per_xcd = [sorted(int(v) - 1 for v in table[x::8] if v) for x in range(8)]
+        for x, tl in enumerate(per_xcd):
+            assert tl == list(range(tl[0], tl[0] + len(tl))), x
+            assert all(int(v) != 0 for v in table[x::8][:len(tl)]) and all(int(v) == 0 for v in table[x::8][len(tl):]), x
+        assert [tl[0] for tl in per_xcd] == [0] + [per_xcd[x - 1][-1] + 1 for x in range(1, 8)]
         b, _, valid_off, _ = run("1", H, W)
         assert valid_off == 0                        # (fresh engine, never written)
         for k in a:

@@ -457,3 +457,42 @@ def test_checkpoints_results_and_resume_in_the_reference_formats(tmp_path):
     n_before = g1._xyz.shape[0]
     again.step(0)       # frame 0 of a resumed run does NOT reseed every pixel (slam/mapper.py:409-418: `"iteration" not in cfg`)
     assert again.gaussians._xyz.shape[0] < n_before + 0.5 * 32 * 48
+
+
+def test_frames_without_sensor_depth_align_the_monocular_estimate_to_the_map_every_frame():
+    """`use_gt_depth: false` (what configs/TUM.yml:8 ships): slam/SLAM.py:392-463 hands the raw monocular estimate to the tracker, renders
+    the map once at the tracked pose, fits the estimate to it by least squares and gives the mapper the rescaled depth.  SLAM.step does
+    the same when the sequence provides an estimate (SyntheticSequence.est: a stand-in for the network, which is out of scope): frame 0
+    takes the reference's arbitrary first-frame scale, later frames must land on the MAP's scale -- whatever that is -- to a few percent."""
+    import random
+    import numpy as np
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.depth_utils import scale_depth_estimate
+    from mm3dgs_slam_amd.renderer import Renderer
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    from oracle.raster_ref import RefRasterizer
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    cfg = default_config(device="cpu", height=32, width=48, use_gt_depth=False, tracking={"iters": 3}, mapping={"iters": 4, "kf_every": 1, "min_covisibility": 2.0})
+    seq = SyntheticSequence(cfg, 3, 600, seed=5, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
+    slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer)
+    seen = []
+    real = slam.mapper.run_frame
+    slam.mapper.run_frame = lambda idx, color, depth, est_scaled, *a, **k: (seen.append(est_scaled.clone()), real(idx, color, depth, est_scaled, *a, **k))[1]
+    for i in range(3):
+        slam.step(i)
+    color, depth, _ = seq[0]
+    # frame 0: 1 / (est + 0.001) * png_depth_scale / 10 (slam/SLAM.py:428-434) -- here about half the true depth; the map lives at that scale
+    assert torch.allclose(seen[0], 1.0 / (seq.est(0) + 0.001) * 500.0)
+    assert float(slam.mapper.camera_extent) == float(seen[0].max()) / cfg["scene_radius_depth_ratio"]
+    # later frames: the rescaled estimate agrees with the depth the map renders at the tracked pose
+    for i in (1, 2):
+        d, sil = slam.mapper._render_depth_sil(slam.estimate_pose_list[i])
+        m = (sil > 0.99) & (seq[i][1] > 0)
+        assert int(m.sum()) > 100
+        rel = ((seen[i] - d).abs() / d)[m]
+        assert float(rel.median()) < 0.05, float(rel.median())
+    # and the map was seeded from the rescaled estimate, not from the sensor depth (half scale: z well below the sensor's 1.5 m minimum)
+    assert float(slam.gaussians.get_xyz[:, 2].median()) < 0.8 * float(depth[depth > 0].median())
+    # a direct call reproduces what the frame used
+    again = scale_depth_estimate(cfg, 2, seq.est(2), seq[2][1], lambda: slam.mapper._render_depth_sil(slam.estimate_pose_list[2]))
+    assert torch.isfinite(again).all()
