@@ -147,6 +147,12 @@ typedef struct Mm3dgsSlamInputs {
   const float* scaling;   /* [P,3] log-scales                                                            */
   const float* rotation;  /* [P,4] raw quaternions (w,x,y,z)                                             */
   int32_t isotropic;      /* pipeline.force_isotropic (slam/renderer.py:167-168)                         */
+  int32_t world_means;    /* 0: pipeline.transform_means_python (the shipped configs): the means are moved to the camera frame, the
+                             rasterizer's view matrix is the identity and the Gaussians' covariances keep their WORLD orientation
+                             (slam/renderer.py:142-153,171-173); 1: transform_means_python: false (:117-124): world-frame means under
+                             the full view matrix -- the covariance is rotated into the view, the pose gradient also flows through that
+                             rotation, and the depth bundle takes the reference's literal z' = (w2c^T [x; 1])_z of :207-214 (the
+                             transposed matrix: third COLUMN of R, no translation)                          */
 } Mm3dgsSlamInputs;
 
 typedef struct Mm3dgsSlamGrads {

@@ -27,7 +27,7 @@ class Mm3dgsHeader(C.Structure):
 
 class Mm3dgsSlamInputs(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("xyz", C.c_void_p), ("f_dc", C.c_void_p), ("opacity", C.c_void_p),
-                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("isotropic", C.c_int32)]
+                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("isotropic", C.c_int32), ("world_means", C.c_int32)]
 
 
 class Mm3dgsSlamGrads(C.Structure):

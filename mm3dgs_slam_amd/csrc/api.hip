@@ -206,7 +206,7 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
 static SlamIn slam_in(const Mm3dgsSlamInputs* in) {
   SlamIn s;
   s.pose = in->pose; s.xyz = in->xyz; s.f_dc = in->f_dc; s.opacity = in->opacity; s.scaling = in->scaling;
-  s.rotation = in->rotation; s.isotropic = in->isotropic;
+  s.rotation = in->rotation; s.isotropic = in->isotropic; s.world = in->world_means;
   return s;
 }
 static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in) {

@@ -84,8 +84,20 @@ struct RawGaussian { float x[3], q[4], ls[3], fd[3], op; };
 
 // projection of a Gaussian whose raw parameters are already in registers (loaded by slam_project_one, or just stepped by the map's
 // in-kernel Adam: slam_bwd_project_kernel)
+// world: Mm3dgsSlamInputs.world_means (transform_means_python: false): the same camera-space mean p = R x + t, but the EWA projection runs
+// under the full view matrix (covariance rotated by R) and the depth bundle carries the reference's literal z' (third column of R . x)
+__device__ __forceinline__ void pose_view_matrix(const PoseDev& ps, float V[16]) {      // row-vector convention: V = w2c^T
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) V[i * 4 + j] = ps.R[j][i];
+    V[i * 4 + 3] = 0.f;
+    V[12 + i] = ps.t[i];
+  }
+  V[15] = 1.f;
+}
 __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool live, int idx, const float* __restrict__ pose, bool isotropic,
-                                                       const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g) {
+                                                       const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g, bool world = false) {
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(pose);
@@ -108,7 +120,13 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
     float S3[3][3], R[3][3], sm[3], qn[4], qinv;
     slam_cov3d_vals(q_raw, ls_raw, isotropic, cam.scale_modifier, S3, R, sm, qn, qinv);
     Ewa e;
-    ewa_project(cam, Vi, p, S3, e);
+    if (world) {
+      float V[16];
+      pose_view_matrix(ps, V);
+      ewa_project(cam, V, rg.x, S3, e);
+    } else {
+      ewa_project(cam, Vi, p, S3, e);
+    }
     float det = e.a * e.c - e.b * e.b;
     float px = ((hx * pw + 1.f) * cam.W - 1.f) * 0.5f;
     float py = ((hy * pw + 1.f) * cam.H - 1.f) * 0.5f;
@@ -130,7 +148,9 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
         o.cl = (c0 < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u);
         g.clamped[idx] = (uint8_t)o.cl;
+        // (the depth the tiles are SORTED by is the view depth p[2] in both modes; zc is the value the depth bundle composites)
         const float z = p[2];
+        const float zc = world ? ps.R[0][2] * rg.x[0] + ps.R[1][2] * rg.x[1] + ps.R[2][2] * rg.x[2] : p[2];
         const float op = 1.f / (1.f + expf(-op_raw));
         float4* sp = (float4*)(g.splat + (size_t)idx * SPLAT_F);
         o.sA = make_float4(px, py, e.c * dinv, -e.b * dinv); o.sB = make_float4(e.a * dinv, op, fmaxf(c0, 0.f), fmaxf(c1, 0.f));
@@ -138,7 +158,7 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         sp[1] = o.sB;
         o.br = block_rect(o.sA, o.sB, o.r0, o.r1);
         o.nblk = (uint32_t)(o.br.bw * o.br.bh);
-        sp[2] = make_float4(fmaxf(c2, 0.f), z, 1.f, z * z);
+        sp[2] = make_float4(fmaxf(c2, 0.f), zc, 1.f, zc * zc);
         g.depth[idx] = z;
         o.z = z;
       }
@@ -167,7 +187,7 @@ __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, 
     for (int k = 0; k < 3; k++) { rg.ls[k] = in.scaling[(size_t)idx * 3 + k]; rg.fd[k] = in.f_dc[(size_t)idx * 3 + k]; }
     rg.op = in.opacity[idx];
   }
-  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g);
+  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g, in.world != 0);
 }
 
 __global__ void __launch_bounds__(FB)
@@ -469,7 +489,7 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 // stepped: (the map's in-kernel Adam, ma.on) the lane's parameters AFTER the step -- what the next iteration's projection reads
-template <bool TRACK, bool DIRECT>
+template <bool TRACK, bool DIRECT, bool WORLD = false>
 __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
                                               uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
                                               const MapAdam& ma, RawGaussian* stepped, const uint32_t* __restrict__ ovf) {
@@ -557,7 +577,15 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       float S3[3][3], R[3][3], sm[3], qn[4], qinv;
       slam_cov3d_vals(q_raw, ls_raw, in.isotropic != 0, cam.scale_modifier, S3, R, sm, qn, qinv);
       Ewa e;
-      ewa_project(cam, Vi, p, S3, e);
+      constexpr bool world = WORLD;       // (a template parameter: the shipped configurations' instantiations keep their registers)
+      if (world) {
+        float V[16];
+        pose_view_matrix(ps, V);
+        const float xw[3] = {x0, x1, x2};
+        ewa_project(cam, V, xw, S3, e);
+      } else {
+        ewa_project(cam, Vi, p, S3, e);
+      }
       const float a = e.a, b = e.b, c = e.c;
       const float det = a * c - b * b, id2 = 1.f / (det * det);
       const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
@@ -587,8 +615,22 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       for (int r = 0; r < 2; r++)
 #pragma unroll
         for (int j = 0; j < 3; j++) dA[r][j] = 2.f * (GA[r][0] * S3[0][j] + GA[r][1] * S3[1][j] + GA[r][2] * S3[2][j]);
-      // view = identity: dJ[r][k] = dA[r][k]
-      const float dJ00 = dA[0][0], dJ02 = dA[0][2], dJ11 = dA[1][1], dJ12 = dA[1][2];
+      // transform mode: view = identity, dJ[r][k] = dA[r][k].  World mode: A = J R  ->  dJ = dA R^T, and the pose's rotation receives
+      // dR[k][i] += sum_r J[r][k] dA[r][i]  (J = [[J00, 0, J02], [0, J11, J12]]) -- the "-w-pose" gradient through the view matrix
+      float dJ00 = dA[0][0], dJ02 = dA[0][2], dJ11 = dA[1][1], dJ12 = dA[1][2];
+      float dRc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      if (world) {
+        dJ00 = dA[0][0] * ps.R[0][0] + dA[0][1] * ps.R[0][1] + dA[0][2] * ps.R[0][2];
+        dJ02 = dA[0][0] * ps.R[2][0] + dA[0][1] * ps.R[2][1] + dA[0][2] * ps.R[2][2];
+        dJ11 = dA[1][0] * ps.R[1][0] + dA[1][1] * ps.R[1][1] + dA[1][2] * ps.R[1][2];
+        dJ12 = dA[1][0] * ps.R[2][0] + dA[1][1] * ps.R[2][1] + dA[1][2] * ps.R[2][2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          dRc[0][i] = e.J00 * dA[0][i];
+          dRc[1][i] = e.J11 * dA[1][i];
+          dRc[2][i] = e.J02 * dA[0][i] + e.J12 * dA[1][i];
+        }
+      }
       const float tz = e.t[2], itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
       float dm[3];
       dm[0] = e.in_x ? -cam.focal_x * itz2 * dJ02 : 0.f;
@@ -604,15 +646,23 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       const float dhx = gnx * pw, dhy = gny * pw, dhw = -(gnx * hx + gny * hy) * pw * pw;
 #pragma unroll
       for (int i = 0; i < 3; i++) dm[i] += PV[i * 4 + 0] * dhx + PV[i * 4 + 1] * dhy + PV[i * 4 + 3] * dhw;
-      dm[2] += dz_tot;
+      if (!world) dm[2] += dz_tot;          // transform mode: the depth bundle's z IS the camera-space z
       // pose: means_cam = R x + t
       cg[0] = dm[0] * x0; cg[1] = dm[0] * x1; cg[2] = dm[0] * x2;
       cg[3] = dm[1] * x0; cg[4] = dm[1] * x1; cg[5] = dm[1] * x2;
       cg[6] = dm[2] * x0; cg[7] = dm[2] * x1; cg[8] = dm[2] * x2;
       cg[9] = dm[0]; cg[10] = dm[1]; cg[11] = dm[2];
+      if (world) {
+        // + the covariance's rotation, + the depth bundle's z' = R[0][2] x0 + R[1][2] x1 + R[2][2] x2
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+          for (int i = 0; i < 3; i++) cg[k * 3 + i] += dRc[k][i];
+        cg[2] += dz_tot * x0; cg[5] += dz_tot * x1; cg[8] += dz_tot * x2;
+      }
       if (out.d_xyz || ma.on) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2];
+        for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2] + (world ? dz_tot * ps.R[j][2] : 0.f);
         const uint32_t cl = cl_bits;
         dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;
         dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
@@ -712,12 +762,12 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
   }
 }
 
-template <bool TRACK, bool DIRECT>
+template <bool TRACK, bool DIRECT, bool WORLD>
 __global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
                            const uint32_t* __restrict__ ovf) {
-  slam_bwd_body<TRACK, DIRECT>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+  slam_bwd_body<TRACK, DIRECT, WORLD>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 // A mapping iteration's backward projection + Adam step and the NEXT iteration's projection + binning in one launch (direct bins, in-kernel
@@ -727,6 +777,7 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
 // iteration k + 1; the bins and cursors were released by iteration k's sort; the per-tile records it sums were written by iteration k's
 // compositor and are not touched again before iteration k + 1's.
 static_assert(SLAM_BWD_FB == FB, "the fused backward + projection kernel uses one lane per Gaussian in both halves");
+template <bool WORLD>
 __global__ void __launch_bounds__(FB)
 slam_bwd_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t N_cap,
                         const float* __restrict__ dsub, SlamGrads out, MapAdam ma, const float* __restrict__ next_pose, uint32_t cap,
@@ -738,8 +789,8 @@ slam_bwd_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
   const int idx = blockIdx.x * FB + tid;
   RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
-  slam_bwd_body<false, true>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg, &iv.hdr->overflow);
-  const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g);
+  slam_bwd_body<false, true, WORLD>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg, &iv.hdr->overflow);
+  const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g, WORLD);
   slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
 }
 
@@ -749,8 +800,12 @@ void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t
   if (P <= 0) return;
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const int T = cam.gx * cam.gy;
-  hipLaunchKernelGGL(slam_bwd_project_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, ncap, bw.dsub, out, ma,
-                     next_pose, bin_cap, rec_cap, slot_bits);
+  if (in.world)
+    hipLaunchKernelGGL(slam_bwd_project_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, ncap, bw.dsub, out, ma,
+                       next_pose, bin_cap, rec_cap, slot_bits);
+  else
+    hipLaunchKernelGGL(slam_bwd_project_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, ncap, bw.dsub, out, ma,
+                       next_pose, bin_cap, rec_cap, slot_bits);
 }
 
 // One wave: fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through
@@ -922,8 +977,10 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
   float* partial = want_pose ? bw.campartial : nullptr;
   if (P > 0) {
     const bool map = out.d_xyz || ma.on;
-    auto kern = map ? (direct ? slam_preprocess_bwd_kernel<false, true> : slam_preprocess_bwd_kernel<false, false>)
-                    : (direct ? slam_preprocess_bwd_kernel<true, true> : slam_preprocess_bwd_kernel<true, false>);
+    auto kern = in.world ? (map ? (direct ? slam_preprocess_bwd_kernel<false, true, true> : slam_preprocess_bwd_kernel<false, false, true>)
+                                : (direct ? slam_preprocess_bwd_kernel<true, true, true> : slam_preprocess_bwd_kernel<true, false, true>))
+                         : (map ? (direct ? slam_preprocess_bwd_kernel<false, true, false> : slam_preprocess_bwd_kernel<false, false, false>)
+                                : (direct ? slam_preprocess_bwd_kernel<true, true, false> : slam_preprocess_bwd_kernel<true, false, false>));
     hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
   }
   if (want_pose)

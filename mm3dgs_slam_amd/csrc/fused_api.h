@@ -5,6 +5,7 @@
 struct SlamIn {
   const float* pose; const float* xyz; const float* f_dc; const float* opacity; const float* scaling; const float* rotation;
   int isotropic;
+  int world;     // Mm3dgsSlamInputs.world_means
 };
 struct SlamGrads {
   float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation;

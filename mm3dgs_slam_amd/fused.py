@@ -72,18 +72,24 @@ class FusedEngine:
     @staticmethod
     def eligible(cfg, gaussians):
         pipe = cfg["pipeline"]
-        ok = (pipe["transform_means_python"] and not pipe["convert_SHs_python"] and not pipe["compute_cov3D_python"]
-              and gaussians.max_sh_degree == 0 and str(cfg["device"]).startswith("cuda"))
+        # SH: what matters is the ACTIVE degree.  The reference never raises it during SLAM (oneupSHdegree is not called on the path;
+        # only a map loaded from a checkpoint starts at max_sh_degree), so a model with `mapping.sh_degree` > 0 still renders
+        # SH_C0 f_dc + 0.5 -- in the kernel or, with `convert_SHs_python`, in Python (slam/renderer.py:179-193: at degree 0 the viewing
+        # direction does not enter) -- while its f_rest rows ride along through seeding / pruning with zero gradients (torch's Adam
+        # leaves a zero-gradient parameter with zero moments where it is).  The native loops do exactly that (round 4).
+        # transform_means_python: false (world-frame means, pose gradient through the view matrix) runs natively too: Mm3dgsSlamInputs.world_means
+        # (with the reference's literal depth bundle; this repository's optional `fix_depth_transpose` only exists in the torch-graph renderer)
+        fixed_depth = (not pipe["transform_means_python"]) and pipe.get("fix_depth_transpose", False)
+        ok = (not pipe["compute_cov3D_python"] and not fixed_depth and gaussians.active_sh_degree == 0 and str(cfg["device"]).startswith("cuda"))
         if not ok and str(cfg["device"]).startswith("cuda"):
             # (the fallback is ~30x slower and used to be silent)
-            why = ", ".join(w for w, bad in (("pipeline.transform_means_python: false", not pipe["transform_means_python"]),
-                                             ("pipeline.convert_SHs_python: true", pipe["convert_SHs_python"]),
-                                             ("pipeline.compute_cov3D_python: true", pipe["compute_cov3D_python"]),
-                                             (f"sh_degree {gaussians.max_sh_degree} > 0", gaussians.max_sh_degree != 0)) if bad)
+            why = ", ".join(w for w, bad in (("pipeline.compute_cov3D_python: true", pipe["compute_cov3D_python"]),
+                                             ("pipeline.fix_depth_transpose", fixed_depth),
+                                             (f"active SH degree {gaussians.active_sh_degree} > 0", gaussians.active_sh_degree != 0)) if bad)
             if why not in FusedEngine._warned:
                 FusedEngine._warned.add(why)
                 import warnings
-                warnings.warn(f"mm3dgs: this configuration ({why}) is outside the native SLAM loops (shipped configs: transform_means_python, SH degree 0); "
+                warnings.warn(f"mm3dgs: this configuration ({why}) is outside the native SLAM loops (covariances from scales + rotations, active SH degree 0); "
                               "tracking and mapping run the torch-graph loops around the generic HIP rasterizer -- correct, but about 30x slower")
         return ok
 
@@ -138,6 +144,7 @@ class FusedEngine:
         si.xyz, si.f_dc, si.opacity = g._xyz.data_ptr(), g._features_dc.data_ptr(), g._opacity.data_ptr()
         si.scaling, si.rotation = g._scaling.data_ptr(), g._rotation.data_ptr()
         si.isotropic = self.isotropic
+        si.world_means = 0 if self.r.cfg["pipeline"]["transform_means_python"] else 1
         return si
 
     def forward(self, pose, g, need_grads=False):

@@ -104,7 +104,7 @@ def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     assert np.allclose(after, G["rng_after"]), (after, G["rng_after"])
 
 
-@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"])
+@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])
 def test_native_loop_orchestration_reproduces_the_reference_classes(variant, monkeypatch):
     """The HOST side of the native loops (mm3dgs_slam_amd/fused.py: FusedTracker / FusedMapper) against the same reference
     trajectories, with tests/cpu_engine.py executing the documented semantics of the C-ABI loops on CPU (through the very structs,

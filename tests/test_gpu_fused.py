@@ -208,7 +208,7 @@ def _setup_slam_like(P, H, W, iso, seed):
     return cfg, g, Renderer(cfg), pose, color.to(DEV), depth.to(DEV)
 
 
-def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, slam_like=False, iso=False):
+def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, slam_like=False, iso=False, world=False):
     """rel-L2 errors of the native SLAM path (pose transform, activations, depth bundle, compositors, chain rules: one fused forward +
     backward) against the float64 CPU oracle driven through the torch-graph Renderer.  direct: second render of the engine (direct bins)
     instead of its first (packed bins).  floor: also the errors of the ORACLE evaluated in float32 against itself in float64 on the same
@@ -223,8 +223,12 @@ def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, sl
     from mm3dgs_slam_amd.renderer import Renderer
     from oracle.raster_ref import RefRasterizer
     cfg, g, R, pose, color, depth = _setup_slam_like(P, H, W, iso, seed) if slam_like else _setup(P=P, H=H, W=W, seed=seed)
+    if world:      # pipeline.transform_means_python: false (slam/renderer.py:117-124): world-frame means under the full view matrix
+        cfg["pipeline"]["transform_means_python"] = False
+        assert R.cfg["pipeline"]["transform_means_python"] is False
     eng = FusedEngine(R)
     si = eng.forward(pose, g, need_grads=True)
+    assert si.world_means == (1 if world else 0)
     assert eng.check_capacity()
     if direct:
         si = eng.forward(pose, g, need_grads=True)
@@ -315,10 +319,13 @@ def test_pose_gradient_on_slam_like_scenes_matches_float64_oracle():
     assert sum(1 for _, _, m in rows if m["d_pose"] <= 1e-5) >= 10, [m["d_pose"] for _, _, m in rows]
 
 
-@pytest.mark.parametrize("seed,direct", [(0, False), (0, True), (3, True)])
-def test_fused_path_matches_float64_oracle(seed, direct):
-    """The fused kernels against the float64 CPU oracle: the strongest statement of parity for the SLAM path (packed and direct bins)."""
-    m = native_vs_oracle(seed, direct)
+@pytest.mark.parametrize("seed,direct,world", [(0, False, False), (0, True, False), (3, True, False), (0, True, True), (3, False, True), (5, True, True)])
+def test_fused_path_matches_float64_oracle(seed, direct, world):
+    """The fused kernels against the float64 CPU oracle: the strongest statement of parity for the SLAM path (packed and direct bins).
+    world: `transform_means_python: false` natively (round 4) -- world-frame means, the covariance rotated into the view, the pose
+    gradient through the view matrix as well (the oracle side differentiates viewmatrix / projmatrix / campos through the torch graph of
+    slam/renderer.py:117-124), the depth bundle with the reference's transposed matrix (:207-214)."""
+    m = native_vs_oracle(seed, direct, world=world)
     assert m["img"] <= pu.IMG_TOL, m
     assert m["d_pose"] <= 1e-5, m          # north_star: pose gradients <= 1e-5
     for k, v in m.items():

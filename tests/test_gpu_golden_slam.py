@@ -92,7 +92,7 @@ def run_variant(variant, verbose=False, prefix="g9"):
 
 
 @pytest.mark.parametrize("prefix", ["g9", "g9L"])
-@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"])
+@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])
 def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, prefix):
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
     from tests import g9_util

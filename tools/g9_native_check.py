@@ -14,7 +14,7 @@ if __name__ == "__main__":
     prefix = "g9"
     if "--large" in sys.argv:
         sys.argv.remove("--large"); prefix = "g9L"
-    for variant in (sys.argv[1:] or ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg"]):
+    for variant in (sys.argv[1:] or ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"]):
         try:
             slam, G, rows = run_variant(variant, verbose=True, prefix=prefix)
         except Exception as e:      # keep going: this is a survey
