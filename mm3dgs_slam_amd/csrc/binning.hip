@@ -275,11 +275,14 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
 // advance together: sum over the four 8x8 sub-tiles of the longest of their four block lists) -- from whatever view was rendered last;
 // the table is a permutation whatever the loads are, so a stale or meaningless load only costs speed.  One workgroup per XCD.
 #define ORDER_MAX_PER 160     // five rounds of 32 CU slots: beyond that the workgroups of a launch are placed dynamically
-// Round 4: the eight spans are cut by LOAD, not by tile count.  On a camera that moves, keyframes seed the newly seen side of the image and
-// the tile lists there grow: with equal-count spans one XCD carried 1.05 - 1.11 x the mean wave steps (tools/xcd_balance.py, the bench's
-// `moving` scenario; 1.02 - 1.03 on the bounded trajectory) and the launch ends when IT is done.  The spans stay contiguous in tile order
-// (L2 locality) but hold equal wave steps (max / mean 1.005); a span may then hold up to TILE_SPAN_SLOTS tiles, the compositors launch
-// 8 x TILE_SPAN_SLOTS workgroups and the ones beyond an XCD's span leave at once.  Every workgroup of this kernel reads all T loads (5 KB).
+// Round 4 experiment, measured and NOT adopted (-DMM3DGS_ORDER_LOAD_SPANS, tools/build_variant.sh): the eight spans cut by LOAD instead of
+// by tile count.  On a camera that moves, keyframes seed the newly seen side of the image and the tile lists there grow: with equal-count
+// spans one XCD carries 1.05 - 1.11 x the mean wave steps (tools/xcd_balance.py on the bench's `moving` scenario; 1.02 - 1.03 on the bounded
+// trajectory), load-cut contiguous spans bring that to 1.005 (a span then holds up to TILE_SPAN_SLOTS tiles, the compositors launch
+// 8 x TILE_SPAN_SLOTS workgroups and the ones beyond an XCD's span leave at once).  On the MI355X the two builds are indistinguishable on the
+// bounded trajectory (31.33 vs 31.32 frames/s under rocprofv3) and the load-cut one is 1.2 % SLOWER on the moving one (42.16 vs 41.67 ms per
+// frame): as with round 3's variants of the dealing, a launch's duration does not follow the per-XCD / per-CU sum of wave steps closely
+// enough for a better model balance to show.  The default stays: equal-count spans, the launch's grid = the tiles.
 __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, uint32_t key) {
   __shared__ uint32_t pre[8 * ORDER_MAX_PER + 1];        // inclusive prefix of the loads in tile order, pre[-1] = 0 at pre[0]
   __shared__ uint32_t load[TILE_SPAN_SLOTS];
@@ -322,6 +325,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   uint32_t base = incl - mine_sum;
   for (int q = 0; q < wv; q++) base += wsum[q];
   const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  (void)total;
   if (tid == 0) pre[0] = 0u;
   {
     uint32_t run = base;
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   if (tid < 9) {
     int c = tid == 8 ? T : 0;
     if (tid > 0 && tid < 8) {
-#if defined(MM3DGS_ORDER_EQUAL_SPANS)                  // developer experiment: round 3's equal-count spans
+#if !defined(MM3DGS_ORDER_LOAD_SPANS)                  // default: equal-count spans (the arithmetic map's spans)
       c = min(T, tid * ((T + 7) >> 3));
 #else
       const unsigned long long want = (unsigned long long)total * (unsigned)tid;      // pre[c] * 8 >= total * k
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   load[j] = mine;
   __syncthreads();
   // the slots of this XCD beyond its span: no tile
-  for (int i = per + tid; i < TILE_SPAN_SLOTS; i += 256) iv.tile_order[(size_t)i * 8 + x] = 0u;
+  for (int i = per + tid; i < slam_span_slots(T); i += 256) iv.tile_order[(size_t)i * 8 + x] = 0u;
   if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
   if (j >= per) return;
   int rank = 0;                                        // descending load, ties by index: a permutation of [0, per)

@@ -61,7 +61,12 @@ __device__ __forceinline__ int slam_tile(const CamDev& cam, const ImageView& iv,
 // workgroups of a SLAM compositor launch: with the tile table every XCD gets TILE_SPAN_SLOTS slots (its load-cut span may hold more than T / 8 tiles)
 static inline int slam_grid(const CamDev& cam, int T) {
   const int n = ((T + 7) / 8) * 8;
+#if defined(MM3DGS_ORDER_LOAD_SPANS)
   return (cam.tile_table && T >= 64 && (T + 7) / 8 <= 160) ? 8 * TILE_SPAN_SLOTS : n;
+#else
+  (void)cam;
+  return n;
+#endif
 }
 
 // identical instruction sequence in forward and backward so both take the same skip decisions

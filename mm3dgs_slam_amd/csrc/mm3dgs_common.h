@@ -79,6 +79,14 @@ static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 // of which its load-cut span of tiles fills the first ones (binning.hip tile_order_kernel)
 #define TILE_SPAN_SLOTS 256
 static inline size_t tile_order_words(size_t T) { size_t n = ((T + 7) / 8) * 8; return n > 8 * TILE_SPAN_SLOTS ? n : (size_t)8 * TILE_SPAN_SLOTS; }
+// workgroup slots per XCD that the table covers: the equal-count spans' ceil(T / 8), or TILE_SPAN_SLOTS in the load-cut experiment build
+static inline __host__ __device__ int slam_span_slots(int T) {
+#if defined(MM3DGS_ORDER_LOAD_SPANS)
+  (void)T; return TILE_SPAN_SLOTS;
+#else
+  return (T + 7) >> 3;
+#endif
+}
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +

@@ -91,6 +91,16 @@ def run_variant(variant, verbose=False, prefix="g9"):
 # optical axis is barely constrained, and the reference's own arithmetic re-run by the torch-graph loops on CPU drifts from it by 6e-3 there.
 
 
+# Round 4: the same runs at 160x120 (g9L_*: 80 tiles, 6.4 - 17 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6; every native variant incl. the
+# two that became native this round, sh2_python and no_transform).  At this size threshold decisions flip from the first mapping loop on
+# (18 k seeded Gaussians pruned at opacity 0.4625: a handful always sit within rounding of the threshold), so "the maps still have the
+# same rows" rarely lasts.  What two float32 programs can agree on here was measured by re-running the REFERENCE-side arithmetic itself --
+# this repository's torch-graph loops over the same CPU oracle, 7 instead of 6 / 8 OpenMP threads, i.e. other summation orders
+# (tools/g9_cpu_check.py --large, profiles/r04_g9L_cpu_float32_floor.txt): map size off by 32 - 74 of 8.5 k (0.4 - 0.9 %) from frame 0 on,
+# camera matrices 2e-4 .. 1.5e-3 (bundle adjustment 6e-3), map moments up to 8.5e-3.  The HIP loops stay INSIDE that floor: map size within
+# 28 (0.3 %), cameras 3e-6 .. 7e-5 while the rows agree and <= 2.7e-3 afterwards (bundle adjustment 6e-3 at frame 7), moments <= 3e-3;
+# keyframes, covisibility graph and the three RNG streams identical in all nine variants.  Bars for g9L: rows aligned -> camera 1e-4,
+# moments 5e-4; afterwards camera 5e-3 (bundle adjustment 1e-2), moments 1e-2; map size within 0.5 %.
 @pytest.mark.parametrize("prefix", ["g9", "g9L"])
 @pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])
 def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, prefix):
@@ -104,18 +114,28 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, pr
         assert r["keyframes"] == want_kf[idx], (idx, r["keyframes"], want_kf[idx])
         assert abs(r["P"] - r["P_ref"]) <= max(2, 0.005 * r["P_ref"]), (idx, r["P"], r["P_ref"])
         aligned = aligned and r["P"] == r["P_ref"]
-        if idx == 0:
+        large = prefix == "g9L"
+        if idx == 0 and not large:
             assert aligned
         loose_ba = variant == "ba" and idx >= 3
-        bar = 1e-2 if loose_ba else (((5e-4 if variant in ("ba", "white_bg") else 1e-4) if aligned else 1e-3))
+        if large:
+            bar = 1e-2 if loose_ba else ((5e-4 if variant in ("ba", "white_bg") else 1e-4) if aligned else 5e-3)
+        else:
+            # (no_transform: in that mode the pose gradient carries the covariance-rotation terms too, which largely cancel over the map; its
+            #  float32 floor is ~10x the camera-frame mode's -- tests/test_gpu_fused.py, world-frame population -- and the runs separate
+            #  sooner: 7.7e-6 after the first tracked frame, 1.1e-4 after the second, against 5e-9 / 2e-8 for sh2_python on the same frames)
+            bar = 1e-2 if loose_ba else (((5e-4 if variant in ("ba", "white_bg", "no_transform") else 1e-4) if aligned else 1e-3))
         assert r["pose_diff"] < bar, (idx, r["pose_diff"], bar)
-        tol = 1e-4 if (aligned and not loose_ba) else 5e-3
+        if large:
+            tol = 5e-4 if (aligned and not loose_ba) else 1e-2
+        else:
+            tol = (5e-4 if variant == "no_transform" else 1e-4) if (aligned and not loose_ba) else 5e-3
         assert np.all(np.abs(r["moments"] - r["moments_ref"]) <= tol + tol * np.abs(r["moments_ref"])), (idx, r["moments"], r["moments_ref"])
     graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
     assert graph == [str(s) for s in G["graph"]]
     for kf, ref in zip(slam.mapper.keyframes, G["keyframe_poses"]):
         d = (get_camera_from_tensor(kf.pose.detach().cpu().float()) - get_camera_from_tensor(torch.from_numpy(ref))).abs().max()
-        assert d < (1e-2 if variant == "ba" else 5e-4), (kf.idx, float(d))
+        assert d < (1e-2 if variant == "ba" else (5e-3 if prefix == "g9L" else 5e-4)), (kf.idx, float(d))
     # the final map as a population (rows are no longer aligned once a single pruning decision differs)
     g = slam.gaussians
     for name, t in (("xyz", g._xyz), ("opacity", g._opacity), ("scaling", g._scaling), ("rotation", g._rotation), ("f_dc", g._features_dc)):
