@@ -498,7 +498,8 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
   // dropped pairs WITHOUT writing their per-tile records: the sums below would read stale scratch.  Such an iteration is void -- no
   // gradient, no statistics, no optimiser step (zero gradients would still move the parameters by their momentum) -- so a loop whose
   // header is only read at a later drained point (fused.py: lazy checks) leaves the map exactly as the last complete iteration left it.
-  const bool skip = ovf != nullptr && *ovf != 0u;
+  // (requested here, consumed only after the gather below: nothing waits for it)
+  const uint32_t ovf_word = ovf != nullptr ? __builtin_nontemporal_load(ovf) : 0u;
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(in.pose);
@@ -525,14 +526,14 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
 #pragma unroll
       for (int k = 0; k < 4; k++) q_raw[k] = in.rotation[(size_t)idx * 4 + k];
       op_raw = in.opacity[idx];
-      rad = skip ? 0 : radii[idx];
+      rad = radii[idx];
       r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
       toff = g.tileoff[idx];
       if (!DIRECT) btile = g.block_tiles[idx >> 8];
       const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
       sA = spl[0]; sB = spl[1];
     }
-    if (r1 != r0 && !skip) {   // <=> radii > 0
+    if (r1 != r0) {   // <=> radii > 0
       area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
       // first per-tile record of this Gaussian's pairs (contiguous, row-major over its tile rectangle): direct bins -- inside its
       // projection workgroup's span; packed bins -- its Gaussian-major pair index
@@ -543,6 +544,8 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
     gather_tile_records<TRACK>(area, first, dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F, acc0, acc1, acc2, DIRECT ? (clb >> 4) : 0u);
     cl_bits = clb;
   }
+  const bool skip = ovf_word != 0u;
+  if (skip) rad = 0;        // void iteration: whatever the gather read (stale records of dropped pairs) is never used
   if (idx < P) {
     float dxyz[3] = {0.f, 0.f, 0.f}, dfd[3] = {0.f, 0.f, 0.f}, dls[3] = {0.f, 0.f, 0.f}, dqr[4] = {0.f, 0.f, 0.f, 0.f};
     float dlogit = 0.f, gnorm = 0.f;
@@ -825,7 +828,9 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < 7; i++) { pcur[i] = 0.f; am[i] = 0.f; av[i] = 0.f; prior[i] = 0.f; }
   int step0 = 0;
+  uint32_t ovf_word = 0u;
   if (k == 0) {
+    if (ovf) ovf_word = *ovf;                           // (requested with the rest of lane 0's state: nothing waits for it)
 #pragma unroll
     for (int i = 0; i < 4; i++) pin[i] = pose_in[i];    // the quaternion the render used (chain rule)
     if (ad.prior) {
@@ -949,7 +954,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
     }
     if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
     // (an iteration whose forward overflowed its capacity is void, see slam_bwd_body: the pose keeps its value AND its Adam state)
-    if (ad.pose && !(ovf != nullptr && *ovf != 0u)) {
+    if (ad.pose && ovf_word == 0u) {
       const int t = step0 + 1;
       *ad.step = t;
       // scalars in double, rounded once to float (torch.optim.Adam does this arithmetic on Python floats)

@@ -20,13 +20,15 @@ def get_scale_shift_LS(est_depth, render_depth, mask=None):
         inv = torch.where(mask, inv, torch.zeros_like(inv))
     valid = inv > 0
     vf = valid.to(est_depth.dtype)
-    H = torch.stack([(est_depth * vf).reshape(-1), vf.reshape(-1)], dim=1)          # zero rows where invalid
-    z = torch.where(valid, inv, torch.zeros_like(inv)).reshape(-1, 1)
-    A = H.t() @ H
-    b = H.t() @ z
-    det = A[0, 0] * A[1, 1] - A[0, 1] * A[1, 0]
-    scale = (A[1, 1] * b[0] - A[0, 1] * b[1]) / det
-    shift = (A[0, 0] * b[1] - A[1, 0] * b[0]) / det
+    # normal equations H^T H x = H^T z with H = [est, 1] over the valid pixels, as five masked sums (a [2, HW] x [HW, 2] product is a
+    # skinny GEMM: 0.56 ms per call at 640x480 through hipBLASLt -- measured in the first round-4 trace -- against ~10 us per reduction)
+    h = est_depth * vf
+    z = torch.where(valid, inv, torch.zeros_like(inv))
+    a00, a01, a11 = (h * h).sum(), h.sum(), vf.sum()
+    b0, b1 = (h * z).sum(), z.sum()
+    det = a00 * a11 - a01 * a01
+    scale = ((a11 * b0 - a01 * b1) / det).reshape(1)
+    shift = ((a00 * b1 - a01 * b0) / det).reshape(1)
     return scale, shift
 
 

@@ -5,10 +5,12 @@ collapsed into a handful of C-ABI calls with no host synchronisation inside the 
     mm3dgs_slam_forward  ->  mm3dgs_loss  ->  mm3dgs_slam_backward ( -> pose Adam on device | mm3dgs_adam )
 
 ``FusedTracker`` / ``FusedMapper`` subclass the torch-graph ``Tracker`` / ``Mapper`` and take over ``optimize_cam`` /
-``optimize_map`` when the pipeline is the one both shipped configs use (``transform_means_python``, SH degree 0 -- the
-reference never raises it --, no python SH / cov3D); the IMU residual, bundle adjustment and the ``method: splatam`` losses
-and pruning schedule run natively too.  Anything else (``keep_best_candidate``, BA with a sharded window) falls back to the
-torch-graph loop, which stays the parity reference for these kernels (tests/test_gpu_fused.py).
+``optimize_map`` whenever the covariances come from scales + rotations and the ACTIVE SH degree is 0 (the reference never
+raises it): both branches of ``transform_means_python`` (round 4: world-frame means natively), models that carry SH rows,
+``convert_SHs_python``, the IMU residual, bundle adjustment -- also with a sharded mapping window (round 4) -- and the
+``method: splatam`` losses and pruning schedule.  What is left (``compute_cov3D_python``, a resumed checkpoint with an active
+SH degree > 0, ``keep_best_candidate``) falls back to the torch-graph loop with a warning; that loop stays the parity
+reference for these kernels (tests/test_gpu_fused.py).
 """
 from __future__ import annotations
 

@@ -2,7 +2,7 @@
 # Idle time between consecutive kernels of the SLAM loops from a rocprofv3 kernel trace (GPU box, repo root).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/p_gap
-rocprofv3 --kernel-trace --output-format csv -d /tmp/p_gap -o kt -- python bench.py --steps 2 --warmup 1 --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --no-cpu-baseline --profile 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_gap -o kt -- python bench.py --steps 2 --warmup 1 --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --mono-frames 0 --no-cpu-baseline --profile 0 > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/p_gap/**/*kernel_trace.csv", recursive=True)[0]

@@ -3,7 +3,7 @@
 # either side (GPU box, repo root).    bash tools/idle_trace.sh [extra bench args]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/p_idle; mkdir -p /tmp/p_idle
-rocprofv3 --kernel-trace --output-format csv -d /tmp/p_idle -o kt -- python bench.py --steps 6 --warmup 2 --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --no-cpu-baseline --profile 0 "$@" > /tmp/p_idle/bench.json 2>/tmp/p_idle/bench.log
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_idle -o kt -- python bench.py --steps 6 --warmup 2 --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --mono-frames 0 --no-cpu-baseline --profile 0 "$@" > /tmp/p_idle/bench.json 2>/tmp/p_idle/bench.log
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/p_idle/**/*kernel_trace.csv", recursive=True)[0]

@@ -9,7 +9,7 @@ TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG; mkdir -p $OUT
 # the counter passes run the bench's OWN default steps / warm-up (the same frames, the same map state as the line they annotate)
-SHORT="--no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --profile 0"
+SHORT="--no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --mono-frames 0 --profile 0"
 # pmc_pass <workload tag> <per-kernel | pass> <bench args...>: FETCH_SIZE and WRITE_SIZE in their own passes -> $OUT/<tag>_pmc_<counter>.csv
 pmc_pass() {
   local W=$1 MODE=$2; shift 2
@@ -50,7 +50,7 @@ pmc_pass slam kernel $SHORT
 # the bench line below replays these counters as roofline.traffic
 python bench.py 2>$OUT/bench.err | tee $OUT/bench.json | cut -c1-300
 # same command as the bench line (minus the follow-up runs), so the per-kernel averages are over the same frames as roofline.avg_launch_us
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 > $OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python bench.py --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --moving-frames 0 --mono-frames 0 > $OUT/bench_under_rocprof.json 2>/dev/null
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 # counters of the other workloads (their bench lines below replay THEIR OWN files; round 3 replayed the configs[1] counters everywhere)
 if [ -z "${SKIP_OTHER_PMC:-}" ]; then
@@ -58,7 +58,7 @@ if [ -z "${SKIP_OTHER_PMC:-}" ]; then
   pmc_pass c4 kernel --workload c4 --steps 5 --warmup 2 $SHORT
   pmc_pass c5_pass pass --workload c5 --steps 5 --warmup 2 --no-cpu-baseline
 fi
-python bench.py --workload c3 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 2>/dev/null | tee $OUT/bench_c3.json | cut -c1-300
+python bench.py --workload c3 --no-cpu-baseline --full-seed-steps 0 --steady-frames 0 --mono-frames 0 2>/dev/null | tee $OUT/bench_c3.json | cut -c1-300
 python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_c4.json | cut -c1-300
 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_c5.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o c5 -- python bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
