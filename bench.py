@@ -266,6 +266,7 @@ def main():
     import torch.distributed as dist
     if world > 1 or args.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")       # (no version banner on stdout: the driver reads ONE JSON line there)
         if world == 1:
             import socket
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -294,11 +295,18 @@ def main():
         torch.cuda.synchronize()
 
     def finish(out, failures=()):
-        if rank == 0:
-            print(json.dumps(out))
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio (buffered on a pipe, flushed at exit --
+        # after a line printed from Python), so the group is torn down and C stdio flushed first
         if collective:
             dist.barrier()
             dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        if rank == 0:
+            print(json.dumps(out), flush=True)
         if failures:           # a multi-GPU line whose self-check failed must not look like a measurement
             log("MULTI-GPU SELF-CHECK FAILED: " + "; ".join(failures))
             sys.exit(3)
