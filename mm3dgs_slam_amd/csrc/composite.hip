@@ -436,6 +436,19 @@ struct SepReduce2 {
 //         -- the chain rule of the depth bundle folded into the reduction -- and dopacity = M0 / opacity (10 floats, not 12).
 // MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
 // (a device function: the tracking loop runs it in the same launch as the sort and the forward compositor, see below)
+#ifdef MM3DGS_BWD_OLD_INDEX      // developer A/B (tools/build_variant.sh): the separate LDS array of record indices
+#define BWD_OLD_INDEX 1
+#else
+#define BWD_OLD_INDEX 0
+#endif
+// u = o dL/dalpha G with two selects (a_eff, G_eff).  Measured alternative (-DMM3DGS_BWD_NEW_U): ONE select of the un-clamped o G, alpha =
+// min(0.99, .) of it, u = dL/dalpha (o G) -- two instructions less per (row, splat) step, six registers less, and 1.3 us SLOWER (62.6 vs 61.0 us,
+// tools/ab_lib.sh): the select moves into the dependent chain alpha -> 1 - alpha -> rcp -> T that every step waits on.
+#ifdef MM3DGS_BWD_NEW_U
+#define BWD_OLD_U 0
+#else
+#define BWD_OLD_U 1
+#endif
 #define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * STG_N + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
 template <int C, int MODE>
 __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
@@ -566,11 +579,14 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
   {
     const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
-    const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+    SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+    // SLAM modes: the entry's gradient-record index rides in the staged record's constant field (C.z = the "1" of [z, 1, z^2]): one LDS
+    // read and its address less per (row, splat) step than a separate index array
+    if constexpr (MODE != 0 && !BWD_OLD_INDEX) r0.C.z = __uint_as_float(e0.y);
     stg[0][wv][0][slane] = r0.A;
     stg[0][wv][1][slane] = r0.B;
     if (C > 2) stg[0][wv][2][slane] = r0.C;
-    stgi[0][wv][lane] = e0.y;
+    if constexpr (MODE == 0 || BWD_OLD_INDEX) stgi[0][wv][lane] = e0.y;
   }
   uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
@@ -581,28 +597,34 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   auto run_chunks = [&](auto z45_tag) {
   constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
-    const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
+    SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
+    if constexpr (MODE != 0 && !BWD_OLD_INDEX) rec_n.C.z = __uint_as_float(ent_nxt.y);
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
     const float4 (*wS)[STG_N] = stg[cur][wv];
     const int r16i = row * 16;
     const int r16 = row * STG_ROW;
     const uint32_t* wI = stgi[cur][wv];
-    auto pair_of = [&](int j) { return wI[r16i + j]; };
+    auto pair_of = [&](int j) { return (MODE == 0 || BWD_OLD_INDEX) ? wI[r16i + j] : 0u; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
-    auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti, const int j) {
+    auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti_in, const int j) {
+      const uint32_t ti = (MODE == 0 || BWD_OLD_INDEX) ? ti_in : __float_as_uint(Cc.z);
       const bool row_on = base + (uint32_t)j < todo;          // this row still has an entry at this step
       const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the row's list (garbage when !row_on)
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
       const float G = SPLAT_EXP(power);
-      const float alpha = fminf(0.99f, B.y * G);
+      const float araw = B.y * G;
+      const float alpha = fminf(0.99f, araw);
       const bool valid = row_on && (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       float tot = 0.f;
       n_visit++;
       if (MODE != 0 || __ballot(valid) != 0ull) {   // SLAM modes: four rows with different splats -- a whole-wave miss is rare, the vote is not worth its cost
         n_red++;
-        const float a_eff = valid ? alpha : 0.f;
+        // SLAM modes: ONE select -- the un-clamped o G where the splat counts, 0 elsewhere: alpha = min(0.99, .) of it (min(0.99, 0) = 0) and
+        // u = dL/dalpha (o G) directly (generic mode also needs G alone for the opacity gradient)
+        const float raw_eff = valid ? araw : 0.f;
+        const float a_eff = (MODE == 0 || BWD_OLD_U) ? (valid ? alpha : 0.f) : fminf(0.99f, raw_eff);
         const float G_eff = valid ? G : 0.f;
         // generic mode: correctly rounded division -- T is rebuilt by ~50 successive divisions per pixel and the 1-ulp v_rcp_f32
         // showed up as 5e-6 of noise on every gradient (camera gradients are held to 1e-5); the SLAM modes keep v_rcp_f32
@@ -618,7 +640,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         if constexpr (C > 1) col[1] = B.w;
         if constexpr (C > 2) col[2] = Cc.x;
         if constexpr (C > 3) col[3] = Cc.y;
-        if constexpr (C > 4) col[4] = Cc.z;
+        if constexpr (C > 4) col[4] = (MODE == 0 || BWD_OLD_INDEX) ? Cc.z : 1.f;      // (SLAM modes: that field carries the record index; the channel is the constant 1)
         if constexpr (C > 5) col[5] = Cc.w;
         // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
         // (behind_dot) instead of C running colours: qd = c . dL;  dLa = qd - behind_dot;  behind_dot += a (qd - behind_dot)
@@ -630,7 +652,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         const float dLa = diff * Tr - Tf_bg * r;
         // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
         // into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
-        const float u = B.y * dLa * G_eff;
+        const float u = (MODE == 0 || BWD_OLD_U) ? B.y * dLa * G_eff : dLa * raw_eff;
         if constexpr (MODE == 0) {
           float vals[NV];
 #pragma unroll
@@ -686,7 +708,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     stg[cur ^ 1][wv][0][slane] = rec_n.A;
     stg[cur ^ 1][wv][1][slane] = rec_n.B;
     if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
-    stgi[cur ^ 1][wv][lane] = ent_nxt.y;
+    if constexpr (MODE == 0 || BWD_OLD_INDEX) stgi[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   };
