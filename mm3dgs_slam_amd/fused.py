@@ -490,8 +490,8 @@ class FusedMapper(Mapper):
                 return None, non_presence.reshape(depth.shape)          # (slam/mapper.py:532,590-591)
             frac = float(self.cfg["mapping"].get("seed_fraction", 1.0))
             if frac < 1.0:     # workload knob (not in the reference): seed only a fixed pseudo-random subset of the pixels
-                gen = torch.Generator(device="cpu").manual_seed(1234 + idx)
-                non_presence = non_presence & (torch.rand(non_presence.numel(), generator=gen) < frac).to(dev)
+                from .mapper import seed_subset
+                non_presence = non_presence & seed_subset(non_presence.numel(), idx, frac, dev)
             fx, fy, cx, cy = self._intr()
             P0 = int(self.gaussians.get_xyz.shape[0])
             n = self.gaussians.seed_device(gt_color, depth, non_presence.reshape(depth.shape), camera_pose, fx, fy, cx, cy)

@@ -27,6 +27,14 @@ from .pose_utils import apply_rigid, get_camera_from_tensor, rigid_inverse
 from .sh_utils import RGB2SH
 
 
+def seed_subset(n, idx, frac, dev):
+    """Workload knob `mapping.seed_fraction` (not in the reference): the fixed pseudo-random subset of a frame's pixels that may seed a
+    Gaussian, drawn on the device the map lives on (a 307 k-element draw on the host + its upload cost ~1 ms of every keyframe event)."""
+    dev = torch.device(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + int(idx))
+    return torch.rand(n, generator=gen, device=dev) < frac
+
+
 class KeyFrame:
     def __init__(self, idx, gt_color, pose, gt_depth=None, est_depth=None, niqe=None):
         self.idx, self.gt_color, self.pose, self.gt_depth, self.est_depth, self.niqe = idx, gt_color, pose, gt_depth, est_depth, niqe
@@ -223,8 +231,7 @@ class Mapper:
             return None, non_presence.reshape(depth.shape)          # (slam/mapper.py:532,590-591)
         frac = float(self.cfg["mapping"].get("seed_fraction", 1.0))
         if frac < 1.0:     # workload knob (not in the reference): seed only a fixed pseudo-random subset of the pixels
-            gen = torch.Generator(device="cpu").manual_seed(1234 + idx)
-            non_presence = non_presence & (torch.rand(non_presence.numel(), generator=gen) < frac).to(dev)
+            non_presence = non_presence & seed_subset(non_presence.numel(), idx, frac, dev)
         cld, msd = self.get_pointcloud(gt_color, depth, get_camera_from_tensor(camera_pose), mask=non_presence)
         n = cld.shape[0]
         rgb = cld[:, 3:6].float()
