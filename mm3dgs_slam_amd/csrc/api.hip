@@ -382,7 +382,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     launch_slam_bwd_project(cd, P, slam_in(in), (int32_t*)radii, g, image_view((void*)image_state, cd.H, cd.W), b, N_capacity, bw, sg, ma, fuse_next_pose,
                             db_bwd.bin_cap, db_bwd.rec_cap, db_bwd.slot_bits, s);
   } else
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on, &iv.hdr->overflow); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on, &iv.hdr->overflow, pose_finish_ticket(iv)); }
   return check_launch("slam_backward");
 }
 

@@ -449,6 +449,14 @@ struct SepReduce2 {
 #else
 #define BWD_OLD_U 1
 #endif
+// -DMM3DGS_BWD_EARLY_FIRST: the first chunk's loads (n_contrib -> list entry -> splat record, three dependent round trips) requested BEFORE the
+// loss prologue and held in registers across it.  Measured 0.9 us SLOWER (59.97 vs 59.09 us, same box, tools/ab_lib.sh): the chain's two waits
+// now sit in front of the prologue's own loads, which start two round trips later -- the latency moves, it does not overlap.
+#ifdef MM3DGS_BWD_EARLY_FIRST
+#define BWD_EARLY_FIRST 1
+#else
+#define BWD_EARLY_FIRST 0
+#endif
 #define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * STG_N + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
 template <int C, int MODE>
 __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
@@ -502,6 +510,23 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
   const float T_final = inside ? iv.final_T[pix] : 0.f;
   const uint32_t last_contributor = inside ? iv.n_contrib[pix] : 0u;
+  // nothing behind the deepest contributor of any pixel of the block matters: todo = max over the row
+  uint32_t todo = last_contributor;
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR1, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR2, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR4, 0xf, 0xf, true));
+  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR8, 0xf, 0xf, true));
+  todo = min(todo, count);
+  const uint32_t maxtodo = max(max((uint32_t)__builtin_amdgcn_readlane((int)todo, 0), (uint32_t)__builtin_amdgcn_readlane((int)todo, 16)),
+                               max((uint32_t)__builtin_amdgcn_readlane((int)todo, 32), (uint32_t)__builtin_amdgcn_readlane((int)todo, 48)));
+  // (experiment BWD_EARLY_FIRST, see above: the first chunk requested here, ahead of the loss prologue)
+  uint2 e0 = make_uint2(0u, 0u), ent_nxt = make_uint2(0u, 0u);
+  SplatRec r0;
+  if constexpr (BWD_EARLY_FIRST) {
+    e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
+    ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
+    r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+  }
   float dL[C];
   float bg_dot = 0.f;
   bool dl_done = false;
@@ -551,16 +576,6 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   float Tr = T_final;
   float behind_dot = 0.f;  // (colour accumulated behind the current list position) . dL
 
-  // nothing behind the deepest contributor of any pixel of the block matters: todo = max over the row
-  uint32_t todo = last_contributor;
-  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR1, 0xf, 0xf, true));
-  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, QP_XOR2, 0xf, 0xf, true));
-  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR4, 0xf, 0xf, true));
-  todo = max(todo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)todo, ROW_ROR8, 0xf, 0xf, true));
-  todo = min(todo, count);
-  uint32_t maxtodo = max(max((uint32_t)__builtin_amdgcn_readlane((int)todo, 0), (uint32_t)__builtin_amdgcn_readlane((int)todo, 16)),
-                         max((uint32_t)__builtin_amdgcn_readlane((int)todo, 32), (uint32_t)__builtin_amdgcn_readlane((int)todo, 48)));
-
   // entries behind `todo` receive no gradient: their records are zero
   for (uint32_t e = todo + q; e < count; e += 16) {
     zero_record<NV>(dsub + (size_t)list[e].y * RECF);
@@ -578,8 +593,10 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
 
   // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
   {
-    const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
-    SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+    if constexpr (!BWD_EARLY_FIRST) {
+      e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
+      r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+    }
     // SLAM modes: the entry's gradient-record index rides in the staged record's constant field (C.z = the "1" of [z, 1, z^2]): one LDS
     // read and its address less per (row, splat) step than a separate index array
     if constexpr (MODE != 0 && !BWD_OLD_INDEX) r0.C.z = __uint_as_float(e0.y);
@@ -588,7 +605,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     if (C > 2) stg[0][wv][2][slane] = r0.C;
     if constexpr (MODE == 0 || BWD_OLD_INDEX) stgi[0][wv][lane] = e0.y;
   }
-  uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
+  if constexpr (!BWD_EARLY_FIRST) ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
 
   // The SLAM losses leave the silhouette and depth^2 channels without gradient (dL[4] = dL[5] = 0): a wave that sees only

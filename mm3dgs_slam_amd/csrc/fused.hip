@@ -489,7 +489,7 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 // stepped: (the map's in-kernel Adam, ma.on) the lane's parameters AFTER the step -- what the next iteration's projection reads
-template <bool TRACK, bool DIRECT, bool WORLD = false>
+template <bool TRACK, bool DIRECT, bool WORLD = false, bool ROW_THROUGH = false>
 __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
                                               uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
                                               const MapAdam& ma, RawGaussian* stepped, const uint32_t* __restrict__ ovf) {
@@ -760,17 +760,10 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       float t = red[0][k];
 #pragma unroll
       for (int w = 1; w < SLAM_BWD_FB / 64; w++) t += red[w][k];
-      posepartial[(size_t)blockIdx.x * 32 + k] = t;
+      if constexpr (ROW_THROUGH) __hip_atomic_store(posepartial + (size_t)blockIdx.x * 32 + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else posepartial[(size_t)blockIdx.x * 32 + k] = t;
     }
   }
-}
-
-template <bool TRACK, bool DIRECT, bool WORLD>
-__global__ void __launch_bounds__(SLAM_BWD_FB)
-slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
-                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
-                           const uint32_t* __restrict__ ovf) {
-  slam_bwd_body<TRACK, DIRECT, WORLD>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 // A mapping iteration's backward projection + Adam step and the NEXT iteration's projection + binning in one launch (direct bins, in-kernel
@@ -811,16 +804,35 @@ void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t
                        next_pose, bin_cap, rec_cap, slot_bits);
 }
 
-// One wave: fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through
-// R(q/|q|), then (optionally) the pose Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults:
-// betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so a tracking iteration needs no host round trip.
-__global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
-                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4,
-                                        const uint32_t* __restrict__ ovf) {
-  // 1024 lanes: lane = 16 * rowgroup + column; 64 row groups keep the dependent-load chains short, then the groups are
-  // added in a fixed order (deterministic, double precision)
-  __shared__ double part[64][16];
-  __shared__ double part8[8][16];
+// b^t for a step counter t >= 1 by squaring, in double (pow() costs this one-lane code ~60 registers of the whole kernel it is inlined into)
+__device__ __forceinline__ double pow_int(double b, int t) {
+  double r = 1.0;
+  for (; t > 0; t >>= 1) { if (t & 1) r *= b; b *= b; }
+  return r;
+}
+
+// Fixed-order double-precision sum of the workgroup rows, chain rule (dR, dt) -> (dq, dt) through R(q/|q|), then (optionally) the pose
+// Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so
+// a tracking iteration needs no host round trip.  One workgroup of 16 * NG lanes: lane = 16 * rowgroup + column; NG row groups keep the
+// dependent-load chains short, then the groups are added in a fixed order (deterministic, double precision).
+struct PoseFinish {
+  const float* pose_in; float* dpose; PoseAdam ad; PoseLossScale pls; float* ad_loss4;
+  uint32_t* ticket;     // NULL: the finish runs as its own launch (slam_pose_finish_kernel)
+};
+// COHERENT: the rows were written by other workgroups of THIS launch (device-scope stores, see slam_preprocess_bwd_kernel): read them past
+// this XCD's L2
+template <bool COHERENT>
+__device__ __forceinline__ float row_load(const float* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <int NG, bool COHERENT>
+__device__ __forceinline__ void pose_finish_body(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
+                                                 float* __restrict__ dpose, const PoseAdam& ad, const PoseLossScale& pls, float* __restrict__ ad_loss4,
+                                                 const uint32_t* __restrict__ ovf) {
+  static_assert(NG % 8 == 0, "row groups are folded eight at a time");
+  __shared__ double part[NG][16];
+  __shared__ double part8[NG / 8][16];
   __shared__ double tot[16];
   const int k = threadIdx.x;
   // lane 0's pose / Adam state: requested first, lands while the rows are summed (this kernel is pure latency)
@@ -852,17 +864,17 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       // (all of a lane's rows are requested before the first one is added: with the loads inside the loop every pair of rows
       //  cost a memory round trip of its own -- 5 in a row at 157 k Gaussians -- in this one-workgroup kernel)
       int r = grp;
-      for (; r + 7 * 64 < nrows; r += 8 * 64) {
+      for (; r + 7 * NG < nrows; r += 8 * NG) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = posepartial[(size_t)(r + u * 64) * 32 + col];
+        for (int u = 0; u < 8; u++) v[u] = row_load<COHERENT>(posepartial + (size_t)(r + u * NG) * 32 + col);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
       }
       {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (r + u * 64 < nrows) ? posepartial[(size_t)(r + u * 64) * 32 + col] : 0.f;
+        for (int u = 0; u < 8; u++) v[u] = (r + u * NG < nrows) ? row_load<COHERENT>(posepartial + (size_t)(r + u * NG) * 32 + col) : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
       }
@@ -871,18 +883,18 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       // (four independent accumulators: 19 dependent loads in a row cost ~6 us of latency in this one-workgroup kernel)
       const double* lr = pls.rows + ((col - NPOSE) & 1);
       double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-      int r = grp + 64 * ((col - NPOSE) >> 1);      // columns 12/13 take rows grp + 128 k, columns 14/15 rows grp + 64 + 128 k
-      for (; r + 384 < pls.nrows; r += 512) {
-        b0 += lr[(size_t)r * 12]; b1 += lr[(size_t)(r + 128) * 12]; b2 += lr[(size_t)(r + 256) * 12]; b3 += lr[(size_t)(r + 384) * 12];
+      int r = grp + NG * ((col - NPOSE) >> 1);      // columns 12/13 take rows grp + 2 NG k, columns 14/15 rows grp + NG + 2 NG k
+      for (; r + 6 * NG < pls.nrows; r += 8 * NG) {
+        b0 += lr[(size_t)r * 12]; b1 += lr[(size_t)(r + 2 * NG) * 12]; b2 += lr[(size_t)(r + 4 * NG) * 12]; b3 += lr[(size_t)(r + 6 * NG) * 12];
       }
-      for (; r < pls.nrows; r += 128) b0 += lr[(size_t)r * 12];
+      for (; r < pls.nrows; r += 2 * NG) b0 += lr[(size_t)r * 12];
       a0 = (b0 + b1) + (b2 + b3);
     }
     part[grp][col] = a0 + a1;
   }
   __syncthreads();
-  // 64 row groups -> 8 -> 1 in a fixed order (a 64-step serial sum of dependent LDS reads cost ~2 us of pure latency)
-  if ((k >> 4) < 8) {
+  // NG row groups -> NG / 8 -> 1 in a fixed order (a 64-step serial sum of dependent LDS reads cost ~2 us of pure latency)
+  if ((k >> 4) < NG / 8) {
     double acc = 0.0;
 #pragma unroll
     for (int gq = 0; gq < 8; gq++) acc += part[(k >> 4) * 8 + gq][k & 15];
@@ -892,7 +904,7 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   if (k < 16) {
     double acc = 0.0;
 #pragma unroll
-    for (int gq = 0; gq < 8; gq++) acc += part8[gq][k];
+    for (int gq = 0; gq < NG / 8; gq++) acc += part8[gq][k];
     tot[k] = acc;
   }
   __syncthreads();
@@ -958,8 +970,8 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
       const int t = step0 + 1;
       *ad.step = t;
       // scalars in double, rounded once to float (torch.optim.Adam does this arithmetic on Python floats)
-      const double bc1 = 1.0 - pow(ad.beta1, (double)t);
-      const float bc2s = (float)sqrt(1.0 - pow(ad.beta2, (double)t));
+      const double bc1 = 1.0 - pow_int(ad.beta1, t);
+      const float bc2s = (float)sqrt(1.0 - pow_int(ad.beta2, t));
       const float omb1 = (float)(1.0 - ad.beta1), b2 = (float)ad.beta2, omb2 = (float)(1.0 - ad.beta2);
       const float ss_q = (float)(ad.lr_q / bc1), ss_t = (float)(ad.lr_t / bc1);
       for (int i = 0; i < 7; i++) {
@@ -974,23 +986,64 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
   }
 }
 
+__global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
+                                        float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4,
+                                        const uint32_t* __restrict__ ovf) {
+  pose_finish_body<64, false>(posepartial, nrows, pose_in, dpose, ad, pls, ad_loss4, ovf);
+}
+
+// The backward projection of an iteration that needs the pose gradient (every tracking iteration; mapping views under bundle adjustment).
+// fin.ticket != NULL (-DMM3DGS_POSE_FINISH_MERGED, a measured and REJECTED experiment): the workgroup that finishes last also runs the pose
+// finish -- each workgroup takes a ticket once its partial row is in memory, the holder of the last one sums the rows and takes the pose's
+// Adam step, and the one-workgroup finish launch (6.8 us, 100 per frame) disappears.  Measured on the bench's tracking iterations (157 k
+// Gaussians, 614 workgroups; tools/ab_lib.sh): with a release fence per workgroup and an acquire in the last one (an L2 write-back /
+// invalidate on this part: 8 XCDs, one L2 each) the launch takes 31.8 us against 9.1 + 6.8 for the two launches; without fences -- the
+// rows as device-scope stores written through the L2, the ticket taken after s_waitcnt vmcnt(0) + a workgroup barrier, device-scope loads
+// in the last workgroup -- 25.1 us: every workgroup's tail now waits for a store and an atomic to reach memory (~4 us), and the last
+// workgroup's 256 lanes fetch their 39 rows each past the L2.  The separate launch, whose rows come out of the L2, stays.
+template <bool TRACK, bool DIRECT, bool WORLD>
+__global__ void __launch_bounds__(SLAM_BWD_FB)
+slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
+                           const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
+                           const uint32_t* __restrict__ ovf, PoseFinish fin) {
+  if (fin.ticket) {      // (kernel-uniform)
+    slam_bwd_body<TRACK, DIRECT, WORLD, true>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+    __shared__ uint32_t last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's row stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (last) {          // (workgroup-uniform)
+      static_assert(SLAM_BWD_FB == 256, "the in-kernel pose finish uses 16 row groups of 16 columns");
+      pose_finish_body<SLAM_BWD_FB / 16, true>(posepartial, (int)gridDim.x, fin.pose_in, fin.dpose, fin.ad, fin.pls, fin.ad_loss4, ovf);
+      if (threadIdx.x == 0) *fin.ticket = 0u;
+    }
+  } else {
+    slam_bwd_body<TRACK, DIRECT, WORLD, false>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+  }
+}
+
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4, bool direct, const uint32_t* ovf) {
+                                const PoseLossScale* pls, float* loss4, bool direct, const uint32_t* ovf, uint32_t* ticket) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
+  const PoseLossScale none = {nullptr, 0, 0.f, nullptr};
+#ifndef MM3DGS_POSE_FINISH_MERGED     // developer experiment, measured and rejected (see slam_preprocess_bwd_kernel): the finish in the last workgroup
+  ticket = nullptr;
+#endif
+  const bool merged = want_pose && ticket != nullptr && P > 0;
   if (P > 0) {
     const bool map = out.d_xyz || ma.on;
     auto kern = in.world ? (map ? (direct ? slam_preprocess_bwd_kernel<false, true, true> : slam_preprocess_bwd_kernel<false, false, true>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, true> : slam_preprocess_bwd_kernel<true, false, true>))
                          : (map ? (direct ? slam_preprocess_bwd_kernel<false, true, false> : slam_preprocess_bwd_kernel<false, false, false>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, false> : slam_preprocess_bwd_kernel<true, false, false>));
-    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
+    PoseFinish fin = {in.pose, dpose, ad, pls ? *pls : none, loss4, merged ? ticket : nullptr};
+    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf, fin);
   }
-  if (want_pose)
-  {
-    PoseLossScale none = {nullptr, 0, 0.f, nullptr};
+  if (want_pose && !merged) {
     // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds
     //  twice as many float rows)
     hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? (P + SLAM_BWD_FB - 1) / SLAM_BWD_FB : 0, in.pose, dpose, ad,

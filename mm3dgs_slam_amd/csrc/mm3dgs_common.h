@@ -92,6 +92,9 @@ static inline size_t image_bytes_impl(int H, int W) {
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +
          align_up(px * 4, 256) + align_up(px * 4, 256) + align_up(tile_order_words(T) * 4, 256);
 }
+// The header block is 256 bytes, Mm3dgsHeader its first words; word 32 is library-private: the ticket counter of the in-kernel pose finish
+// (fused.hip slam_preprocess_bwd_kernel), zero between launches like the rest of the zero-initialised state.
+static inline uint32_t* pose_finish_ticket(const struct ImageView& v);
 static inline ImageView image_view(void* base, int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   char* c = (char*)base;
@@ -107,6 +110,8 @@ static inline ImageView image_view(void* base, int H, int W) {
   v.tile_order = (uint32_t*)c;
   return v;
 }
+static_assert(sizeof(Mm3dgsHeader) <= 128, "word 32 of the header block is the pose-finish ticket");
+static inline uint32_t* pose_finish_ticket(const ImageView& v) { return (uint32_t*)v.hdr + 32; }
 
 // what Mm3dgsHeader.tile_order_tiles holds while image_state's workgroup -> tile table is valid: the image size it was built for (the
 // table sits behind final_T / n_contrib, so its offset depends on H * W, not on the tile count alone); 0 = no table
