@@ -29,12 +29,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t* src, uint32_t* dst
     uint32_t v = (i < n) ? src[i] : 0u;
     if (clear_src && i < n) src[i] = 0u;   // leave the counters zero for the next forward (persistent state buffers)
     local_max = max(local_max, v);
-    uint32_t x = v;  // inclusive scan inside the wave
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t y = __shfl_up(x, off, 64);
-      if (lane >= off) x += y;
-    }
+    const uint32_t x = wave_scan_incl(v);  // inclusive scan inside the wave
     if (lane == 63) wave_tot[wv] = x;
     __syncthreads();
     uint32_t prefix = *carry_s;
@@ -154,12 +149,7 @@ __device__ __forceinline__ uint32_t block256_excl_scan_inplace(uint32_t* a, int 
   const int lo = min(tid * per, n), hi = min(lo + per, n);
   uint32_t sum = 0, mx = 0;
   for (int i = lo; i < hi; i++) { const uint32_t v = a[i]; sum += v; mx = max(mx, v); }
-  uint32_t x = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
-  }
+  const uint32_t x = wave_scan_incl(sum);
   if (lane == 63) wave_tot[wv] = x;
   if (maxv) atomicMax(maxv, mx);
   __syncthreads();
@@ -314,12 +304,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
     mine_sum += m;
   }
   // exclusive scan of the per-thread sums over the workgroup
-  uint32_t incl = mine_sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += y;
-  }
+  const uint32_t incl = wave_scan_incl(mine_sum);
   if (lane == 63) wsum[wv] = incl;
   __syncthreads();
   uint32_t base = incl - mine_sum;

@@ -50,12 +50,7 @@ __global__ void __launch_bounds__(1024) compact_scan_kernel(int nb, uint32_t* __
   for (int base = 0; base < nb; base += 1024) {
     const int i = base + tid;
     const uint32_t v = i < nb ? block_counts[i] : 0u;
-    uint32_t x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t y = __shfl_up(x, off, 64);
-      if (lane >= off) x += y;
-    }
+    const uint32_t x = wave_scan_incl(v);
     if (lane == 63) wtot[wv] = x;
     __syncthreads();
     uint32_t pre = carry;

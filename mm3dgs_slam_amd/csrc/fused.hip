@@ -213,12 +213,7 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
       __shared__ uint32_t wtot[FB / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
       __shared__ uint32_t wtot2[FB / 64];
-      uint32_t x = (uint32_t)area, x2 = nblk;   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
-        if (ln >= off) { x += y; x2 += y2; }
-      }
+      const uint32_t x = wave_scan_incl((uint32_t)area), x2 = wave_scan_incl(nblk);   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
       if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
       __syncthreads();
       uint32_t pre = 0, pre2 = 0;
@@ -307,12 +302,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   c.idbits = (uint32_t)idx << slot_bits;
   {   // workgroup-local exclusive scan of the gradient records (4x4 blocks of the block rectangles) + the workgroup's pairs
     __shared__ uint32_t wtot[FB / 64], wtot2[FB / 64];
-    uint32_t x = pr.nblk, x2 = (uint32_t)c.area;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
-      if (lane >= off) { x += y; x2 += y2; }
-    }
+    const uint32_t x = wave_scan_incl(pr.nblk), x2 = wave_scan_incl((uint32_t)c.area);
     if (lane == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
     __syncthreads();                      // (also orders the histogram clear before sweep 1)
     uint32_t pre = 0, pre2 = 0;
@@ -385,12 +375,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
       if (++ttx == c.minx + c.w) { ttx = c.minx; tty++; }
     }
   }
-  uint32_t incl = (uint32_t)max(c.area - OWN, 0);
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += y;
-  }
+  const uint32_t incl = wave_scan_incl((uint32_t)max(c.area - OWN, 0));
   const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   if (S) {   // wave-uniform
     __shared__ uint32_t s_pref[FB / 64][64];
@@ -1001,11 +986,19 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 // rows as device-scope stores written through the L2, the ticket taken after s_waitcnt vmcnt(0) + a workgroup barrier, device-scope loads
 // in the last workgroup -- 25.1 us: every workgroup's tail now waits for a store and an atomic to reach memory (~4 us), and the last
 // workgroup's 256 lanes fetch their 39 rows each past the L2.  The separate launch, whose rows come out of the L2, stays.
+#ifdef MM3DGS_POSE_FINISH_MERGED
+#define POSE_FINISH_PARAM , PoseFinish fin
+#define POSE_FINISH_ARG(x) , x
+#else      // (the default build's kernel does not even carry the argument: its 150 bytes of kernarg cost the 9 us launch 1.3 us)
+#define POSE_FINISH_PARAM
+#define POSE_FINISH_ARG(x)
+#endif
 template <bool TRACK, bool DIRECT, bool WORLD>
 __global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
-                           const uint32_t* __restrict__ ovf, PoseFinish fin) {
+                           const uint32_t* __restrict__ ovf POSE_FINISH_PARAM) {
+#ifdef MM3DGS_POSE_FINISH_MERGED
   if (fin.ticket) {      // (kernel-uniform)
     slam_bwd_body<TRACK, DIRECT, WORLD, true>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
     __shared__ uint32_t last;
@@ -1018,9 +1011,10 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
       pose_finish_body<SLAM_BWD_FB / 16, true>(posepartial, (int)gridDim.x, fin.pose_in, fin.dpose, fin.ad, fin.pls, fin.ad_loss4, ovf);
       if (threadIdx.x == 0) *fin.ticket = 0u;
     }
-  } else {
-    slam_bwd_body<TRACK, DIRECT, WORLD, false>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+    return;
   }
+#endif
+  slam_bwd_body<TRACK, DIRECT, WORLD, false>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
@@ -1041,7 +1035,8 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
                          : (map ? (direct ? slam_preprocess_bwd_kernel<false, true, false> : slam_preprocess_bwd_kernel<false, false, false>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, false> : slam_preprocess_bwd_kernel<true, false, false>));
     PoseFinish fin = {in.pose, dpose, ad, pls ? *pls : none, loss4, merged ? ticket : nullptr};
-    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf, fin);
+    (void)fin;
+    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf POSE_FINISH_ARG(fin));
   }
   if (want_pose && !merged) {
     // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds

@@ -101,11 +101,7 @@ __device__ __forceinline__ void gather_records(int area, uint32_t goff, uint32_t
       __shared__ float s_acc[NTHREADS / 64][64][12];
       const bool own = isbig && area > 0;
       uint32_t incl = own ? (uint32_t)nblk : 0u;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += y;
-      }
+      incl = wave_scan_incl(incl);
       const uint32_t S = __builtin_amdgcn_readlane(incl, 63);
       s_pref[wvq][lane] = incl;
       int* par = s_par[wvq][lane];

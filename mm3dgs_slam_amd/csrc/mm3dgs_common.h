@@ -87,6 +87,28 @@ static inline __host__ __device__ int slam_span_slots(int T) {
   return (T + 7) >> 3;
 #endif
 }
+#ifdef __HIPCC__
+// Inclusive prefix sum over the 64 lanes of a wave on the VALU's own crossbars: four shifted adds inside each 16-lane row (row_shr with
+// zero fill), then the last lane of row 0 / row 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31) -- six
+// DPP adds instead of six ds_bpermute round trips through the LDS crossbar (26 ns of latency each, tools/ubench) plus their selects.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+#ifdef MM3DGS_SCAN_BPERMUTE
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+  return x;
+#else
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);     // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);     // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);     // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);     // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+  return x;
+#endif
+}
+#endif
+
 static inline size_t image_bytes_impl(int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +

@@ -134,12 +134,7 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       __shared__ uint32_t wtot[PP_BLOCK / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
       __shared__ uint32_t wtot2[PP_BLOCK / 64];
-      uint32_t x = (uint32_t)area, x2 = nblk;   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t y = __shfl_up(x, off, 64), y2 = __shfl_up(x2, off, 64);
-        if (ln >= off) { x += y; x2 += y2; }
-      }
+      const uint32_t x = wave_scan_incl((uint32_t)area), x2 = wave_scan_incl(nblk);   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
       if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
       __syncthreads();
       uint32_t pre = 0, pre2 = 0;

@@ -44,6 +44,60 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
   }
 }
 
+// ---- in-register bitonic sort of one 64-key run per wave ------------------------------------------------------------
+// The partner of a compare-exchange at distance J comes through the VALU's own lane crossbars instead of the LDS one (ds_bpermute_b32:
+// 26 ns of latency per dependent step, 10 ns of LDS pipe per instruction at 4 waves per SIMD; v_mov_b32_dpp: 2 ns, tools/ubench): distances
+// 1, 2 (quad_perm) and 8 (row_ror:8) are one DPP move per dword, 4 is two (mirror of the 8-lane half, then of the quads), 16 and 32 are
+// gfx950's v_permlane16_swap / v_permlane32_swap of two copies of the dword (-DMM3DGS_SORT_BPERMUTE: the ds_bpermute exchanges, as before
+// round 4).  Any correct network yields the same order (keys are unique).
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_dpp(uint32_t v) {
+  static_assert(J == 1 || J == 2 || J == 4 || J == 8, "distances inside a 16-lane row");
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);         // quad_perm:[1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm:[2,3,0,1]
+  else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
+  else {
+    const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);                              // row_half_mirror: i -> 7 - i
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);                                 // quad_perm:[3,2,1,0]: -> i ^ 4
+  }
+}
+template <int J>
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long key, int lane) {
+#ifdef MM3DGS_SORT_BPERMUTE
+  return __shfl_xor(key, J, 64);
+#else
+  uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  if constexpr (J <= 8) {
+    lo = lane_xor_dpp<J>(lo); hi = lane_xor_dpp<J>(hi);
+  } else if constexpr (J == 16) {
+    // [0]: the even rows' values in both rows of a pair, [1]: the odd rows' (rows = 16 lanes)
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    lo = (lane & 16) ? a[0] : a[1]; hi = (lane & 16) ? b[0] : b[1];
+  } else {
+    static_assert(J == 32, "wave64");
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    lo = (lane & 32) ? a[0] : a[1]; hi = (lane & 32) ? b[0] : b[1];
+  }
+  return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+template <int K, int J>
+__device__ __forceinline__ unsigned long long bitonic_step64(unsigned long long key, int lane) {
+  const unsigned long long other = lane_xor64<J>(key, lane);
+  const bool up = (lane & K) == 0, lower = (lane & J) == 0;
+  const bool take_min = lower == up;
+  const bool other_less = other < key;
+  key = (take_min == other_less) ? other : key;
+  if constexpr (J > 1) return bitonic_step64<K, J / 2>(key, lane);
+  else return key;
+}
+template <int K = 2>
+__device__ __forceinline__ unsigned long long wave_bitonic_sort64(unsigned long long key, int lane) {
+  key = bitonic_step64<K, K / 2>(key, lane);
+  if constexpr (K < 64) return wave_bitonic_sort64<2 * K>(key, lane);
+  else return key;
+}
+
 #define RANK_SORT_MAX 1024  // lists up to this length are rank-sorted (needs 2 * RANK_SORT_MAX <= CAP keys of LDS)
 
 // Handles a tile with lo < len <= CAP in LDS (sk[CAP]); when GLOBAL_TAIL it also sorts len > CAP in place in global
@@ -123,17 +177,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       const int i = r * 64 + lane;
       unsigned long long key = ~0ull;                      // padding sorts to the end of the last run
       if (i < len) key = (direct && r == wv) ? pre0 : ((direct && r == wv + 4) ? pre1 : gk[i]);
-#pragma unroll
-      for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          const unsigned long long other = __shfl_xor(key, j, 64);
-          const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-          const bool take_min = lower == up;
-          const bool other_less = other < key;
-          key = (take_min == other_less) ? other : key;
-        }
-      }
+      key = wave_bitonic_sort64(key, lane);
       sk2[i] = key;
     }
     __syncthreads();
