@@ -185,31 +185,57 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
       *(float2*)&hS[4][row][2 * s] = make_float2(e12[0], e12[1]);
     }
     __syncthreads();
-    // vertical pass: one output per lane (all 256), 11 rows of each moment
-    {
-      float st[5];
+    // vertical pass: one output per lane (all 256), 11 rows of each moment.  (-DMM3DGS_SSIM_V2: two horizontally adjacent outputs per lane on
+    // 128 lanes, 11 ds_read_b64 per moment -- half the LDS reads, but ten moments live in a kernel that is held to 96 registers: 7 - 14 of them
+    // spill and the launch takes 15.8 us instead of 12.3, tools/ab_lib.sh)
+#ifndef MM3DGS_SSIM_V2
+    constexpr int NO = 1;
+    const int vx = tx, vy = ty;
+    const bool v_on = true;
+#else
+    constexpr int NO = 2;
+    const int vx = 2 * (tid & 7), vy = (tid >> 3) & 15;
+    const bool v_on = tid < 128;
+#endif
+    if (v_on) {
+      float st[5][NO];
 #pragma unroll
       for (int q = 0; q < 5; q++) {
-        float acc = 0.f;
+        float acc[NO];
 #pragma unroll
-        for (int k = 0; k < 11; k++) acc = fmaf(cfg.window[k], hS[q][ty + k][tx], acc);
-        st[q] = acc;
+        for (int o = 0; o < NO; o++) acc[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          if constexpr (NO == 2) {
+            const float2 h = *(const float2*)&hS[q][vy + k][vx];
+            acc[0] = fmaf(cfg.window[k], h.x, acc[0]); acc[NO - 1] = fmaf(cfg.window[k], h.y, acc[NO - 1]);
+          } else {
+            acc[0] = fmaf(cfg.window[k], hS[q][vy + k][vx], acc[0]);
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; o++) st[q][o] = acc[o];
       }
-      if (inside) {
-        const float m1 = st[0], m2 = st[1];
-        const float s1 = st[2] - m1 * m1, s2 = st[3] - m2 * m2, s12 = st[4] - m1 * m2;
-        const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
-        // v_rcp_f32 (1 ulp) instead of three IEEE divisions (their scale / fixup sequences held ~40 registers live)
-        const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
-        const float inv = rB1 * rB2;
-        const float f = A1 * A2 * inv;
-        ssim_sum += f;
-        const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 * rB1;
-        const float df_ds1 = -f * rB2;
-        const float df_ds12 = 2.f * A1 * inv;
-        bst(r_dm, (uint32_t)(ch * 3 + 0) * HW + pix, df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12);  // d/d mu1 (total)
-        bst(r_dm, (uint32_t)(ch * 3 + 1) * HW + pix, df_ds1);                                     // d/d E[x^2]
-        bst(r_dm, (uint32_t)(ch * 3 + 2) * HW + pix, df_ds12);                                    // d/d E[xy]
+#pragma unroll
+      for (int o = 0; o < NO; o++) {
+        const int opx = x0 + vx + o, opy = y0 + vy;
+        if (opx < cfg.W && opy < cfg.H) {
+          const uint32_t opix = (uint32_t)opy * (uint32_t)cfg.W + (uint32_t)opx;
+          const float m1 = st[0][o], m2 = st[1][o];
+          const float s1 = st[2][o] - m1 * m1, s2 = st[3][o] - m2 * m2, s12 = st[4][o] - m1 * m2;
+          const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s1 + s2 + C2;
+          // v_rcp_f32 (1 ulp) instead of three IEEE divisions (their scale / fixup sequences held ~40 registers live)
+          const float rB1 = __builtin_amdgcn_rcpf(B1), rB2 = __builtin_amdgcn_rcpf(B2);
+          const float inv = rB1 * rB2;
+          const float f = A1 * A2 * inv;
+          ssim_sum += f;
+          const float df_dm1 = 2.f * m2 * A2 * inv - f * 2.f * m1 * rB1;
+          const float df_ds1 = -f * rB2;
+          const float df_ds12 = 2.f * A1 * inv;
+          bst(r_dm, (uint32_t)(ch * 3 + 0) * HW + opix, df_dm1 - 2.f * m1 * df_ds1 - m2 * df_ds12);  // d/d mu1 (total)
+          bst(r_dm, (uint32_t)(ch * 3 + 1) * HW + opix, df_ds1);                                     // d/d E[x^2]
+          bst(r_dm, (uint32_t)(ch * 3 + 2) * HW + opix, df_ds12);                                    // d/d E[xy]
+        }
       }
     }
   }
