@@ -643,13 +643,25 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         const float raw_eff = valid ? araw : 0.f;
         const float a_eff = (MODE == 0 || BWD_OLD_U) ? (valid ? alpha : 0.f) : fminf(0.99f, raw_eff);
         const float G_eff = valid ? G : 0.f;
-        // generic mode: correctly rounded division -- T is rebuilt by ~50 successive divisions per pixel and the 1-ulp v_rcp_f32
-        // showed up as 5e-6 of noise on every gradient (camera gradients are held to 1e-5); the SLAM modes keep v_rcp_f32
-#ifdef MM3DGS_SLAM_EXACT_DIV      // developer experiment (tools/build_variant.sh): what the 1-ulp v_rcp_f32 costs the SLAM modes in accuracy
-        const float r = 1.f / (1.f - a_eff);
+        // generic mode: the reciprocal to within an ulp -- T is rebuilt by ~50 successive divisions per pixel and the raw 1-ulp v_rcp_f32 showed up as
+        // 5e-6 of noise on every gradient (camera gradients are held to 1e-5).  v_rcp_f32 + one Newton step holds the same bars as the IEEE
+        // division sequence (tests/test_gpu_parity.py) at 3 instead of ~10 instructions: 1080p / 3 M backward compositor 1327 -> 1291 us
+        // (-DMM3DGS_GENERIC_IEEE_DIV: the division).  The SLAM modes keep the raw v_rcp_f32.
+        float r;
+        if constexpr (MODE == 0) {
+#if defined(MM3DGS_GENERIC_IEEE_DIV)
+          r = 1.f / (1.f - a_eff);
 #else
-        const float r = MODE == 0 ? 1.f / (1.f - a_eff) : __builtin_amdgcn_rcpf(1.f - a_eff);
+          const float d = 1.f - a_eff, r0 = __builtin_amdgcn_rcpf(d);
+          r = fmaf(fmaf(-d, r0, 1.f), r0, r0);
 #endif
+        } else {
+#ifdef MM3DGS_SLAM_EXACT_DIV      // developer experiment (tools/build_variant.sh): what the 1-ulp v_rcp_f32 costs the SLAM modes in accuracy
+          r = 1.f / (1.f - a_eff);
+#else
+          r = __builtin_amdgcn_rcpf(1.f - a_eff);
+#endif
+        }
         Tr *= r;  // transmittance in front of this splat
         const float w = a_eff * Tr;
         float col[C];
