@@ -337,7 +337,8 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   const bool droppable = c.area > 0 && c.area <= 32;
   if (droppable) {
     int ttx = c.minx, tty = c.miny;
-    for (int k = 0; k < c.area; k++) {
+    const int kmax = (cam.exp & 128) ? min(c.area, OWN) : c.area;      // (MM3DGS_EXP bit 7: timing probe, only the own pairs counted)
+    for (int k = 0; k < kmax; k++) {
       bool count = true;
       if (k < OWN) {
         const uint32_t mk = tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
@@ -350,6 +351,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
     }
   }
   if (live) g.clamped[idx] = (uint8_t)(pr.cl | (empty4 << 4));
+  if (cam.exp & 256) big = 0ull;      // (MM3DGS_EXP bit 8: timing probe without the > 32-tile splats' counting)
   for (unsigned long long bb = big; bb; bb &= bb - 1) {
     const int src = __ffsll((long long)bb) - 1;
     const int sminx = __builtin_amdgcn_readlane(c.minx, src), sminy = __builtin_amdgcn_readlane(c.miny, src);
@@ -376,7 +378,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
     }
   }
   const uint32_t incl = wave_scan_incl((uint32_t)max(c.area - OWN, 0));
-  const uint32_t S = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t S = (cam.exp & 64) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (MM3DGS_EXP bit 6: timing probe without the shared list)
   if (S) {   // wave-uniform
     __shared__ uint32_t s_pref[FB / 64][64];
     __shared__ PairCtx s_ctx[FB / 64][64];

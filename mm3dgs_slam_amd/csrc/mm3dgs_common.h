@@ -247,7 +247,7 @@ struct CamDev {
   int tilemap;  // 0: tile = workgroup id; 1 (default): contiguous tile span per XCD
   int tile_table; // SLAM entry points with persistent state: honour image_state's load-balanced workgroup -> tile table when it is valid
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
-  int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid): bit 0 = backward compositor skips its record stores
+  int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid; bits 6 - 8: binning without its shared list / big-rectangle counting): bit 0 = backward compositor skips its record stores
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
   int bg_extras;    // 1 (SLAM entry points): channels 3..5 are the depth bundle of a second reference pass and get T_final * bg[ch - 3] as well
   uint32_t trec_cap; // direct bins: per-tile gradient records per projection workgroup (workgroup w owns [w * trec_cap, (w + 1) * trec_cap)); 0: packed bins (Gaussian-major pair index)
