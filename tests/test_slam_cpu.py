@@ -496,3 +496,24 @@ def test_frames_without_sensor_depth_align_the_monocular_estimate_to_the_map_eve
     # a direct call reproduces what the frame used
     again = scale_depth_estimate(cfg, 2, seq.est(2), seq[2][1], lambda: slam.mapper._render_depth_sil(slam.estimate_pose_list[2]))
     assert torch.isfinite(again).all()
+
+
+def test_seed_fraction_thins_the_seeding_with_a_fixed_per_frame_subset():
+    """`mapping.seed_fraction` (a workload knob of bench.py, not in the reference): the subset of a frame's pixels that may seed a Gaussian
+    is a pure function of (frame index, pixel count, fraction, device) -- every rank of a multi-GPU window draws the same one -- and 1.0
+    is the reference's one-Gaussian-per-valid-pixel seeding (slam/mapper.py:600-688)."""
+    from mm3dgs_slam_amd.mapper import seed_subset
+    a, b, c = seed_subset(5000, 3, 0.5, "cpu"), seed_subset(5000, 3, 0.5, "cpu"), seed_subset(5000, 4, 0.5, "cpu")
+    assert a.dtype == torch.bool and a.shape == (5000,) and torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.float().mean()) - 0.5) < 0.05
+    assert bool(seed_subset(100, 0, 1.0, "cpu").all())          # torch.rand is in [0, 1): nothing is dropped at 1.0
+    n = {}
+    for frac in (1.0, 0.5):
+        cfg = _cfg()
+        cfg["mapping"].update(iters=2, seed_fraction=frac)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        seq = SyntheticSequence(cfg, 1, 500, seed=1, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
+        slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer)
+        slam.step(0)
+        n[frac] = int(slam.gaussians.get_xyz.shape[0])
+    assert 0.35 * n[1.0] < n[0.5] < 0.65 * n[1.0], n
