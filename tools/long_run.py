@@ -8,7 +8,7 @@ from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 _lib.load(); rasterizer.set_binning_policy("async")
 torch.manual_seed(0); random.seed(0); np.random.seed(0)
-cfg = default_config(device="cuda:0", height=480, width=640, mapping={"seed_fraction": 0.51})
+cfg = default_config(device="cuda:0", height=480, width=640, mapping={"seed_fraction": float(os.environ.get("LONGRUN_SEED_FRACTION", "0.51"))})
 seq = SyntheticSequence(cfg, n, 150000, seed=0)
 slam = SLAM(cfg, seq)
 slam.step(0); torch.cuda.synchronize()
