@@ -200,6 +200,11 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
                                     then laid out per projection workgroup (see Mm3dgsHeader.max_group_records). */
 #define MM3DGS_FWD_SHORT_LISTS 2 /* hint: no tile list exceeds 2048 splats -> one sort launch (longer lists stay correct
                                     through the global-memory path, only slower)                                        */
+#define MM3DGS_FWD_KEEP_TILE_ORDER 8 /* mm3dgs_slam_track / mm3dgs_slam_map: do not rebuild image_state's load-balanced workgroup -> tile
+                                    table at the head of this call (Mm3dgsHeader.tile_order_tiles); the table of an earlier call stays
+                                    in force while it matches the image size.  For callers that enqueue ONE iteration per call (the
+                                    multi-GPU window: gradients out, all-reduce, step): any valid table renders the same image, a
+                                    fresher one only balances better, and rebuilding it costs a 9 us launch                 */
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color /*[6,H,W]*/,
                         int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity,
                         int flags, void* stream);
@@ -240,6 +245,7 @@ typedef struct Mm3dgsMapView {
    * no pose step is taken. */
   float* dpose_out_or_null;
 } Mm3dgsMapView;
+/* (loss4 may be NULL: the loss scalars of the call's last iteration are then not finished -- one launch less) */
 int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in,
                     float* out_color, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
                     size_t N_capacity, int fwd_flags, const struct Mm3dgsLossConfig* loss_cfg, void* loss_work, float* dL_dout,

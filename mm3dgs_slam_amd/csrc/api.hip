@@ -251,6 +251,7 @@ static DirectBins slam_direct_bins(int flags, const CamDev& cd, int P, size_t N_
 static bool slam_tile_table(int flags) { return (flags & MM3DGS_FWD_STATE_CLEAN) && !env_flag("MM3DGS_NO_TILE_ORDER", 0); }
 static void slam_refresh_tile_order(const Mm3dgsCamera* cam, void* image_state, int flags, void* stream) {
   if (!cam || !image_state || !slam_tile_table(flags) || cam->image_height <= 0 || cam->image_width <= 0) return;
+  if (flags & MM3DGS_FWD_KEEP_TILE_ORDER) return;      // (a table left by an earlier call is honoured while its key matches the image size)
   const CamDev cd = cam_dev(cam);
   launch_tile_order(cd.gx * cd.gy, cd.H, cd.W, image_view(image_state, cd.H, cd.W), (hipStream_t)stream);
 }

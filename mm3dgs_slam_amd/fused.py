@@ -169,9 +169,12 @@ class FusedEngine:
                                               _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
                                               C.byref(pose_adam), _stream()))
 
-    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True):
         """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...].  With `grads`
-        (and map_adam None) the gradients of the last view are written out instead of stepped (multi-GPU window)."""
+        (and map_adam None) the gradients of the last view are written out instead of stepped (multi-GPU window).
+        keep_tile_order / want_loss=False: for callers that enqueue one iteration per call -- the workgroup -> tile table of an earlier
+        call stays in force (MM3DGS_FWD_KEEP_TILE_ORDER) and the loss scalars' finishing launch is left out (`loss` then keeps the values
+        of the last call that asked for them)."""
         P = int(g._xyz.shape[0])
         self._ensure(P, True)
         arr = getattr(views, "table", None)      # built ahead of time by FusedMapper (a _Views list)
@@ -186,11 +189,11 @@ class FusedEngine:
             if grads is not None:
                 sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
                 sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
-        flags = self._flags()
+        flags = self._flags() | (8 if keep_tile_order else 0)
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
-                                            _p(self.dL), _p(self.loss), _p(self.scratch), C.byref(sg) if sg is not None else None,
+                                            _p(self.dL), _p(self.loss) if want_loss else None, _p(self.scratch), C.byref(sg) if sg is not None else None,
                                             C.byref(map_adam) if map_adam is not None else None, _stream()))
 
     @staticmethod
@@ -706,7 +709,10 @@ class FusedMapper(Mapper):
                     if self._ba_ids:
                         self._ba_grad.zero_()
                     for j, k in enumerate(ids):
-                        eng.map_loop([view_of(k)], g, lcfg, eng.stat_delta if densify else None, None, grads=eng.grads)
+                        # (one iteration per C call here: the workgroup -> tile table is rebuilt by the first call of the loop only, the
+                        #  loss scalars are finished by the last one only -- 9 + 6 us of launches per step otherwise)
+                        eng.map_loop([view_of(k)], g, lcfg, eng.stat_delta if densify else None, None, grads=eng.grads,
+                                     keep_tile_order=iteration > 0 or j > 0, want_loss=iteration == num_iter - 1 and j == len(ids) - 1)
                         if k in self._ba_ids:      # this view's pose gradient (its slot is overwritten by the pose's next view)
                             self._ba_grad[self._ba_ids.index(k)] += self._ba_state[k][6]
                         if len(ids) > 1:
@@ -735,7 +741,8 @@ class FusedMapper(Mapper):
                     # a pruning iteration: gradients + statistics only (the reference prunes BEFORE optimizer.step(): the
                     # parameters are replaced, so that step is a no-op)
                     stats = (g.max_radii2D, g.xyz_gradient_accum, g.denom) if densify else None
-                    eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads)
+                    eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads, keep_tile_order=iteration > 0,
+                                 want_loss=iteration == num_iter - 1)
                 if prune_now:
                     # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
                     # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py).

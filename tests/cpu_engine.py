@@ -151,7 +151,7 @@ class CpuEngine:
             self.out, self.loss = out6.detach(), torch.tensor([float(loss), 0.0, 0.0, 0.0])
         self.calls.append(("track", n_iter))
 
-    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True):
         """mm3dgs_slam_map: one iteration per view -- render, mapping loss, backward; densification statistics when given; the map's
         Adam step (state through the struct's pointers, step number map_adam.step + i) or, without it, gradient outputs; the view's
         own pose Adam (bundle adjustment) when it carries one."""
@@ -204,4 +204,5 @@ class CpuEngine:
                     p.grad = None
             self.out = out6.detach()
         self.calls.append(("map", len(views), stats is not None, map_adam is not None))
+        self.hints = getattr(self, "hints", []) + [(bool(keep_tile_order), bool(want_loss))]      # (speed hints of the C call: no effect on the results)
         self.view_log.append(tuple(round(float(v[1].double().sum()), 4) for v in views))      # which views (by their colour target) this call rendered

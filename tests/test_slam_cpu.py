@@ -127,7 +127,7 @@ def test_native_mapper_groups_iterations_into_runs_between_pruning_steps(monkeyp
             self.calls.append(("backward", grads is not None, stats is not None, map_adam is not None))
         def _ensure(self, P, need_grads):
             pass
-        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, **hints):
             self.calls.append(("map_loop", len(views), stats is not None, int(map_adam.step) if map_adam is not None else None, grads is not None))
         pruned_count = 0
         class _Img:
@@ -202,7 +202,7 @@ def test_native_mapper_restores_and_reruns_after_a_binning_overflow(monkeypatch)
             pass
         def _ensure(self, P, need_grads):
             pass
-        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, **hints):
             self.picks[-1] += [float(v[0][4]) for v in views]
             self.seen_xyz.append(g._xyz.detach().clone())
             with torch.no_grad():                     # what the in-kernel Adam would do: the map moves
@@ -268,7 +268,7 @@ def test_native_mapper_with_ample_headroom_reads_the_header_only_at_pruning_step
             pass
         def headroom(self):
             return 2.0
-        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, **hints):
             self.calls.append(("map_loop", len(views)))
         def check_capacity_begin(self):
             self.calls.append(("begin",))
@@ -365,7 +365,7 @@ def test_native_loops_hand_the_reference_loss_of_each_method_to_the_c_loops(monk
             self.loss, self.out = torch.zeros(4), torch.zeros(6, 24, 32)
         def track_loop(self, n, pose, g, lcfg, gt_color, ref, ad):
             self.track.append((n, lcfg, ref, bool(ad.prior_pose)))
-        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None):
+        def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, **hints):
             self.maps.append((len(views), lcfg, [v[2] for v in views], stats is not None))
         def _ensure(self, P, need_grads):
             pass
