@@ -200,6 +200,8 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
                                     then laid out per projection workgroup (see Mm3dgsHeader.max_group_records). */
 #define MM3DGS_FWD_SHORT_LISTS 2 /* hint: no tile list exceeds 2048 splats -> one sort launch (longer lists stay correct
                                     through the global-memory path, only slower)                                        */
+#define MM3DGS_FWD_PROJECTED 16 /* mm3dgs_slam_forward / the FIRST view of mm3dgs_slam_map: projection + binning of this view were
+                                    already launched by mm3dgs_slam_adam_project (direct bins only; ignored otherwise)            */
 #define MM3DGS_FWD_KEEP_TILE_ORDER 8 /* mm3dgs_slam_track / mm3dgs_slam_map: do not rebuild image_state's load-balanced workgroup -> tile
                                     table at the head of this call (Mm3dgsHeader.tile_order_tiles); the table of an earlier call stays
                                     in force while it matches the image size.  For callers that enqueue ONE iteration per call (the
@@ -282,6 +284,17 @@ int mm3dgs_loss(const Mm3dgsLossConfig* cfg, const float* out6, const float* gt_
  * step = 1-based step count used for the bias corrections. */
 typedef struct Mm3dgsAdamGroup { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; double lr; } Mm3dgsAdamGroup;
 int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double beta1, double beta2, double eps, void* stream);
+
+/* The multi-GPU mapping window's optimiser step AND the next view's projection + binning in one launch: the map's Adam step
+ * (slam/mapper.py:931-948) from gradient ARRAYS -- grads->d_* as mm3dgs_slam_map wrote them out and the caller all-reduced them; the
+ * statistics pointers are ignored -- with `adam` as for mm3dgs_slam_backward (opt_mask included), then, from the stepped parameters
+ * still in registers, what the head of the next mm3dgs_slam_map / mm3dgs_slam_forward call would launch for the view at in->pose.
+ * That call must carry MM3DGS_FWD_PROJECTED (and the same cam, P, buffers, capacity and flags).  Replaces mm3dgs_adam + the next
+ * call's projection launch; same arithmetic as both.  Needs direct bins (MM3DGS_FWD_DIRECT_BINS in fwd_flags and honoured for this
+ * P / capacity): returns -3 otherwise, nothing done. */
+int mm3dgs_slam_adam_project(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const Mm3dgsSlamGrads* grads,
+                             const Mm3dgsMapAdam* adam, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
+                             size_t N_capacity, int fwd_flags, void* stream);
 
 /* =====================================================================================================
  * Map surgery on the device: pruning predicate, order-preserving compaction of the

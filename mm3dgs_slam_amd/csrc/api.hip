@@ -101,7 +101,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
 }
 
 const char* mm3dgs_last_error(void) { return g_err; }
-int mm3dgs_version(void) { return 203; }   // 203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations void; 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
+int mm3dgs_version(void) { return 204; }   // 204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / KEEP_TILE_ORDER; 203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations void; 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
 
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
@@ -313,7 +313,24 @@ int mm3dgs_slam_visibility(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInput
 
 int mm3dgs_slam_forward(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                         void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream) {
-  return slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, flags, stream, nullptr);
+  return slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, flags, stream, nullptr, nullptr,
+                           (flags & MM3DGS_FWD_PROJECTED) != 0);
+}
+
+// Mm3dgsMapAdam -> the kernels' scalars: formed in double, rounded once to float (torch.optim.Adam does this arithmetic on Python floats)
+static int map_adam_dev(const Mm3dgsMapAdam* map_adam, MapAdam& ma) {
+  if (map_adam->step < 1) return fail(-1, "map Adam step must be >= 1");
+  for (int i = 0; i < 5; i++) {
+    if (!map_adam->param[i] || !map_adam->exp_avg[i] || !map_adam->exp_avg_sq[i]) return fail(-2, "map Adam group %d has a NULL pointer", i);
+    ma.p[i] = map_adam->param[i]; ma.m[i] = map_adam->exp_avg[i]; ma.v[i] = map_adam->exp_avg_sq[i];
+    ma.step_size[i] = (float)(map_adam->lr[i] / (1.0 - pow(map_adam->beta1, (double)map_adam->step)));
+  }
+  ma.omb1 = (float)(1.0 - map_adam->beta1); ma.beta2 = (float)map_adam->beta2; ma.omb2 = (float)(1.0 - map_adam->beta2);
+  ma.eps = (float)map_adam->eps;
+  ma.bc2s = (float)sqrt(1.0 - pow(map_adam->beta2, (double)map_adam->step));
+  ma.opt_mask = map_adam->opt_mask;
+  ma.on = 1;
+  return 0;
 }
 
 static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const int32_t* radii,
@@ -357,19 +374,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   }
   MapAdam ma;
   memset(&ma, 0, sizeof(ma));
-  if (map_adam) {
-    if (map_adam->step < 1) return fail(-1, "map Adam step must be >= 1");
-    for (int i = 0; i < 5; i++) {
-      if (!map_adam->param[i] || !map_adam->exp_avg[i] || !map_adam->exp_avg_sq[i]) return fail(-2, "map Adam group %d has a NULL pointer", i);
-      ma.p[i] = map_adam->param[i]; ma.m[i] = map_adam->exp_avg[i]; ma.v[i] = map_adam->exp_avg_sq[i];
-      ma.step_size[i] = (float)(map_adam->lr[i] / (1.0 - pow(map_adam->beta1, (double)map_adam->step)));
-    }
-    ma.omb1 = (float)(1.0 - map_adam->beta1); ma.beta2 = (float)map_adam->beta2; ma.omb2 = (float)(1.0 - map_adam->beta2);
-    ma.eps = (float)map_adam->eps;
-    ma.bc2s = (float)sqrt(1.0 - pow(map_adam->beta2, (double)map_adam->step));
-    ma.opt_mask = map_adam->opt_mask;
-    ma.on = 1;
-  }
+  if (map_adam)
+    if (int rc2 = map_adam_dev(map_adam, ma)) return rc2;
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
   if (!compositor_done)
@@ -516,7 +522,7 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
   // the backward launch of iteration `it` projects and bins the view of iteration `it + 1` when nothing stands between them (direct bins,
   // in-kernel Adam, neither view steps its pose); MM3DGS_NO_FUSED_PROJECT keeps the two launches apart (tests compare both, bit for bit)
   const int no_fuse_proj = env_flag("MM3DGS_NO_FUSED_PROJECT", 0);
-  bool projected = false;
+  bool projected = (fwd_flags & MM3DGS_FWD_PROJECTED) != 0;     // (view 0 only: mm3dgs_slam_adam_project launched its projection + binning)
   if (n_iter > 0) slam_refresh_tile_order(cam, image_state, fwd_flags, stream);
   for (int it = 0; it < n_iter; it++) {
     if (!views[it].pose || !views[it].gt_color) return fail(-1, "view %d: NULL pose or colour target", it);
@@ -574,6 +580,30 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double be
   ProfScope ps(MM3DGS_PROF_ADAM, s);
   launch_fused_adam(a, s);
   return check_launch("adam");
+}
+
+int mm3dgs_slam_adam_project(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const Mm3dgsSlamGrads* grads, const Mm3dgsMapAdam* adam,
+                             int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags, void* stream) {
+  int rc = check_slam(cam, P, in);
+  if (rc) return rc;
+  if (!grads || !adam || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL argument");
+  if (!grads->d_xyz || !grads->d_f_dc || !grads->d_opacity || !grads->d_scaling || !grads->d_rotation) return fail(-2, "all five gradient arrays are needed");
+  hipStream_t s = (hipStream_t)stream;
+  CamDev cd = cam_dev(cam);
+  cd.bg_extras = 1;
+  cd.tile_table = slam_tile_table(fwd_flags) ? 1 : 0;
+  const DirectBins db = slam_direct_bins(fwd_flags, cd, P, N_capacity);
+  if (!db.on) return fail(-3, "mm3dgs_slam_adam_project needs direct bins (flags / map size / capacity)");
+  cd.trec_cap = db.trec_cap;
+  MapAdam ma;
+  memset(&ma, 0, sizeof(ma));
+  if ((rc = map_adam_dev(adam, ma))) return rc;
+  SlamGrads sg = {};
+  sg.d_xyz = grads->d_xyz; sg.d_f_dc = grads->d_f_dc; sg.d_opacity = grads->d_opacity; sg.d_scaling = grads->d_scaling; sg.d_rotation = grads->d_rotation;
+  { ProfScope ps(MM3DGS_PROF_ADAM, s);
+    launch_slam_adam_project(cd, P, slam_in(in), radii, geom_view(geom_state, P > 0 ? P : 1), image_view(image_state, cd.H, cd.W), bin_view(binning_state, N_capacity),
+                             sg, ma, in->pose, db.bin_cap, db.rec_cap, db.slot_bits, s); }
+  return check_launch("slam_adam_project");
 }
 
 // ---- map surgery (compact.hip) -----------------------------------------------------------------------------------------

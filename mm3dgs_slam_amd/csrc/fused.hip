@@ -791,6 +791,69 @@ void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t
                        next_pose, bin_cap, rec_cap, slot_bits);
 }
 
+// The multi-GPU window's optimiser step (slam/mapper.py:931-948 on all-reduced gradients) and the NEXT view's projection + binning in one launch: what
+// fused_adam_kernel + slam_project_bin_kernel do in two, with the stepped parameters going from the optimiser to the projection in
+// registers (the second half of slam_bwd_project_kernel, fed by gradient arrays instead of the record gather).  Same update arithmetic as
+// slam_bwd_body's in-kernel Adam; opt_mask as there.
+template <bool WORLD>
+__global__ void __launch_bounds__(FB)
+slam_adam_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, SlamGrads gr, MapAdam ma,
+                         const float* __restrict__ next_pose, uint32_t cap, uint32_t rec_cap, int slot_bits) {
+  extern __shared__ uint32_t hist[];
+  const int T = cam.gx * cam.gy;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < T; t += FB) hist[t] = 0;
+  if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
+  const int idx = blockIdx.x * FB + tid;
+  RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+  if (idx < P) {
+    constexpr int AG_OFF[5] = {0, 3, 6, 7, 10}, AG_N[5] = {3, 3, 1, 3, 4};     // xyz | f_dc | opacity | scaling | rotation
+    const float* gsrc[5] = {gr.d_xyz, gr.d_f_dc, gr.d_opacity, gr.d_scaling, gr.d_rotation};
+    float ap[14], am[14], av[14], g14[14];
+#pragma unroll
+    for (int gq = 0; gq < 5; gq++)
+#pragma unroll
+      for (int c = 0; c < AG_N[gq]; c++) {
+        const size_t off = (size_t)idx * AG_N[gq] + c;
+        ap[AG_OFF[gq] + c] = ma.p[gq][off]; am[AG_OFF[gq] + c] = ma.m[gq][off]; av[AG_OFF[gq] + c] = ma.v[gq][off];
+        g14[AG_OFF[gq] + c] = gsrc[gq][off];
+      }
+    const float keepg = (ma.opt_mask && ma.opt_mask[idx] == 0) ? 0.f : 1.f;
+#pragma unroll
+    for (int gq = 0; gq < 5; gq++)
+#pragma unroll
+      for (int c = 0; c < AG_N[gq]; c++) {
+        const int q = AG_OFF[gq] + c;
+        const size_t off = (size_t)idx * AG_N[gq] + c;
+        const float grd = keepg * g14[q];
+        const float mi = am[q] + (grd - am[q]) * ma.omb1;                 // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = av[q] * ma.beta2 + grd * grd * ma.omb2;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        ma.m[gq][off] = mi; ma.v[gq][off] = vi;
+        ap[q] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+        ma.p[gq][off] = ap[q];
+      }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rg.x[k] = ap[k]; rg.fd[k] = ap[3 + k]; rg.ls[k] = ap[7 + k]; }
+    rg.op = ap[6];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rg.q[k] = ap[10 + k];
+  }
+  const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g, WORLD);
+  slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
+}
+
+void launch_slam_adam_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, const SlamGrads& gr,
+                              const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap, int slot_bits, hipStream_t s) {
+  if (P <= 0) return;
+  const int T = cam.gx * cam.gy;
+  if (in.world)
+    hipLaunchKernelGGL(slam_adam_project_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, gr, ma, next_pose,
+                       bin_cap, rec_cap, slot_bits);
+  else
+    hipLaunchKernelGGL(slam_adam_project_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, gr, ma, next_pose,
+                       bin_cap, rec_cap, slot_bits);
+}
+
 // b^t for a step counter t >= 1 by squaring, in double (pow() costs this one-lane code ~60 registers of the whole kernel it is inlined into)
 __device__ __forceinline__ double pow_int(double b, int t) {
   double r = 1.0;

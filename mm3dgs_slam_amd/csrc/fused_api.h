@@ -64,13 +64,16 @@ void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, Bin
 // the same + the backward compositor of a tracking iteration (masked-L1 loss, deferred normalisation) in that launch
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
                                          hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX);
-// projection + binning in one launch (direct bins: every tile owns bin_cap pairs at tile * bin_cap)
 // backward projection + map Adam of one mapping iteration and projection + binning of the next one (its pose: next_pose) in one launch
 void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, size_t N_cap,
                              BwdView bw, const SlamGrads& out, const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap,
                              int slot_bits, hipStream_t s);
+// projection + binning in one launch (direct bins: every tile owns bin_cap pairs at tile * bin_cap)
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
                              uint32_t rec_cap, int slot_bits, hipStream_t s);
+// the map's Adam step from gradient arrays (the multi-GPU window: all-reduced gradients) + projection + binning of the next view in one launch
+void launch_slam_adam_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, const SlamGrads& gr,
+                              const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap, int slot_bits, hipStream_t s);
 void launch_fused_adam(const AdamArgs& a, hipStream_t s);
 void launch_loss(const LossCfg& cfg, const float* out, const float* gt, const float* ref, float* dmaps, double* sums, double* partial,
                  float* dL, float* loss, hipStream_t s);

@@ -169,12 +169,28 @@ class FusedEngine:
                                               _p(ref), _p(self.loss_work), _p(self.dL), _p(self.loss), _p(self.scratch),
                                               C.byref(pose_adam), _stream()))
 
-    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True):
+    def adam_project(self, next_pose, g, grads, map_adam):
+        """The multi-GPU window's optimiser step from the (all-reduced) gradient arrays and the projection + binning of the NEXT view in one
+        launch (mm3dgs_slam_adam_project); the map_loop call that renders that view must say projected=True.  Direct bins only
+        (self.can_adam_project())."""
+        P = int(g._xyz.shape[0])
+        si = self.inputs(next_pose, g)
+        sg = _lib.Mm3dgsSlamGrads()
+        sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
+        sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
+        self._pose_keepalive = next_pose
+        _lib.check(self.lib.mm3dgs_slam_adam_project(C.byref(self.cam), P, C.byref(si), C.byref(sg), C.byref(map_adam), _p(self.radii), _p(self.geom),
+                                                     _p(self.img_state), _p(self.binning), self.n_cap, self._flags(), _stream()))
+
+    def can_adam_project(self, g):
+        return bool(self.direct) and int(g._xyz.shape[0]) > 0
+
+    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True, projected=False):
         """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...].  With `grads`
         (and map_adam None) the gradients of the last view are written out instead of stepped (multi-GPU window).
         keep_tile_order / want_loss=False: for callers that enqueue one iteration per call -- the workgroup -> tile table of an earlier
         call stays in force (MM3DGS_FWD_KEEP_TILE_ORDER) and the loss scalars' finishing launch is left out (`loss` then keeps the values
-        of the last call that asked for them)."""
+        of the last call that asked for them).  projected: adam_project already launched the projection + binning of views[0]."""
         P = int(g._xyz.shape[0])
         self._ensure(P, True)
         arr = getattr(views, "table", None)      # built ahead of time by FusedMapper (a _Views list)
@@ -189,7 +205,7 @@ class FusedEngine:
             if grads is not None:
                 sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
                 sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
-        flags = self._flags() | (8 if keep_tile_order else 0)
+        flags = self._flags() | (8 if keep_tile_order else 0) | (16 if projected else 0)
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),
@@ -365,6 +381,7 @@ class FusedTracker(Tracker):
 
 
 class FusedMapper(Mapper):
+    fuse_adam_project = True     # multi-GPU window: the optimiser step and the next view's projection + binning in one launch (False: mm3dgs_adam, then the projection)
     lazy_checks = True       # False: read the capacity header back after every loop (debugging / tests)
     _piggybacked = False
     _late_overflow = False
@@ -679,6 +696,7 @@ class FusedMapper(Mapper):
         with torch.no_grad():
             iteration = 0
             prepared = None      # (first iteration, views, table) of a run whose host side was built while the GPU was still busy
+            pending, projected_next = None, False      # multi-GPU window: the next step's keyframe picks, drawn ahead by a fused Adam + projection launch
             while iteration < num_iter:
                 densify = dens(iteration)
                 if not multi and not prune_at(iteration):
@@ -696,7 +714,11 @@ class FusedMapper(Mapper):
                     iteration += n
                     continue
                 # one optimiser step over this rank's share of the window batch (a single view without a window)
-                all_ids, ids = self.window.take_all(pop) if self.window is not None else (None, [pop()])
+                if pending is not None:
+                    all_ids, ids = pending        # (popped ahead by the previous step, whose Adam launch already projected ids[0]'s view)
+                else:
+                    all_ids, ids = self.window.take_all(pop) if self.window is not None else (None, [pop()])
+                was_projected, pending, projected_next = projected_next, None, False
                 P = int(g._xyz.shape[0])
                 eng._ensure(P, True)
                 prune_now = prune_at(iteration)
@@ -712,7 +734,8 @@ class FusedMapper(Mapper):
                         # (one iteration per C call here: the workgroup -> tile table is rebuilt by the first call of the loop only, the
                         #  loss scalars are finished by the last one only -- 9 + 6 us of launches per step otherwise)
                         eng.map_loop([view_of(k)], g, lcfg, eng.stat_delta if densify else None, None, grads=eng.grads,
-                                     keep_tile_order=iteration > 0 or j > 0, want_loss=iteration == num_iter - 1 and j == len(ids) - 1)
+                                     keep_tile_order=iteration > 0 or j > 0, want_loss=iteration == num_iter - 1 and j == len(ids) - 1,
+                                     **({"projected": True} if (was_projected and j == 0) else {}))
                         if k in self._ba_ids:      # this view's pose gradient (its slot is overwritten by the pose's next view)
                             self._ba_grad[self._ba_ids.index(k)] += self._ba_state[k][6]
                         if len(ids) > 1:
@@ -732,11 +755,19 @@ class FusedMapper(Mapper):
                     if self._ba_ids:
                         self._ba_window_step(eng, m, all_ids, ids)
                     if not prune_now:
-                        if self._opt_mask is not None:       # bundle adjustment: Gaussians outside the covisible set keep a zero gradient (slam/mapper.py:931-938)
-                            keep = self._opt_mask.to(eng.flat.dtype)
-                            for t in eng.grads.values():
-                                t.mul_(keep.view(-1, *([1] * (t.dim() - 1))))
-                        self._adam_step(eng)
+                        fuse = (self.fuse_adam_project and iteration + 1 < num_iter and hasattr(eng, "adam_project") and eng.can_adam_project(g))
+                        if fuse:
+                            # the step and the NEXT view's projection + binning in one launch: the next step's keyframe picks are drawn now
+                            # (same draws, same order as at the head of the next iteration), its first local view's pose goes with the step
+                            pending = self.window.take_all(pop)
+                            eng.adam_project(view_of(pending[1][0])[0], g, eng.grads, self._inline_adam(1))      # (opt_mask rides in the Adam struct)
+                            projected_next = True
+                        else:
+                            if self._opt_mask is not None:       # bundle adjustment: Gaussians outside the covisible set keep a zero gradient (slam/mapper.py:931-938)
+                                keep = self._opt_mask.to(eng.flat.dtype)
+                                for t in eng.grads.values():
+                                    t.mul_(keep.view(-1, *([1] * (t.dim() - 1))))
+                            self._adam_step(eng)
                 else:
                     # a pruning iteration: gradients + statistics only (the reference prunes BEFORE optimizer.step(): the
                     # parameters are replaced, so that step is a no-op)

@@ -151,13 +151,38 @@ class CpuEngine:
             self.out, self.loss = out6.detach(), torch.tensor([float(loss), 0.0, 0.0, 0.0])
         self.calls.append(("track", n_iter))
 
-    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True):
+    def can_adam_project(self, g):
+        return int(g._xyz.shape[0]) > 0
+
+    def adam_project(self, next_pose, g, grads, map_adam):
+        """mm3dgs_slam_adam_project: the map's Adam step from the gradient arrays (opt_mask honoured); the projection of the next view it
+        also launches has no counterpart here (map_loop renders from scratch)."""
+        names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
+        P = getattr(g, names[0]).shape[0]
+        keep = _view(map_adam.opt_mask, P, C.c_uint8).bool() if map_adam.opt_mask else None
+        with torch.no_grad():
+            for k, (n_, gname) in enumerate(zip(names, ("xyz", "f_dc", "opacity", "scaling", "rotation"))):
+                p = getattr(g, n_)
+                assert map_adam.param[k] == p.data_ptr(), "Mm3dgsMapAdam.param does not point at the model's tensor"
+                n = p.numel()
+                pv, mv, vv = _view(map_adam.param[k], n), _view(map_adam.exp_avg[k], n), _view(map_adam.exp_avg_sq[k], n)
+                gk = grads[gname].reshape(P, -1)
+                if keep is not None:
+                    gk = gk * keep[:, None]
+                _adam(pv, gk.reshape(-1), mv, vv, int(map_adam.step), map_adam.lr[k], map_adam.beta1, map_adam.beta2, map_adam.eps)
+        self.calls.append(("adam_project",))
+        self.pending_projection = next_pose.data_ptr()
+
+    def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True, projected=False):
         """mm3dgs_slam_map: one iteration per view -- render, mapping loss, backward; densification statistics when given; the map's
         Adam step (state through the struct's pointers, step number map_adam.step + i) or, without it, gradient outputs; the view's
         own pose Adam (bundle adjustment) when it carries one."""
         names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
         params = [getattr(g, n) for n in names]
         P = params[0].shape[0]
+        # MM3DGS_FWD_PROJECTED: the caller promises that adam_project launched the projection of views[0] -- for exactly that pose buffer
+        assert (not projected) or getattr(self, "pending_projection", None) == views[0][0].data_ptr(), "projected=True without a matching adam_project"
+        self.pending_projection = None
         for i, view in enumerate(views):
             pose_buf, gt_color, ref = view[:3]
             pad = view[3] if len(view) > 3 else None

@@ -405,6 +405,47 @@ def test_fused_mapper_window_parallel_two_ranks(tmp_path):
     assert torch.allclose(g.xyz_gradient_accum.cpu(), a["acc"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("ba", [False, True])
+def test_window_step_fused_with_the_next_projection_is_bit_identical(ba, monkeypatch):
+    """The multi-GPU window's optimiser step: mm3dgs_slam_adam_project (Adam from the reduced gradient arrays + projection and binning of
+    the next view in one launch, that view's mm3dgs_slam_map call carrying MM3DGS_FWD_PROJECTED) against mm3dgs_adam followed by the
+    view's own projection launch -- same map, same poses, same statistics, bit for bit, with bundle adjustment's opt_mask riding in the
+    Adam struct on one side and multiplied into the gradients on the other."""
+    from mm3dgs_slam_amd.config import default_config
+    from mm3dgs_slam_amd.fused import FusedMapper
+    from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    from mm3dgs_slam_amd.fused import FusedEngine, _engine
+    outs, n_fused = [], []
+    real = FusedEngine.adam_project
+    def counting(self, *a, **k):
+        n_fused[-1] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(FusedEngine, "adam_project", counting)
+    for fuse in (True, False):
+        monkeypatch.setattr(FusedMapper, "fuse_adam_project", fuse)
+        n_fused.append(0)
+        torch.manual_seed(0); random.seed(0); np.random.seed(0)
+        cfg = default_config(device=DEV, height=120, width=160, tracking={"iters": 5}, mapping={"iters": 8, "kf_every": 1, "do_BA": ba})
+        seq = SyntheticSequence(cfg, 3, 6000, seed=6)
+        slam = SLAM(cfg, seq, window=WindowParallel(0, 1, batch=2))
+        for i in range(3):
+            slam.step(i)
+        eng = _engine(slam.renderer)
+        g = slam.gaussians
+        outs.append((g._xyz.detach().clone(), g._opacity.detach().clone(), g._scaling.detach().clone(), g._rotation.detach().clone(), g._features_dc.detach().clone(),
+                     g.xyz_gradient_accum.clone(), g.max_radii2D.clone(), torch.stack([p.detach().clone() for p in slam.estimate_pose_list[:3]]),
+                     [kf.pose.detach().clone() for kf in slam.mapper.keyframes], eng.out.clone()))
+    a, b = outs
+    assert n_fused[0] >= 10 and n_fused[1] == 0, n_fused          # the fused launch really served the steps of the first run
+    assert a[0].shape == b[0].shape and a[0].shape[0] > 0
+    for x, y in zip(a[:8], b[:8]):
+        assert torch.equal(x, y), (x - y).abs().max()
+    for x, y in zip(a[8], b[8]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[9], b[9])
+
+
 @pytest.mark.parametrize("long_lists", [False, True])
 def test_sort_fused_into_the_forward_launch_is_bit_identical(long_lists, monkeypatch):
     """MM3DGS_FWD_SHORT_LISTS selects the sort + forward-composite kernel; it must reproduce the separate launches bit for
