@@ -5,6 +5,7 @@ import random
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -272,3 +273,29 @@ def test_forced_collectives_on_one_rank_equal_the_plain_single_view_loop(tmp_pat
     for k in ref:
         assert ref[k].shape == a[k].shape, k
         assert torch.allclose(ref[k], a[k], rtol=1e-5, atol=1e-7), (k, (ref[k] - a[k]).abs().max())
+
+
+@pytest.mark.parametrize("ba", [False, True])
+def test_window_step_with_the_fused_adam_and_projection_call_equals_the_two_call_step(ba, monkeypatch):
+    """fused.py's two forms of a sharded optimiser step over the CPU stand-in engine: mm3dgs_slam_adam_project (the step from the reduced
+    gradients + the next view's projection; the next step's keyframe picks are drawn one call early and its first view is marked
+    MM3DGS_FWD_PROJECTED) against mm3dgs_adam + a self-projecting next call -- the same keyframe picks, the same map, the same poses;
+    every projected=True call is matched to the pose buffer the fused call was given (tests/cpu_engine.py asserts it)."""
+    from mm3dgs_slam_amd import fused
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    torch.set_num_threads(2)
+    registry = _install_cpu_engine(monkeypatch.setattr)
+    states, logs, n_fused = [], [], []
+    for fuse in (True, False):
+        monkeypatch.setattr(fused.FusedMapper, "fuse_adam_project", fuse)
+        registry.clear()
+        slam = _build(WindowParallel(0, 1, batch=2), native=True, ba=ba)
+        _run(slam, ba=ba)
+        states.append(_state(slam))
+        eng = next(iter(registry.values()))
+        logs.append(list(eng.view_log))
+        n_fused.append(sum(1 for c in eng.calls if c[0] == "adam_project"))
+    assert n_fused[0] > 0 and n_fused[1] == 0, n_fused
+    assert logs[0] == logs[1]                      # the same views, in the same order, in every step
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), (k, (states[0][k] - states[1][k]).abs().max())
