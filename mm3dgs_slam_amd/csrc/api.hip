@@ -551,7 +551,9 @@ int mm3dgs_slam_map(int n_iter, const Mm3dgsMapView* views, const Mm3dgsCamera* 
                               views[it].pose_adam_or_null, map_adam ? &ad : nullptr, fwd_flags, stream, fold_grad ? &tl : nullptr, nullptr, 4, false,
                               next_pose, &projected);
     } else {
-      rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream);
+      // (MM3DGS_FWD_PROJECTED speaks of view 0 only)
+      rc = mm3dgs_slam_forward(cam, P, &si, out_color, radii, geom_state, image_state, binning_state, N_capacity,
+                               it == 0 ? fwd_flags : (fwd_flags & ~MM3DGS_FWD_PROJECTED), stream);
       if (rc) return rc;
       rc = mm3dgs_loss(loss_cfg, out_color, views[it].gt_color, views[it].ref_depth_or_null, loss_work, dL_dout, loss4, stream);
       if (rc) return rc;
