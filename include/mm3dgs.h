@@ -292,6 +292,9 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double be
  * That call must carry MM3DGS_FWD_PROJECTED (and the same cam, P, buffers, capacity and flags).  Replaces mm3dgs_adam + the next
  * call's projection launch; same arithmetic as both.  Needs direct bins (MM3DGS_FWD_DIRECT_BINS in fwd_flags and honoured for this
  * P / capacity): returns -3 otherwise, nothing done. */
+/* 1 if the SLAM entry points run with direct bins for this camera, map size, capacity and flags, 0 otherwise (pure host arithmetic:
+ * what a caller of mm3dgs_slam_adam_project asks first). */
+int mm3dgs_slam_direct_bins(const Mm3dgsCamera* cam, int P, size_t N_capacity, int fwd_flags);
 int mm3dgs_slam_adam_project(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const Mm3dgsSlamGrads* grads,
                              const Mm3dgsMapAdam* adam, int32_t* radii, void* geom_state, void* image_state, void* binning_state,
                              size_t N_capacity, int fwd_flags, void* stream);

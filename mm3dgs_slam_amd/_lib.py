@@ -105,6 +105,7 @@ _SIGS = {
     "mm3dgs_loss_work_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mm3dgs_loss": (C.c_int, [C.POINTER(Mm3dgsLossConfig), _P, _P, _P, _P, _P, _P, _P]),
     "mm3dgs_adam": (C.c_int, [C.POINTER(Mm3dgsAdamGroup), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _P]),
+    "mm3dgs_slam_direct_bins": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.c_size_t, C.c_int]),
     "mm3dgs_slam_adam_project": (C.c_int, [C.POINTER(Mm3dgsCamera), C.c_int, C.POINTER(Mm3dgsSlamInputs), C.POINTER(Mm3dgsSlamGrads), C.POINTER(Mm3dgsMapAdam),
                                            _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "mm3dgs_profile_enable": (None, [C.c_int]),

@@ -584,6 +584,11 @@ int mm3dgs_adam(const Mm3dgsAdamGroup* groups, int n_groups, int step, double be
   return check_launch("adam");
 }
 
+int mm3dgs_slam_direct_bins(const Mm3dgsCamera* cam, int P, size_t N_capacity, int fwd_flags) {
+  if (!cam || P <= 0 || cam->image_height <= 0 || cam->image_width <= 0) return 0;
+  return slam_direct_bins(fwd_flags, cam_dev(cam), P, N_capacity).on ? 1 : 0;
+}
+
 int mm3dgs_slam_adam_project(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, const Mm3dgsSlamGrads* grads, const Mm3dgsMapAdam* adam,
                              int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags, void* stream) {
   int rc = check_slam(cam, P, in);

@@ -183,7 +183,10 @@ class FusedEngine:
                                                      _p(self.img_state), _p(self.binning), self.n_cap, self._flags(), _stream()))
 
     def can_adam_project(self, g):
-        return bool(self.direct) and int(g._xyz.shape[0]) > 0
+        """Whether the library runs this map with direct bins under the flags the next calls will carry (the fused launch exists for
+        them only; the library's own decision, not this class's sizing hint)."""
+        P = int(g._xyz.shape[0])
+        return P > 0 and bool(self.direct) and self.lib.mm3dgs_slam_direct_bins(C.byref(self.cam), P, self.n_cap, self._flags()) == 1
 
     def map_loop(self, views, g, lcfg, stats, map_adam, grads=None, keep_tile_order=False, want_loss=True, projected=False):
         """A run of mapping iterations enqueued by one C call; views = [(pose[7], gt_color, ref_or_None), ...].  With `grads`
