@@ -730,7 +730,7 @@ class FusedMapper(Mapper):
                     # one local view (window-batch mode): summed in view order; then ONE flat all-reduce over the ranks carries
                     # every parameter gradient and, while densifying, the statistics tail [14P, 16P) (+ a max-reduce of the radii)
                     if densify:
-                        eng.stat_delta[0].zero_(); eng.flat[14 * P:].zero_()
+                        torch._foreach_zero_([eng.stat_delta[0], eng.flat[14 * P:]])        # (one launch)
                     if self._ba_ids:
                         self._ba_grad.zero_()
                     for j, k in enumerate(ids):
@@ -750,9 +750,8 @@ class FusedMapper(Mapper):
                         eng.flat[:14 * P].copy_(eng.acc[:14 * P])
                     if densify:
                         self.window.reduce_flat(eng.flat, eng.stat_delta[0])
-                        g.max_radii2D = torch.max(g.max_radii2D, eng.stat_delta[0])
-                        g.xyz_gradient_accum += eng.stat_delta[1]
-                        g.denom += eng.stat_delta[2]
+                        torch.maximum(g.max_radii2D, eng.stat_delta[0], out=g.max_radii2D)
+                        torch._foreach_add_([g.xyz_gradient_accum, g.denom], [eng.stat_delta[1], eng.stat_delta[2]])      # (one launch)
                     else:
                         self.window.reduce_flat(eng.flat[:14 * P])
                     if self._ba_ids:
