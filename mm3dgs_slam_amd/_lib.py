@@ -19,6 +19,10 @@ class Mm3dgsCamera(C.Structure):
     ]
 
 
+# flags of the SLAM entry points (include/mm3dgs.h: MM3DGS_FWD_*; tests/test_cabi.py holds these to the header)
+FWD_STATE_CLEAN, FWD_SHORT_LISTS, FWD_DIRECT_BINS, FWD_KEEP_TILE_ORDER, FWD_PROJECTED = 1, 2, 4, 8, 16
+
+
 class Mm3dgsHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("max_tile_len", C.c_uint32),
                 ("max_num_rendered", C.c_uint32), ("fwd_wave_iters", C.c_uint32), ("bwd_wave_iters", C.c_uint32),

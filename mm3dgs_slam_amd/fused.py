@@ -138,7 +138,7 @@ class FusedEngine:
 
     def _flags(self):
         """STATE_CLEAN | SHORT_LISTS (hint from the last header check) | DIRECT_BINS (the capacity was sized per tile)."""
-        return 1 | (2 if self.max_tile_len <= 1400 else 0) | (4 if self.direct else 0)
+        return _lib.FWD_STATE_CLEAN | (_lib.FWD_SHORT_LISTS if self.max_tile_len <= 1400 else 0) | (_lib.FWD_DIRECT_BINS if self.direct else 0)
 
     def inputs(self, pose, g):
         si = _lib.Mm3dgsSlamInputs()
@@ -208,7 +208,7 @@ class FusedEngine:
             if grads is not None:
                 sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
                 sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
-        flags = self._flags() | (8 if keep_tile_order else 0) | (16 if projected else 0)
+        flags = self._flags() | (_lib.FWD_KEEP_TILE_ORDER if keep_tile_order else 0) | (_lib.FWD_PROJECTED if projected else 0)
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                             _p(self.img_state), _p(self.binning), self.n_cap, flags, C.byref(lcfg), _p(self.loss_work),

@@ -73,3 +73,13 @@ def test_struct_layouts_of_the_binding_match_the_header(tmp_path):
         assert int(got[n]) == C.sizeof(c), (n, got[n], C.sizeof(c))
         for f in c._fields_:
             assert int(got[f"{n}.{f[0]}"]) == getattr(c, f[0]).offset, (n, f[0])
+
+
+def test_flag_constants_of_the_binding_equal_the_headers_defines():
+    import re
+    from mm3dgs_slam_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mm3dgs.h")).read()
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+MM3DGS_FWD_(\w+)\s+(\d+)", text)}
+    assert defines == {"STATE_CLEAN": _lib.FWD_STATE_CLEAN, "SHORT_LISTS": _lib.FWD_SHORT_LISTS, "DIRECT_BINS": _lib.FWD_DIRECT_BINS,
+                       "KEEP_TILE_ORDER": _lib.FWD_KEEP_TILE_ORDER, "PROJECTED": _lib.FWD_PROJECTED}, defines
+    assert len(set(defines.values())) == len(defines) and all(v & (v - 1) == 0 for v in defines.values())     # distinct single bits
