@@ -74,6 +74,10 @@ typedef struct Mm3dgsHeader {
   uint32_t tile_order_tiles;  /* 0: workgroup -> tile by arithmetic; H << 16 | W: image_state holds a load-balanced workgroup -> tile table
                                  for an H x W image, written by the SLAM loop entry points from the list lengths of the last render
                                  (any permutation of the tiles renders the same image; only the speed depends on it) */
+  uint32_t overflow_seen;     /* ABI 205: the value of `overflow` as the mapping-mode backward compositor of an iteration found it, i.e. after
+                                 every launch of THAT iteration's forward.  The fused backward projection + next projection launch reads
+                                 this copy: its second half bins the NEXT view and may raise `overflow` while workgroups of its first half
+                                 are still starting -- with the copy, all of them take the same step / no-step decision */
 } Mm3dgsHeader;
 
 struct Mm3dgsLossConfig;   /* defined with mm3dgs_loss below; the SLAM loop entry points take a pointer to it */
@@ -358,7 +362,14 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 double mm3dgs_profile_event_overhead_ms(void* stream);
 
 const char* mm3dgs_last_error(void);
-int mm3dgs_version(void);   /* 100: round 1; 200: direct bins; 201: this header (Mm3dgsLossConfig grew by three fields) */
+/* ABI version of the library = the version of this header (tests/test_cabi.py holds the two together).
+   100: round 1 | 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points
+   201: Mm3dgsLossConfig grew by the three splatam fields | 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
+   203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations are void
+   204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / MM3DGS_FWD_KEEP_TILE_ORDER
+   205: Mm3dgsHeader.overflow_seen (appended) */
+#define MM3DGS_ABI_VERSION 205
+int mm3dgs_version(void);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms) {
 }
 
 const char* mm3dgs_last_error(void) { return g_err; }
-int mm3dgs_version(void) { return 204; }   // 204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / KEEP_TILE_ORDER; 203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations void; 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points; 201: splatam loss fields; 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
+int mm3dgs_version(void) { return MM3DGS_ABI_VERSION; }   // (history in include/mm3dgs.h)
 
 size_t mm3dgs_geom_bytes(int P) { return geom_bytes_impl(P > 0 ? P : 1); }
 size_t mm3dgs_image_bytes(int H, int W) { return image_bytes_impl(H, W); }
@@ -389,7 +389,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     launch_slam_bwd_project(cd, P, slam_in(in), (int32_t*)radii, g, image_view((void*)image_state, cd.H, cd.W), b, N_capacity, bw, sg, ma, fuse_next_pose,
                             db_bwd.bin_cap, db_bwd.rec_cap, db_bwd.slot_bits, s);
   } else
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on, &iv.hdr->overflow, pose_finish_ticket(iv)); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s); launch_slam_preprocess_bwd(cd, P, slam_in(in), radii, g, b, N_capacity, bw, sg, dL_dpose, pa, ma, s, pls.rows ? &pls : nullptr, prior_loss4, db_bwd.on, &iv.hdr->overflow); }
   return check_launch("slam_backward");
 }
 

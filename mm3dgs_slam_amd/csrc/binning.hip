@@ -292,11 +292,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         const uint4 q = sc[w];
-#if defined(MM3DGS_ORDER_ROWSTEPS)                      // developer experiment (tools/build_variant.sh): load = row steps instead of wave steps
-        m += q.x + q.y + q.z + q.w;
-#else
-        m += max(max(q.x, q.y), max(q.z, q.w));
-#endif
+        m += max(max(q.x, q.y), max(q.z, q.w));        // load = wave steps (row steps as the load measured the same: DESIGN.md section 4)
       }
       m += 1u;                                         // (a real tile outranks the padding; an unrendered grid cuts into equal spans)
     }
@@ -309,8 +305,6 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   __syncthreads();
   uint32_t base = incl - mine_sum;
   for (int q = 0; q < wv; q++) base += wsum[q];
-  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  (void)total;
   if (tid == 0) pre[0] = 0u;
   {
     uint32_t run = base;
@@ -322,24 +316,9 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
     }
   }
   __syncthreads();
-  // cut k = first tile index whose prefix reaches k / 8 of the total (binary search; every workgroup computes all nine identically)
-  if (tid < 9) {
-    int c = tid == 8 ? T : 0;
-    if (tid > 0 && tid < 8) {
-#if !defined(MM3DGS_ORDER_LOAD_SPANS)                  // default: equal-count spans (the arithmetic map's spans)
-      c = min(T, tid * ((T + 7) >> 3));
-#else
-      const unsigned long long want = (unsigned long long)total * (unsigned)tid;      // pre[c] * 8 >= total * k
-      int lo = 0, hi = T;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((unsigned long long)pre[mid] * 8ull >= want) hi = mid; else lo = mid + 1;
-      }
-      c = lo;
-#endif
-    }
-    cut[tid] = c;
-  }
+  // cut k: equal-count spans, the arithmetic map's (spans of equal LOAD measured no better on a bounded trajectory and 1.2 % slower on a
+  // moving one: DESIGN.md section 4); every workgroup computes all nine identically
+  if (tid < 9) cut[tid] = tid == 8 ? T : min(T, tid * ((T + 7) >> 3));
   __syncthreads();
   // a span that would not fit its XCD's workgroup slots: fall back to equal-count spans (the same decision in every workgroup)
   bool fits = true;
@@ -361,14 +340,7 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
     rank += (o > mine || (o == mine && k < j)) ? 1 : 0;
   }
   const int R = (per + 31) >> 5;                       // rounds; CU slots c < full hold R workgroups, the others R - 1
-#if defined(MM3DGS_ORDER_PLAIN)                          // developer experiment: plain serpentine over all 32 slots (ignores which slots hold one workgroup less)
-  const int full = 32, L = 0, n_light = 0;
-#else
   const int full = per - (R - 1) * 32, L = 32 - full, n_light = L * (R - 1);
-#endif
-#if defined(MM3DGS_ORDER_REVERSED)                       // developer experiment: the LIGHTEST tiles to the slots with one workgroup less (should lose)
-  rank = per - 1 - rank;
-#endif
   int r, c;
   if (rank < n_light) {                                // heaviest tiles: the slots with one workgroup less, serpentine over their R - 1 rounds
     r = rank / L;

@@ -189,8 +189,8 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, cam.exp, direct_blocks, direct_cap, slot_bits, 1);
-  if (cam.exp & 2) return;   // MM3DGS_EXP probe: sort phase only (timing only)
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, PROBE_WORD(cam), direct_blocks, direct_cap, slot_bits, 1);
+  if (PROBE(cam, 1)) return;   // (-DMM3DGS_PROBES builds only: sort phase alone, timing)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
   composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
 
@@ -436,27 +436,6 @@ struct SepReduce2 {
 //         -- the chain rule of the depth bundle folded into the reduction -- and dopacity = M0 / opacity (10 floats, not 12).
 // MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
 // (a device function: the tracking loop runs it in the same launch as the sort and the forward compositor, see below)
-#ifdef MM3DGS_BWD_OLD_INDEX      // developer A/B (tools/build_variant.sh): the separate LDS array of record indices
-#define BWD_OLD_INDEX 1
-#else
-#define BWD_OLD_INDEX 0
-#endif
-// u = o dL/dalpha G with two selects (a_eff, G_eff).  Measured alternative (-DMM3DGS_BWD_NEW_U): ONE select of the un-clamped o G, alpha =
-// min(0.99, .) of it, u = dL/dalpha (o G) -- two instructions less per (row, splat) step, six registers less, and 1.3 us SLOWER (62.6 vs 61.0 us,
-// tools/ab_lib.sh): the select moves into the dependent chain alpha -> 1 - alpha -> rcp -> T that every step waits on.
-#ifdef MM3DGS_BWD_NEW_U
-#define BWD_OLD_U 0
-#else
-#define BWD_OLD_U 1
-#endif
-// -DMM3DGS_BWD_EARLY_FIRST: the first chunk's loads (n_contrib -> list entry -> splat record, three dependent round trips) requested BEFORE the
-// loss prologue and held in registers across it.  Measured 0.9 us SLOWER (59.97 vs 59.09 us, same box, tools/ab_lib.sh): the chain's two waits
-// now sit in front of the prologue's own loads, which start two round trips later -- the latency moves, it does not overlap.
-#ifdef MM3DGS_BWD_EARLY_FIRST
-#define BWD_EARLY_FIRST 1
-#else
-#define BWD_EARLY_FIRST 0
-#endif
 #define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * STG_N + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
 template <int C, int MODE>
 __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
@@ -478,25 +457,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   const uint2* __restrict__ list = b.sublist + (size_t)NLIST * start + (size_t)L * len;
 
   constexpr int NV = MODE == 0 ? 6 + C : (MODE == 1 ? 10 : 7);   // floats per record
-  // per-tile combine (end of this function).  Measured on a static 150 k scene (tools/exp_ab.sh, MM3DGS_EXP bits 4 / 5): the pass costs
-  // 7.6 us of a 77.5 us launch -- 4.7 without its record loads (barrier, table loads, stores: the tail of every workgroup, and all
-  // 1200 of them end together), 2.9 for the loads; 2, 4 or 8 records in flight make no difference, and requesting the lane's table
-  // entries up here (COMBINE_TPRE) costs 5.5 us more than it saves.
-#ifndef COMBINE_TPRE
-#define COMBINE_TPRE 0
-#endif
-#ifndef COMBINE_UR
-#define COMBINE_UR 4
-#endif
-  constexpr int TPRE = COMBINE_TPRE;
-  unsigned long long tpl[TPRE > 0 ? TPRE : 1];
-  uint32_t ttr[TPRE > 0 ? TPRE : 1];
-#pragma unroll
-  for (int j = 0; j < TPRE; j++) {
-    const uint32_t e = (uint32_t)tid + 256u * (uint32_t)j;
-    tpl[j] = (MODE != 0 && e < len) ? b.payload[start + e] : 0ull;
-    ttr[j] = (MODE != 0 && e < len) ? b.trec[start + e] : 0xffffffffu;
-  }
+  // (the per-tile combine at the end of this function costs 7.6 us of a 77.5 us launch on a static 150 k scene: 4.7 without its record
+  //  loads -- barrier, table loads, stores: the tail of every workgroup -- and 2.9 for the loads; 2, 4 or 8 records in flight make no
+  //  difference, and requesting a lane's table entries up here costs more than it saves: DESIGN.md section 4)
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
   constexpr int RECF = MODE == 0 ? NV : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats: packed at the record's real size (composite_common.h; generic: 6 + C)
   // [buffer][wave][field A|B|C][row * 16 + entry] + [buffer][wave][row * 16 + entry] record indices: lane-contiguous
@@ -519,14 +482,6 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   todo = min(todo, count);
   const uint32_t maxtodo = max(max((uint32_t)__builtin_amdgcn_readlane((int)todo, 0), (uint32_t)__builtin_amdgcn_readlane((int)todo, 16)),
                                max((uint32_t)__builtin_amdgcn_readlane((int)todo, 32), (uint32_t)__builtin_amdgcn_readlane((int)todo, 48)));
-  // (experiment BWD_EARLY_FIRST, see above: the first chunk requested here, ahead of the loss prologue)
-  uint2 e0 = make_uint2(0u, 0u), ent_nxt = make_uint2(0u, 0u);
-  SplatRec r0;
-  if constexpr (BWD_EARLY_FIRST) {
-    e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
-    ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
-    r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
-  }
   float dL[C];
   float bg_dot = 0.f;
   bool dl_done = false;
@@ -587,25 +542,21 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   if (MODE != 0 && !SEP_REDUCE2) SepReduce<MODE == 1>::ymult(q, ym_0, ym_1a, ym_1b);
   // this lane's component of record 0; the list entries carry the record index of their (splat, block)
   float* const my_rec = dsub + (my_slot >= 0 ? my_slot : 0);
-  const uint32_t my_slot_bytes = (uint32_t)(my_slot >= 0 ? my_slot : 0) * 4u;
-  (void)my_slot_bytes;
   uint32_t n_visit = 0, n_red = 0;
 
   // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front)
   {
-    if constexpr (!BWD_EARLY_FIRST) {
-      e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
-      r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
-    }
+    const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
+    SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
     // SLAM modes: the entry's gradient-record index rides in the staged record's constant field (C.z = the "1" of [z, 1, z^2]): one LDS
     // read and its address less per (row, splat) step than a separate index array
-    if constexpr (MODE != 0 && !BWD_OLD_INDEX) r0.C.z = __uint_as_float(e0.y);
+    if constexpr (MODE != 0) r0.C.z = __uint_as_float(e0.y);
     stg[0][wv][0][slane] = r0.A;
     stg[0][wv][1][slane] = r0.B;
     if (C > 2) stg[0][wv][2][slane] = r0.C;
-    if constexpr (MODE == 0 || BWD_OLD_INDEX) stgi[0][wv][lane] = e0.y;
+    if constexpr (MODE == 0) stgi[0][wv][lane] = e0.y;
   }
-  if constexpr (!BWD_EARLY_FIRST) ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
+  uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
 
   // The SLAM losses leave the silhouette and depth^2 channels without gradient (dL[4] = dL[5] = 0): a wave that sees only
@@ -615,17 +566,17 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
     SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
-    if constexpr (MODE != 0 && !BWD_OLD_INDEX) rec_n.C.z = __uint_as_float(ent_nxt.y);
+    if constexpr (MODE != 0) rec_n.C.z = __uint_as_float(ent_nxt.y);
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
     const float4 (*wS)[STG_N] = stg[cur][wv];
     const int r16i = row * 16;
     const int r16 = row * STG_ROW;
     const uint32_t* wI = stgi[cur][wv];
-    auto pair_of = [&](int j) { return (MODE == 0 || BWD_OLD_INDEX) ? wI[r16i + j] : 0u; };
+    auto pair_of = [&](int j) { return MODE == 0 ? wI[r16i + j] : 0u; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti_in, const int j) {
-      const uint32_t ti = (MODE == 0 || BWD_OLD_INDEX) ? ti_in : __float_as_uint(Cc.z);
+      const uint32_t ti = MODE == 0 ? ti_in : __float_as_uint(Cc.z);
       const bool row_on = base + (uint32_t)j < todo;          // this row still has an entry at this step
       const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the row's list (garbage when !row_on)
       const float dx = A.x - pxf, dy = A.y - pyf;
@@ -638,29 +589,20 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
       n_visit++;
       if (MODE != 0 || __ballot(valid) != 0ull) {   // SLAM modes: four rows with different splats -- a whole-wave miss is rare, the vote is not worth its cost
         n_red++;
-        // SLAM modes: ONE select -- the un-clamped o G where the splat counts, 0 elsewhere: alpha = min(0.99, .) of it (min(0.99, 0) = 0) and
-        // u = dL/dalpha (o G) directly (generic mode also needs G alone for the opacity gradient)
-        const float raw_eff = valid ? araw : 0.f;
-        const float a_eff = (MODE == 0 || BWD_OLD_U) ? (valid ? alpha : 0.f) : fminf(0.99f, raw_eff);
+        // two selects (a_eff, G_eff).  ONE select of the un-clamped o G with alpha = min(0.99, .) of it is two instructions and six registers
+        // less and measured 1.3 us SLOWER: the select moves into the dependent chain alpha -> 1 - alpha -> rcp -> T
+        const float a_eff = valid ? alpha : 0.f;
         const float G_eff = valid ? G : 0.f;
         // generic mode: the reciprocal to within an ulp -- T is rebuilt by ~50 successive divisions per pixel and the raw 1-ulp v_rcp_f32 showed up as
         // 5e-6 of noise on every gradient (camera gradients are held to 1e-5).  v_rcp_f32 + one Newton step holds the same bars as the IEEE
-        // division sequence (tests/test_gpu_parity.py) at 3 instead of ~10 instructions: 1080p / 3 M backward compositor 1327 -> 1291 us
-        // (-DMM3DGS_GENERIC_IEEE_DIV: the division).  The SLAM modes keep the raw v_rcp_f32.
+        // division sequence (tests/test_gpu_parity.py) at 3 instead of ~10 instructions: 1080p / 3 M backward compositor 1327 -> 1291 us.
+        // The SLAM modes keep the raw v_rcp_f32 (an exact division changes none of their parity figures: measured, round 3).
         float r;
         if constexpr (MODE == 0) {
-#if defined(MM3DGS_GENERIC_IEEE_DIV)
-          r = 1.f / (1.f - a_eff);
-#else
           const float d = 1.f - a_eff, r0 = __builtin_amdgcn_rcpf(d);
           r = fmaf(fmaf(-d, r0, 1.f), r0, r0);
-#endif
         } else {
-#ifdef MM3DGS_SLAM_EXACT_DIV      // developer experiment (tools/build_variant.sh): what the 1-ulp v_rcp_f32 costs the SLAM modes in accuracy
-          r = 1.f / (1.f - a_eff);
-#else
           r = __builtin_amdgcn_rcpf(1.f - a_eff);
-#endif
         }
         Tr *= r;  // transmittance in front of this splat
         const float w = a_eff * Tr;
@@ -669,7 +611,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         if constexpr (C > 1) col[1] = B.w;
         if constexpr (C > 2) col[2] = Cc.x;
         if constexpr (C > 3) col[3] = Cc.y;
-        if constexpr (C > 4) col[4] = (MODE == 0 || BWD_OLD_INDEX) ? Cc.z : 1.f;      // (SLAM modes: that field carries the record index; the channel is the constant 1)
+        if constexpr (C > 4) col[4] = MODE == 0 ? Cc.z : 1.f;      // (SLAM modes: that field carries the record index; the channel is the constant 1)
         if constexpr (C > 5) col[5] = Cc.w;
         // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: track the dL-weighted colour behind as ONE scalar
         // (behind_dot) instead of C running colours: qd = c . dL;  dLa = qd - behind_dot;  behind_dot += a (qd - behind_dot)
@@ -681,7 +623,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         const float dLa = diff * Tr - Tf_bg * r;
         // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
         // into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
-        const float u = (MODE == 0 || BWD_OLD_U) ? B.y * dLa * G_eff : dLa * raw_eff;
+        const float u = B.y * dLa * G_eff;
         if constexpr (MODE == 0) {
           float vals[NV];
 #pragma unroll
@@ -702,21 +644,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
-#ifdef MM3DGS_REC_OFF32
-      // (variant: 32-bit byte offset = two shift-adds + an SGPR base instead of v_mad_u64_u32; needs 16 N_cap RECF 4 < 2^32)
-      if (my_slot >= 0 && row_on && !(cam.exp & 1)) {
-        // (inline asm: left to the compiler, the shift-adds are folded back into a v_mad_u64_u32)
-        uint32_t off;
-        if constexpr (RECF == 10) {       // 5 ti, then 40 ti + 4 slot
-          asm("v_lshl_add_u32 %0, %1, 2, %1\n\tv_lshl_add_u32 %0, %0, 3, %2" : "=&v"(off) : "v"(ti), "v"(my_slot_bytes));
-        } else if constexpr (RECF == 7) { // 8 ti - ti, then 28 ti + 4 slot
-          asm("v_lshlrev_b32 %0, 3, %1\n\tv_sub_u32 %0, %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(off) : "v"(ti), "v"(my_slot_bytes));
-        } else off = ti * (uint32_t)(RECF * 4) + my_slot_bytes;
-        *(float*)((char*)dsub + off) = tot;
-      }
-#else
-      if (my_slot >= 0 && row_on && !(cam.exp & 1)) my_rec[(size_t)ti * RECF] = tot;
-#endif
+      if (my_slot >= 0 && row_on && !PROBE(cam, 0)) my_rec[(size_t)ti * RECF] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
@@ -737,7 +665,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     stg[cur ^ 1][wv][0][slane] = rec_n.A;
     stg[cur ^ 1][wv][1][slane] = rec_n.B;
     if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
-    if constexpr (MODE == 0 || BWD_OLD_INDEX) stgi[cur ^ 1][wv][lane] = ent_nxt.y;
+    if constexpr (MODE == 0) stgi[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   };
@@ -762,7 +690,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
       float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
       while (mask) {
         // a few records in flight (a pair lists ~4 blocks on average: one round for most)
-        constexpr int UR = COMBINE_UR;
+        constexpr int UR = 4;
         float4 ra[UR], rb[UR], rc[UR];
         bool on[UR];
 #pragma unroll
@@ -771,7 +699,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
           const int L = on[u] ? __ffs((int)mask) - 1 : 0;
           mask &= mask - 1u;
           const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
-          const float* r = dsub + ((on[u] && !(cam.exp & 16)) ? (size_t)rec * RECF : (size_t)0);      // (MM3DGS_EXP bit 4: timing probe without the record gather)
+          const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? (size_t)rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
           ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
           rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -790,12 +718,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
       }
     };
-    if (!(cam.exp & 32)) {      // (MM3DGS_EXP bit 5: timing probe without the combine)
-#pragma unroll
-    for (int j = 0; j < TPRE; j++)
-      if ((uint32_t)tid + 256u * (uint32_t)j < len) combine(tpl[j], ttr[j]);
-    for (uint32_t e = (uint32_t)tid + 256u * TPRE; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
-    }
+    if (!PROBE(cam, 5))      // (probe builds, bit 5: timing without the combine)
+      for (uint32_t e = (uint32_t)tid; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
   }
 }
 
@@ -812,6 +736,9 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
+  // every launch of this iteration's forward has retired: what the sticky overflow word holds NOW is what the whole backward projection that
+  // follows must act on (Mm3dgsHeader.overflow_seen; its fused second half bins the next view and may raise the word itself)
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) iv.hdr->overflow_seen = iv.hdr->overflow;
   composite_bwd_body<C, MODE>(tile, cam, g, iv, b, N_cap, dL_dout, dsub, has_tl, tl, dl_planes, smem_raw);
 }
 

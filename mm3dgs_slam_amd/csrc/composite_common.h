@@ -30,12 +30,8 @@ __device__ __forceinline__ void st_part(float* p, const float4& v, int n) {
 }
 
 // exp of the Gaussian's power: v_exp_f32 on power * log2(e) (forward and backward use the same sequence: same decisions).
-// MM3DGS_SLAM_EXACT_EXP: developer experiment (tools/build_variant.sh) with the correctly rounded expf.
-#ifdef MM3DGS_SLAM_EXACT_EXP
-#define SPLAT_EXP(p) expf(p)
-#else
+// (the correctly rounded expf changes none of the parity figures: measured in round 3)
 #define SPLAT_EXP(p) __expf(p)
-#endif
 #define ALPHA_MIN (1.0f / 255.0f)
 #define T_EPS 0.0001f
 
@@ -58,15 +54,10 @@ __device__ __forceinline__ int slam_tile(const CamDev& cam, const ImageView& iv,
   }
   return tile;
 }
-// workgroups of a SLAM compositor launch: with the tile table every XCD gets TILE_SPAN_SLOTS slots (its load-cut span may hold more than T / 8 tiles)
+// workgroups of a SLAM compositor launch: ceil(T / 8) slots per XCD
 static inline int slam_grid(const CamDev& cam, int T) {
-  const int n = ((T + 7) / 8) * 8;
-#if defined(MM3DGS_ORDER_LOAD_SPANS)
-  return (cam.tile_table && T >= 64 && (T + 7) / 8 <= 160) ? 8 * TILE_SPAN_SLOTS : n;
-#else
   (void)cam;
-  return n;
-#endif
+  return ((T + 7) / 8) * 8;
 }
 
 // identical instruction sequence in forward and backward so both take the same skip decisions

@@ -25,10 +25,7 @@
 // gather (its wave-level work lists, 28 KB of LDS) 128 lanes spread better over the CUs (mapping 33.1 -> 30.8 us); with one record per
 // (tile, splat) pair the kernel is two short rounds of loads and 256 lanes win again (mapping 19.1 -> 18.6 us, and the pose-finish
 // kernel reads half the rows: 8.4 -> 7.3 us).  The partial-row region of the scratch holds (P / 256 + 1) * 64 floats: 64-lane groups would not fit.
-#ifndef SLAM_BWD_FB
 #define SLAM_BWD_FB 256
-#endif
-static_assert(SLAM_BWD_FB == 128 || SLAM_BWD_FB == 256, "the partial-row region holds (P / 256 + 1) * 64 floats");
 #define SH_C0F 0.28209479177387814f
 
 struct PoseDev { float R[3][3]; float t[3]; float qn[4]; float inv_norm; };
@@ -337,7 +334,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   const bool droppable = c.area > 0 && c.area <= 32;
   if (droppable) {
     int ttx = c.minx, tty = c.miny;
-    const int kmax = (cam.exp & 128) ? min(c.area, OWN) : c.area;      // (MM3DGS_EXP bit 7: timing probe, only the own pairs counted)
+    const int kmax = PROBE(cam, 7) ? min(c.area, OWN) : c.area;      // (probe builds, bit 7: only the own pairs counted)
     for (int k = 0; k < kmax; k++) {
       bool count = true;
       if (k < OWN) {
@@ -351,7 +348,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
     }
   }
   if (live) g.clamped[idx] = (uint8_t)(pr.cl | (empty4 << 4));
-  if (cam.exp & 256) big = 0ull;      // (MM3DGS_EXP bit 8: timing probe without the > 32-tile splats' counting)
+  if (PROBE(cam, 8)) big = 0ull;      // (probe builds, bit 8: without the > 32-tile splats' counting)
   for (unsigned long long bb = big; bb; bb &= bb - 1) {
     const int src = __ffsll((long long)bb) - 1;
     const int sminx = __builtin_amdgcn_readlane(c.minx, src), sminy = __builtin_amdgcn_readlane(c.miny, src);
@@ -378,7 +375,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
     }
   }
   const uint32_t incl = wave_scan_incl((uint32_t)max(c.area - OWN, 0));
-  const uint32_t S = (cam.exp & 64) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (MM3DGS_EXP bit 6: timing probe without the shared list)
+  const uint32_t S = PROBE(cam, 6) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (probe builds, bit 6: without the shared list)
   if (S) {   // wave-uniform
     __shared__ uint32_t s_pref[FB / 64][64];
     __shared__ PairCtx s_ctx[FB / 64][64];
@@ -476,7 +473,7 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 // stepped: (the map's in-kernel Adam, ma.on) the lane's parameters AFTER the step -- what the next iteration's projection reads
-template <bool TRACK, bool DIRECT, bool WORLD = false, bool ROW_THROUGH = false>
+template <bool TRACK, bool DIRECT, bool WORLD = false>
 __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
                                               uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
                                               const MapAdam& ma, RawGaussian* stepped, const uint32_t* __restrict__ ovf) {
@@ -747,8 +744,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       float t = red[0][k];
 #pragma unroll
       for (int w = 1; w < SLAM_BWD_FB / 64; w++) t += red[w][k];
-      if constexpr (ROW_THROUGH) __hip_atomic_store(posepartial + (size_t)blockIdx.x * 32 + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else posepartial[(size_t)blockIdx.x * 32 + k] = t;
+      posepartial[(size_t)blockIdx.x * 32 + k] = t;
     }
   }
 }
@@ -772,7 +768,9 @@ slam_bwd_project_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
   const int idx = blockIdx.x * FB + tid;
   RawGaussian rg = {{0.f, 0.f, 0.f}, {1.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
-  slam_bwd_body<false, true, WORLD>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg, &iv.hdr->overflow);
+  // (the overflow word as the backward compositor of this iteration found it: the binning half below may set the live word while
+  //  workgroups of this half are still starting, and a partially stepped map is worse than either outcome)
+  slam_bwd_body<false, true, WORLD>(cam, P, in, radii, g, N_cap, dsub, nullptr, out, ma, &rg, &iv.hdr->overflow_seen);
   const Projected pr = slam_project_vals(cam, idx < P, idx, next_pose, in.isotropic != 0, rg, radii, g, WORLD);
   slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
 }
@@ -865,18 +863,7 @@ __device__ __forceinline__ double pow_int(double b, int t) {
 // Adam step of slam/tracker.py:233-246,160-162 (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8) -- entirely on the device, so
 // a tracking iteration needs no host round trip.  One workgroup of 16 * NG lanes: lane = 16 * rowgroup + column; NG row groups keep the
 // dependent-load chains short, then the groups are added in a fixed order (deterministic, double precision).
-struct PoseFinish {
-  const float* pose_in; float* dpose; PoseAdam ad; PoseLossScale pls; float* ad_loss4;
-  uint32_t* ticket;     // NULL: the finish runs as its own launch (slam_pose_finish_kernel)
-};
-// COHERENT: the rows were written by other workgroups of THIS launch (device-scope stores, see slam_preprocess_bwd_kernel): read them past
-// this XCD's L2
-template <bool COHERENT>
-__device__ __forceinline__ float row_load(const float* p) {
-  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <int NG, bool COHERENT>
+template <int NG>
 __device__ __forceinline__ void pose_finish_body(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
                                                  float* __restrict__ dpose, const PoseAdam& ad, const PoseLossScale& pls, float* __restrict__ ad_loss4,
                                                  const uint32_t* __restrict__ ovf) {
@@ -917,14 +904,14 @@ __device__ __forceinline__ void pose_finish_body(const float* __restrict__ posep
       for (; r + 7 * NG < nrows; r += 8 * NG) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = row_load<COHERENT>(posepartial + (size_t)(r + u * NG) * 32 + col);
+        for (int u = 0; u < 8; u++) v[u] = *(posepartial + (size_t)(r + u * NG) * 32 + col);
 #pragma unroll
         for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
       }
       {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (r + u * NG < nrows) ? row_load<COHERENT>(posepartial + (size_t)(r + u * NG) * 32 + col) : 0.f;
+        for (int u = 0; u < 8; u++) v[u] = (r + u * NG < nrows) ? *(posepartial + (size_t)(r + u * NG) * 32 + col) : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; u += 2) { a0 += (double)v[u]; a1 += (double)v[u + 1]; }
       }
@@ -1039,71 +1026,36 @@ __device__ __forceinline__ void pose_finish_body(const float* __restrict__ posep
 __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __restrict__ posepartial, int nrows, const float* __restrict__ pose_in,
                                         float* __restrict__ dpose, PoseAdam ad, PoseLossScale pls, float* __restrict__ ad_loss4,
                                         const uint32_t* __restrict__ ovf) {
-  pose_finish_body<64, false>(posepartial, nrows, pose_in, dpose, ad, pls, ad_loss4, ovf);
+  pose_finish_body<64>(posepartial, nrows, pose_in, dpose, ad, pls, ad_loss4, ovf);
 }
 
 // The backward projection of an iteration that needs the pose gradient (every tracking iteration; mapping views under bundle adjustment).
-// fin.ticket != NULL (-DMM3DGS_POSE_FINISH_MERGED, a measured and REJECTED experiment): the workgroup that finishes last also runs the pose
-// finish -- each workgroup takes a ticket once its partial row is in memory, the holder of the last one sums the rows and takes the pose's
-// Adam step, and the one-workgroup finish launch (6.8 us, 100 per frame) disappears.  Measured on the bench's tracking iterations (157 k
-// Gaussians, 614 workgroups; tools/ab_lib.sh): with a release fence per workgroup and an acquire in the last one (an L2 write-back /
-// invalidate on this part: 8 XCDs, one L2 each) the launch takes 31.8 us against 9.1 + 6.8 for the two launches; without fences -- the
-// rows as device-scope stores written through the L2, the ticket taken after s_waitcnt vmcnt(0) + a workgroup barrier, device-scope loads
-// in the last workgroup -- 25.1 us: every workgroup's tail now waits for a store and an atomic to reach memory (~4 us), and the last
-// workgroup's 256 lanes fetch their 39 rows each past the L2.  The separate launch, whose rows come out of the L2, stays.
-#ifdef MM3DGS_POSE_FINISH_MERGED
-#define POSE_FINISH_PARAM , PoseFinish fin
-#define POSE_FINISH_ARG(x) , x
-#else      // (the default build's kernel does not even carry the argument: its 150 bytes of kernarg cost the 9 us launch 1.3 us)
-#define POSE_FINISH_PARAM
-#define POSE_FINISH_ARG(x)
-#endif
+// (The pose finish in the LAST workgroup of this launch -- a ticket counter -- was measured and rejected: 25 .. 32 us against 9.1 + 6.8 for the two
+// launches; the finish stays a one-workgroup launch of its own, slam_pose_finish_kernel.)
 template <bool TRACK, bool DIRECT, bool WORLD>
 __global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
-                           const uint32_t* __restrict__ ovf POSE_FINISH_PARAM) {
-#ifdef MM3DGS_POSE_FINISH_MERGED
-  if (fin.ticket) {      // (kernel-uniform)
-    slam_bwd_body<TRACK, DIRECT, WORLD, true>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
-    __shared__ uint32_t last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's row stores have reached memory
-    __syncthreads();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
-    __syncthreads();
-    if (last) {          // (workgroup-uniform)
-      static_assert(SLAM_BWD_FB == 256, "the in-kernel pose finish uses 16 row groups of 16 columns");
-      pose_finish_body<SLAM_BWD_FB / 16, true>(posepartial, (int)gridDim.x, fin.pose_in, fin.dpose, fin.ad, fin.pls, fin.ad_loss4, ovf);
-      if (threadIdx.x == 0) *fin.ticket = 0u;
-    }
-    return;
-  }
-#endif
-  slam_bwd_body<TRACK, DIRECT, WORLD, false>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+                           const uint32_t* __restrict__ ovf) {
+  slam_bwd_body<TRACK, DIRECT, WORLD>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls, float* loss4, bool direct, const uint32_t* ovf, uint32_t* ticket) {
+                                const PoseLossScale* pls, float* loss4, bool direct, const uint32_t* ovf) {
   const uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   const bool want_pose = dpose != nullptr || ad.pose != nullptr;
   float* partial = want_pose ? bw.campartial : nullptr;
   const PoseLossScale none = {nullptr, 0, 0.f, nullptr};
-#ifndef MM3DGS_POSE_FINISH_MERGED     // developer experiment, measured and rejected (see slam_preprocess_bwd_kernel): the finish in the last workgroup
-  ticket = nullptr;
-#endif
-  const bool merged = want_pose && ticket != nullptr && P > 0;
   if (P > 0) {
     const bool map = out.d_xyz || ma.on;
     auto kern = in.world ? (map ? (direct ? slam_preprocess_bwd_kernel<false, true, true> : slam_preprocess_bwd_kernel<false, false, true>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, true> : slam_preprocess_bwd_kernel<true, false, true>))
                          : (map ? (direct ? slam_preprocess_bwd_kernel<false, true, false> : slam_preprocess_bwd_kernel<false, false, false>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, false> : slam_preprocess_bwd_kernel<true, false, false>));
-    PoseFinish fin = {in.pose, dpose, ad, pls ? *pls : none, loss4, merged ? ticket : nullptr};
-    (void)fin;
-    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf POSE_FINISH_ARG(fin));
+    hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
   }
-  if (want_pose && !merged) {
+  if (want_pose) {
     // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds
     //  twice as many float rows)
     hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, bw.campartial, P > 0 ? (P + SLAM_BWD_FB - 1) / SLAM_BWD_FB : 0, in.pose, dpose, ad,

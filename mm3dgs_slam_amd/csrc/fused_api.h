@@ -52,8 +52,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
                                 uint32_t* seen_only = nullptr, bool visibility_only = false);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
-                                const PoseLossScale* pls = nullptr, float* loss4 = nullptr, bool direct = false, const uint32_t* overflow_flag = nullptr,
-                                uint32_t* finish_ticket = nullptr);   // finish_ticket: a zero word the launch leaves zero -> the pose finish runs in the last workgroup
+                                const PoseLossScale* pls = nullptr, float* loss4 = nullptr, bool direct = false, const uint32_t* overflow_flag = nullptr);
 // dl_planes: 6, or 4 when the caller guarantees that the silhouette / depth^2 planes of dL are zero AND need not be read
 // (the mapping loop's loss kernel does not even write them)
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,

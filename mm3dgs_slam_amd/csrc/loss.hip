@@ -185,19 +185,11 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
       *(float2*)&hS[4][row][2 * s] = make_float2(e12[0], e12[1]);
     }
     __syncthreads();
-    // vertical pass: one output per lane (all 256), 11 rows of each moment.  (-DMM3DGS_SSIM_V2: two horizontally adjacent outputs per lane on
-    // 128 lanes, 11 ds_read_b64 per moment -- half the LDS reads, but ten moments live in a kernel that is held to 96 registers: 7 - 14 of them
-    // spill and the launch takes 15.8 us instead of 12.3, tools/ab_lib.sh)
-#ifndef MM3DGS_SSIM_V2
+    // vertical pass: one output per lane (all 256), 11 rows of each moment.  (Two horizontally adjacent outputs per lane on 128 lanes -- half the
+    // LDS reads -- keep ten moments live in a kernel that is held to 96 registers: 7 - 14 of them spill, 15.8 us instead of 12.3: DESIGN.md section 4)
     constexpr int NO = 1;
     const int vx = tx, vy = ty;
-    const bool v_on = true;
-#else
-    constexpr int NO = 2;
-    const int vx = 2 * (tid & 7), vy = (tid >> 3) & 15;
-    const bool v_on = tid < 128;
-#endif
-    if (v_on) {
+    {
       float st[5][NO];
 #pragma unroll
       for (int q = 0; q < 5; q++) {
@@ -206,12 +198,7 @@ ssim_maps_kernel(LossCfg cfg, const float* __restrict__ out, const float* __rest
         for (int o = 0; o < NO; o++) acc[o] = 0.f;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
-          if constexpr (NO == 2) {
-            const float2 h = *(const float2*)&hS[q][vy + k][vx];
-            acc[0] = fmaf(cfg.window[k], h.x, acc[0]); acc[NO - 1] = fmaf(cfg.window[k], h.y, acc[NO - 1]);
-          } else {
-            acc[0] = fmaf(cfg.window[k], hS[q][vy + k][vx], acc[0]);
-          }
+          acc[0] = fmaf(cfg.window[k], hS[q][vy + k][vx], acc[0]);
         }
 #pragma unroll
         for (int o = 0; o < NO; o++) st[q][o] = acc[o];

@@ -79,25 +79,13 @@ static inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 // of which its load-cut span of tiles fills the first ones (binning.hip tile_order_kernel)
 #define TILE_SPAN_SLOTS 256
 static inline size_t tile_order_words(size_t T) { size_t n = ((T + 7) / 8) * 8; return n > 8 * TILE_SPAN_SLOTS ? n : (size_t)8 * TILE_SPAN_SLOTS; }
-// workgroup slots per XCD that the table covers: the equal-count spans' ceil(T / 8), or TILE_SPAN_SLOTS in the load-cut experiment build
-static inline __host__ __device__ int slam_span_slots(int T) {
-#if defined(MM3DGS_ORDER_LOAD_SPANS)
-  (void)T; return TILE_SPAN_SLOTS;
-#else
-  return (T + 7) >> 3;
-#endif
-}
+// workgroup slots per XCD that the table covers: the equal-count spans' ceil(T / 8)
+static inline __host__ __device__ int slam_span_slots(int T) { return (T + 7) >> 3; }
 #ifdef __HIPCC__
 // Inclusive prefix sum over the 64 lanes of a wave on the VALU's own crossbars: four shifted adds inside each 16-lane row (row_shr with
 // zero fill), then the last lane of row 0 / row 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31) -- six
 // DPP adds instead of six ds_bpermute round trips through the LDS crossbar (26 ns of latency each, tools/ubench) plus their selects.
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
-#ifdef MM3DGS_SCAN_BPERMUTE
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { const uint32_t y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
-  return x;
-#else
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);     // row_shr:1
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);     // row_shr:2
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);     // row_shr:4
@@ -105,7 +93,6 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
   return x;
-#endif
 }
 #endif
 
@@ -114,9 +101,7 @@ static inline size_t image_bytes_impl(int H, int W) {
   return 256 + align_up(T * 4, 256) + align_up((T + 1) * 4, 256) + align_up(T * 4, 256) + align_up(T * NLIST * 4, 256) +
          align_up(px * 4, 256) + align_up(px * 4, 256) + align_up(tile_order_words(T) * 4, 256);
 }
-// The header block is 256 bytes, Mm3dgsHeader its first words; word 32 is library-private: the ticket counter of the in-kernel pose finish
-// (fused.hip slam_preprocess_bwd_kernel), zero between launches like the rest of the zero-initialised state.
-static inline uint32_t* pose_finish_ticket(const struct ImageView& v);
+// (the header block is 256 bytes, Mm3dgsHeader its first words)
 static inline ImageView image_view(void* base, int H, int W) {
   size_t T = (size_t)tiles_x(W) * tiles_y(H), px = (size_t)H * W;
   char* c = (char*)base;
@@ -132,8 +117,7 @@ static inline ImageView image_view(void* base, int H, int W) {
   v.tile_order = (uint32_t*)c;
   return v;
 }
-static_assert(sizeof(Mm3dgsHeader) <= 128, "word 32 of the header block is the pose-finish ticket");
-static inline uint32_t* pose_finish_ticket(const ImageView& v) { return (uint32_t*)v.hdr + 32; }
+static_assert(sizeof(Mm3dgsHeader) <= 256, "the header block is 256 bytes");
 
 // what Mm3dgsHeader.tile_order_tiles holds while image_state's workgroup -> tile table is valid: the image size it was built for (the
 // table sits behind final_T / n_contrib, so its offset depends on H * W, not on the tile count alone); 0 = no table
@@ -247,7 +231,9 @@ struct CamDev {
   int tilemap;  // 0: tile = workgroup id; 1 (default): contiguous tile span per XCD
   int tile_table; // SLAM entry points with persistent state: honour image_state's load-balanced workgroup -> tile table when it is valid
   int stats;    // count diagnostics into the header (MM3DGS_STATS=1)
-  int exp;      // MM3DGS_EXP: developer experiments (timing only, results invalid; bits 6 - 8: binning without its shared list / big-rectangle counting): bit 0 = backward compositor skips its record stores
+#ifdef MM3DGS_PROBES
+  int probes;   // MM3DGS_EXP bits (see PROBE below)
+#endif
   int sort_single;  // 1: a single sort launch (16 KB LDS tier + global-memory path for longer lists)
   int bg_extras;    // 1 (SLAM entry points): channels 3..5 are the depth bundle of a second reference pass and get T_final * bg[ch - 3] as well
   uint32_t trec_cap; // direct bins: per-tile gradient records per projection workgroup (workgroup w owns [w * trec_cap, (w + 1) * trec_cap)); 0: packed bins (Gaussian-major pair index)
@@ -258,6 +244,18 @@ struct CamDev {
   const float* proj;
   const float* campos;
 };
+// Timing probes of the hot kernels (tools/late_probe.sh, tools/exp_ab.sh: "how long does the launch take without phase X" -- the results of such a
+// run are INVALID).  They exist only in a library built with -DMM3DGS_PROBES (tools/build_variant.sh), where the environment variable MM3DGS_EXP
+// selects them by bit; in the product build PROBE() is the constant 0, the probed branches fold away and the variable is never read.
+//   bit 0: backward compositor without its record stores | 1: sort phase only | 2: no list emission | 3: no sort | 4: combine without its
+//   record gather | 5: no combine | 6: binning without the shared big-splat list | 7: only the own pairs counted | 8: no > 32-tile counting
+#ifdef MM3DGS_PROBES
+#define PROBE(cam, bit) ((((cam).probes) >> (bit)) & 1)
+#define PROBE_WORD(cam) ((cam).probes)
+#else
+#define PROBE(cam, bit) 0
+#define PROBE_WORD(cam) 0
+#endif
 static inline int env_flag(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -273,7 +271,9 @@ static inline CamDev cam_dev(const Mm3dgsCamera* c) {
   d.sh_degree = c->sh_degree;
   d.tilemap = env_flag("MM3DGS_TILEMAP", 1);   // contiguous tile span per XCD: the backward compositor measured 4 % faster (splat records and lists stay in one L2)
   d.stats = env_flag("MM3DGS_STATS", 0);
-  d.exp = env_flag("MM3DGS_EXP", 0);
+#ifdef MM3DGS_PROBES
+  d.probes = env_flag("MM3DGS_EXP", 0);
+#endif
   d.sort_single = 0;
   d.bg_extras = 0;
   d.state_clean = 0;

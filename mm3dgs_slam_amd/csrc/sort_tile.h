@@ -63,9 +63,6 @@ __device__ __forceinline__ uint32_t lane_xor_dpp(uint32_t v) {
 }
 template <int J>
 __device__ __forceinline__ unsigned long long lane_xor64(unsigned long long key, int lane) {
-#ifdef MM3DGS_SORT_BPERMUTE
-  return __shfl_xor(key, J, 64);
-#else
   uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
   if constexpr (J <= 8) {
     lo = lane_xor_dpp<J>(lo); hi = lane_xor_dpp<J>(hi);
@@ -79,7 +76,6 @@ __device__ __forceinline__ unsigned long long lane_xor64(unsigned long long key,
     lo = (lane & 32) ? a[0] : a[1]; hi = (lane & 32) ? b[0] : b[1];
   }
   return ((unsigned long long)hi << 32) | lo;
-#endif
 }
 template <int K, int J>
 __device__ __forceinline__ unsigned long long bitonic_step64(unsigned long long key, int lane) {
@@ -163,7 +159,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
   if (!GLOBAL_TAIL && len > CAP) return false;
   unsigned long long* gk = b.keys + start;
   const bool in_lds = len <= CAP;
-  if (in_lds && (ex & 8)) {   // MM3DGS_EXP probe: no sort (timing only)
+  if (in_lds && (ex & 8)) {   // (probe builds, bit 3: no sort; `ex` is the constant 0 in the product build)
     for (int i = tid; i < len; i += 256) sk[i] = gk[i];
     __syncthreads();
   } else if (in_lds && len <= RANK_SORT_MAX) {
@@ -215,7 +211,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     __syncthreads();
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
   }
-  if (ex & 4) return true;   // MM3DGS_EXP probe: no emission (timing only)
+  if (ex & 4) return true;   // (probe builds, bit 2: no emission)
   if (direct && in_lds && len <= RANK_SORT_MAX && !(ex & 8)) {
     // ---- direct bins: every wave builds the four lists of ITS OWN 8x8 sub-tile (the ones it composites) from the sorted ids
     // and payloads in LDS: ballots and running counts inside the wave, no barriers, no cross-wave prefix

@@ -22,13 +22,21 @@ def get_scale_shift_LS(est_depth, render_depth, mask=None):
     vf = valid.to(est_depth.dtype)
     # normal equations H^T H x = H^T z with H = [est, 1] over the valid pixels, as five masked sums (a [2, HW] x [HW, 2] product is a
     # skinny GEMM: 0.56 ms per call at 640x480 through hipBLASLt -- measured in the first round-4 trace -- against ~10 us per reduction)
-    h = est_depth * vf
+    # (torch.where, not a product with the 0/1 mask: a NaN / inf of the network at a masked-out pixel must not reach the sums -- the
+    #  reference gathers the valid pixels only)
+    h = torch.where(valid, est_depth, torch.zeros_like(est_depth))
     z = torch.where(valid, inv, torch.zeros_like(inv))
     a00, a01, a11 = (h * h).sum(), h.sum(), vf.sum()
     b0, b1 = (h * z).sum(), z.sum()
     det = a00 * a11 - a01 * a01
-    scale = ((a11 * b0 - a01 * b1) / det).reshape(1)
-    shift = ((a00 * b1 - a01 * b0) / det).reshape(1)
+    # a singular system (fewer than two valid pixels, or a constant estimate over them: the reference's torch.inverse raises there) has
+    # no fit: the identity (scale 1, shift 0) is returned instead of NaN / inf that would silently flow into seeding and the Pearson
+    # target -- decided on the device (no host read-back); `fit_ok` lets a caller that wants to know look
+    ok = (a11 >= 2) & (det.abs() > 1e-12 * (a00 * a11).abs().clamp_min(1e-30)) & torch.isfinite(det)
+    safe = torch.where(ok, det, torch.ones_like(det))
+    scale = torch.where(ok, (a11 * b0 - a01 * b1) / safe, torch.ones_like(det)).reshape(1)
+    shift = torch.where(ok, (a00 * b1 - a01 * b0) / safe, torch.zeros_like(det)).reshape(1)
+    get_scale_shift_LS.fit_ok = ok
     return scale, shift
 
 

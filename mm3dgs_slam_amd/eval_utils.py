@@ -62,7 +62,9 @@ def evaluate_ate_rmse(est_poses, gt_poses, method: str = "umeyama"):
         q = rotation2quad(torch.matmul(torch.tensor(R).float(), quad2rotation(torch.as_tensor(est[:, :4]).float()).float()))
         aligned[:, :4] = q.numpy()
         aligned[:, 4:] = (R @ est_traj.T + t).T
-    else:                                # (the reference's fall-through: no alignment)
+    else:                                # (the reference's fall-through, utils/eval_utils.py:231-294: no alignment -- said aloud here)
+        import warnings
+        warnings.warn(f"evaluate_ate_rmse: unknown alignment method {method!r} (umeyama / horn): the trajectories are compared without alignment")
         ate = np.linalg.norm(est_traj - gt_traj, axis=1)
     rmse = float(np.sqrt(np.dot(ate, ate) / len(ate)))
     if isinstance(est_poses, torch.Tensor):

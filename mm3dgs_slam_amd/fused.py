@@ -264,6 +264,15 @@ class FusedEngine:
         h = self._hdr_pin
         P, n_cap = token
         overflow, n_max = int(h[1]), int(h[3])
+        unchecked, self.unchecked_tracking = getattr(self, "unchecked_tracking", None), None
+        if overflow and unchecked is not None:
+            # a tracking loop that skipped its own header read (lazy check, ample headroom) ran -- at least in part -- on an overflowed
+            # forward: the kernels voided those pose steps (no optimiser step, no corruption), but the frame was tracked with fewer
+            # iterations than configured.  By now the map has moved on, so the loop cannot be re-run; counted and said aloud.
+            import warnings
+            self.unrecovered_tracking_overflows = getattr(self, "unrecovered_tracking_overflows", 0) + 1
+            warnings.warn(f"mm3dgs: the tracking loop of frame {unchecked} ran without a capacity check and the binning capacity overflowed since "
+                          "(its pose steps from the first overflowing forward on were skipped on the device); capacity raised")
         self.max_tile_len = int(h[2])
         self.max_group_records = max(getattr(self, "max_group_records", 0), int(h[8]))
         self.ratio = max(self.ratio or 0.0, n_max / max(P, 1))
@@ -330,6 +339,12 @@ class FusedTracker(Tracker):
 
     def optimize_cam(self, idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth=None, est_depth=None):
         trk = self.cfg["tracking"]
+        if self.keep_best_candidate and num_iter > 0 and "keep_best_candidate" not in FusedEngine._warned:
+            FusedEngine._warned.add("keep_best_candidate")
+            import warnings
+            warnings.warn("mm3dgs: keep_best_candidate=True (this repository's option; the reference computes the candidate and discards it, "
+                          "slam/tracker.py:161-181) is outside the native tracking loop: tracking runs the torch-graph loop around the generic HIP "
+                          "rasterizer -- correct, but about 30x slower")
         if (num_iter == 0 or self.keep_best_candidate or not FusedEngine.eligible(self.cfg, self.gaussians)):
             return super().optimize_cam(idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth, est_depth)
         eng = _engine(self.renderer)
@@ -366,6 +381,10 @@ class FusedTracker(Tracker):
                 # synchronisation per frame -- is left to the mapper's next drained point (the header's overflow word is sticky, so
                 # nothing is lost; a frame's 100 pose steps cannot grow a tile list by half).
                 if self.lazy_checks and getattr(eng, "headroom", lambda: 0.0)() >= 1.5:
+                    # (should such a loop overflow after all, its pose steps from the first overflowing forward on are void
+                    #  on the device -- the tracked pose is then the pose of the last complete iteration; the engine remembers that this
+                    #  frame went unchecked and says so at the next header read, check_capacity_end)
+                    eng.unchecked_tracking = idx
                     break
                 if eng.check_capacity():
                     break

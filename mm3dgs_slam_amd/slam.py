@@ -254,12 +254,13 @@ class SLAM:
         self.mapper.run_frame(idx, color, depth, est_scaled)
         self.gt_pose_list[idx] = gt_pose.detach().clone()
 
-    def run(self, progress=None, reraise=False):
+    def run(self, progress=None, reraise=True):
         """slam/SLAM.py:375-503: every frame; `save_iterations` checkpoints on the way; with an `outputdir` the final map (as
         iteration <last_idx>) and results.npz at the end -- also when a frame raised: the reference catches the exception, prints it
         ("SLAM failed. Saving map and results.") and goes on to its `finally` (slam/SLAM.py:494-503).  Same here; the exception is kept
-        in `self.failure`, and `reraise=True` raises it again AFTER the outputs were written (a failure while writing them never masks
-        it: it is printed and the original one is raised)."""
+        in `self.failure`, and -- the default for library callers (a failed run must not look like a success) -- raised again
+        AFTER the outputs were written (a failure while writing them never masks it: it is printed and the original one is raised).
+        `reraise=False` is the reference's literal print-and-carry-on, which `slam_top.py` opts into (and turns into the exit code)."""
         last_idx = 0
         self.failure = None
         try:

@@ -141,6 +141,8 @@ class WindowParallel:
             if ev is not None:
                 ev[1].record()
                 self._timed.append((ev, flat.numel() * flat.element_size()))
+                if len(self._timed) > 256:      # (a long run must not hoard events -- the last 256 samples are the statistic)
+                    del self._timed[:-256]
 
     def allreduce_stats(self):
         """{calls, sampled, ms_per_call, bytes_per_call} of the gradient all-reduces since timing was switched on (synchronises)."""

@@ -5,7 +5,9 @@ The YAML schema is the reference's (configs/TUM.yml, configs/UTMM.yml).  No data
 (SURVEY.md section 2), so the frames come from the in-memory synthetic RGB-D sequence (`dataset: synthetic`, the
 default of `mm3dgs_slam_amd.config.default_config`); a reference config whose `dataset` is tum / utmm / replica is
 accepted for its hot-path settings (iteration budgets, learning rates, pipeline flags, intrinsics) and run on the
-synthetic sequence as well, with `use_gt_depth` forced on and `niqe_kf` off (both need downloaded networks).
+synthetic sequence as well.  `use_gt_depth: false` (what configs/TUM.yml ships) and `tracking.dynamics_model: imu` are honoured: the
+sequence provides a stand-in for the monocular estimate (`SyntheticSequence.est`, aligned per frame like slam/SLAM.py:411-448) and
+synthetic IMU rows (`SyntheticSequence.imu`); only `niqe_kf` is forced off (it needs a downloaded network).
 
 Outputs in `outputdir`, in the reference's formats (slam/SLAM.py:286-373,488-500): `point_cloud/iteration_<n>/point_cloud.ply` for
 every frame index in `save_iterations` and for the final map (attribute layout of slam/gaussian_model.py:205-257), `results.npz`
@@ -50,9 +52,7 @@ def main():
                 cfg[k].update(v)
             else:
                 cfg[k] = v
-    cfg["use_gt_depth"] = True
     cfg["mapping"]["niqe_kf"] = False
-    cfg["tracking"]["dynamics_model"] = "const_velocity" if cfg["tracking"].get("dynamics_model") == "imu" else cfg["tracking"].get("dynamics_model")
     dbg = dict(cfg.get("debug") or {})
     cfg["debug"] = {"get_runtime_stats": bool(dbg.get("get_runtime_stats", False)), "create_video": False, "save_keyframes": False}
     cfg.setdefault("outputdir", "output/synthetic")
@@ -69,7 +69,7 @@ def main():
         err = slam.pose_errors()[-1]
         print(f"frame {i:4d}  {times[-1] * 1e3:8.1f} ms  gaussians {slam.gaussians.get_xyz.shape[0]:7d}  pose error {err * 100:.2f} cm")
 
-    slam.run(progress)          # checkpoints, the final map and results.npz are written inside (reference formats)
+    slam.run(progress, reraise=False)          # (the reference's behaviour on a failed frame: print, save, carry on -- reported by the exit code below); checkpoints, the final map and results.npz are written inside (reference formats)
     res = np.load(os.path.join(outdir, "results.npz"), allow_pickle=True)
     print(f"Average Trajectory Error RMSE: {float(res['ate_rmse'])} m; {1.0 / np.mean(times[1:]):.2f} frames/s after frame 0; outputs in {outdir}")
     if slam.failure is not None:      # (the reference prints the exception and saves what it has, slam/SLAM.py:494-503; the exit code says so too)

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mm3dgs_version() >= 100
+    import re
+    abi = int(re.search(r"#define\s+MM3DGS_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "mm3dgs.h")).read()).group(1))
+    assert lib.mm3dgs_version() == abi >= 204      # the header documents the version the library reports
     assert lib.mm3dgs_geom_bytes(1000) >= 1000 * 48
     assert lib.mm3dgs_image_bytes(480, 640) >= 480 * 640 * 8
     assert lib.mm3dgs_binning_bytes(1000) >= 1000 * 41
@@ -83,3 +85,20 @@ def test_flag_constants_of_the_binding_equal_the_headers_defines():
     assert defines == {"STATE_CLEAN": _lib.FWD_STATE_CLEAN, "SHORT_LISTS": _lib.FWD_SHORT_LISTS, "DIRECT_BINS": _lib.FWD_DIRECT_BINS,
                        "KEEP_TILE_ORDER": _lib.FWD_KEEP_TILE_ORDER, "PROJECTED": _lib.FWD_PROJECTED}, defines
     assert len(set(defines.values())) == len(defines) and all(v & (v - 1) == 0 for v in defines.values())     # distinct single bits
+
+
+def test_product_sources_carry_no_timing_probe():
+    """The MM3DGS_EXP probes (launches with a phase removed: invalid results) exist only behind -DMM3DGS_PROBES: the product build neither
+    reads the environment variable nor tests a probe word inside a kernel."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "mm3dgs_slam_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(f).read()
+        assert "cam.exp" not in text, f
+        if "MM3DGS_EXP" in text:      # only inside the #ifdef MM3DGS_PROBES block of mm3dgs_common.h (and comments that name the variable)
+            code = [l for l in text.splitlines() if "MM3DGS_EXP" in l and not l.lstrip().startswith("//") and "//" not in l.split("MM3DGS_EXP")[0]]
+            assert all("env_flag" in l for l in code) and f.endswith("mm3dgs_common.h"), (f, code)
+    if os.path.exists(_lib.LIB_PATH):
+        out = subprocess.run(["strings", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+        assert "MM3DGS_EXP" not in out

@@ -5,6 +5,7 @@ the shipped method, `method: splatam`, bundle adjustment, the UTMM-style IMU con
 renderer branches outside the shipped configs (world-frame means, Python SH with max_sh_degree 2, white background).  Pins the harness rows of
 SURVEY.md 8f: RNG consumption order (keyframe picks, window subsets), keyframe decisions and covisibility graph, seeding masks and
 order, densification statistics, the pruning schedule and its interplay with Adam, both optimisers, pose propagation."""
+import ast
 import os
 import random
 
@@ -40,7 +41,7 @@ def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     from mm3dgs_slam_amd.slam import SLAM
     F = np.load(os.path.join(HERE, "golden", "g9_frames.npz"))
     G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
-    overrides = eval(str(G["overrides"]), {"__builtins__": {}})          # a dict literal written by the generator
+    overrides = ast.literal_eval(str(G["overrides"]))          # a dict literal written by the generator
     cfg = default_config(device="cpu", height=int(F["H"]), width=int(F["W"]), **overrides)
     n = G["est_poses"].shape[0]                                            # (the renderer-branch variants run 3 of the 5 frames)
     seq = _Frames(F["color"][:n], F["depth"][:n], F["gt_poses"][:n], F["imu"][:n], F["tstamps"][:n])
@@ -116,7 +117,7 @@ def test_native_loop_orchestration_reproduces_the_reference_classes(variant, mon
     from tests.cpu_engine import CpuEngine
     F = np.load(os.path.join(HERE, "golden", "g9_frames.npz"))
     G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
-    overrides = eval(str(G["overrides"]), {"__builtins__": {}})
+    overrides = ast.literal_eval(str(G["overrides"]))
     cfg = default_config(device="cpu", height=int(F["H"]), width=int(F["W"]), **overrides)
     n = G["est_poses"].shape[0]
     seq = _Frames(F["color"][:n], F["depth"][:n], F["gt_poses"][:n], F["imu"][:n], F["tstamps"][:n])

@@ -44,7 +44,8 @@ def run_variant(variant, verbose=False, prefix="g9"):
     from tests import g9_util
     F = g9_util.load_frames(prefix)
     G = g9_util.load_variant(prefix, variant)
-    overrides = eval(str(G["overrides"]), {"__builtins__": {}})          # a dict literal written by the generator
+    import ast
+    overrides = ast.literal_eval(str(G["overrides"]))          # a dict literal written by the generator
     cfg = default_config(device=DEV, height=int(F["H"]), width=int(F["W"]), **overrides)
     n = G["est_poses"].shape[0]
     seq = _Frames(F, n)

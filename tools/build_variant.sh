@@ -1,6 +1,7 @@
 #!/bin/bash
 # Variant build of the library with extra compile flags (developer experiments; needs no GPU):
-#   tools/build_variant.sh exactdiv -DMM3DGS_SLAM_EXACT_DIV     ->  mm3dgs_slam_amd/csrc/variants/libmm3dgs_hip_exactdiv.so
+#   tools/build_variant.sh probes -DMM3DGS_PROBES     ->  mm3dgs_slam_amd/csrc/variants/libmm3dgs_hip_probes.so
+# (-DMM3DGS_PROBES compiles the MM3DGS_EXP timing probes in: tools/late_probe.sh, tools/exp_ab.sh; the product build has none)
 # run with   MM3DGS_LIB=$PWD/mm3dgs_slam_amd/csrc/variants/libmm3dgs_hip_exactdiv.so python ...
 set -e
 TAG=$1; shift

@@ -1,7 +1,10 @@
 #!/bin/bash
 # A/B of MM3DGS_EXP probe bits on a STATIC scene (tools/raster_bench.py --fused: the map does not evolve, so invalid gradients do not
 # change the workload): average kernel times per value.   bash tools/exp_ab.sh 0 16 32
+# Needs the probe build: tools/build_variant.sh probes -DMM3DGS_PROBES (the product library carries no probe).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export MM3DGS_LIB=$PWD/mm3dgs_slam_amd/csrc/variants/libmm3dgs_hip_probes.so
+[ -f "$MM3DGS_LIB" ] || { echo "build the probe library first: tools/build_variant.sh probes -DMM3DGS_PROBES"; exit 1; }
 for E in "$@"; do
   rm -rf /tmp/p_exp
   MM3DGS_EXP=$E rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_exp -o e -- python tools/raster_bench.py --fused --iters 60 > /dev/null 2>&1

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Developer probe: kernel times of forward launches on the map after N frames of the bench run, with MM3DGS_EXP timing bits (results invalid
 # by construction when a bit is set).   PROBE_EXPS="0 64" bash tools/late_probe.sh [frames]
+# Needs the probe build: tools/build_variant.sh probes -DMM3DGS_PROBES (the product library carries no probe).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export MM3DGS_LIB=$PWD/mm3dgs_slam_amd/csrc/variants/libmm3dgs_hip_probes.so
+[ -f "$MM3DGS_LIB" ] || { echo "build the probe library first: tools/build_variant.sh probes -DMM3DGS_PROBES"; exit 1; }
 N=${1:-100}
 cat > /tmp/late_probe.py <<PY
 import os, sys, random
