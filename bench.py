@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true",
                     help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
                          "(gradient-output loops, the flat all-reduce over RCCL, separate Adam launch) -- the code path of --gpus N, measurable on one GPU")
+    ap.add_argument("--optimizer", choices=("auto", "allreduce", "reduce_scatter"), default="auto",
+                    help="multi-GPU window: all-reduce + replicated Adam, or reduce-scatter -> Adam on 1 / N of the elements -> all-gather of the parameters "
+                         "(auto: the latter from 500 k Gaussians on; window_parallel.py)")
     return ap.parse_args()
 
 
@@ -413,7 +416,7 @@ def main():
                                  mapping={"iters": args.map_iters, "seed_fraction": frac_}, **(top or {}))
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
         seq = SyntheticSequence(cfg, n_frames, n_target, seed=0, motion=motion)        # untimed: builds the RGB-D frames on the GPU
-        window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives)
+        window = (WindowParallel(rank, world, batch=args.window_batch, always_reduce=args.force_collectives, optimizer=args.optimizer)
                   if (world > 1 or args.window_batch > 1 or args.force_collectives) else None)
         if window is not None:
             window.timing = True
@@ -460,6 +463,11 @@ def main():
         # next projection needs the stepped parameters): this is time added to every optimiser step
         rank_check["allreduce_calls"], rank_check["allreduce_ms_per_step"] = st["calls"], st["ms_per_call"]
         rank_check["allreduce_bytes_per_step"] = st["bytes_per_call"]
+        w_ = slam.mapper.window
+        sharded_ = w_.shard_optimizer(int(slam.gaussians.get_xyz.shape[0]))
+        rank_check["optimizer"] = ("reduce-scatter -> Adam on 1 / N of the elements -> all-gather of the parameters" if sharded_ else
+                                   "flat all-reduce -> identical Adam on every replica (fused with the next view's projection)")
+        rank_check["optimizer_sharded_steps"] = int(w_.sharded_steps)
         rank_check["optimiser_note"] = (f"N > 1 changes the optimiser, not only the speed: every mapping step sums the gradients of {world * args.window_batch} views "
                                         "(the reference takes ONE view per Adam step, slam/mapper.py:803-807); `value` counts those views as frame-equivalents")
 

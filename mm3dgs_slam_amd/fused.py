@@ -129,7 +129,8 @@ class FusedEngine:
         if need_grads and self.grads is None:
             # one flat buffer [xyz 3P | f_dc 3P | opacity P | scaling 3P | rotation 4P | accum P | denom P]: the multi-GPU
             # window all-reduces it in a single collective (window_parallel.py)
-            self.flat = torch.zeros(16 * P, device=self.dev)
+            # (+ 64: a sharded optimiser step reduce-scatters world x S >= 14 P elements of it, S = the 4-aligned shard size)
+            self.flat = torch.zeros(16 * P + 64, device=self.dev)
             self.acc = torch.zeros(14 * P, device=self.dev)      # window-batch mode: sum of the local views' gradients
             o = [0, 3 * P, 6 * P, 7 * P, 10 * P, 14 * P, 15 * P, 16 * P]
             v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
@@ -767,15 +768,29 @@ class FusedMapper(Mapper):
                                 eng.acc[:14 * P].add_(eng.flat[:14 * P])
                     if len(ids) > 1:
                         eng.flat[:14 * P].copy_(eng.acc[:14 * P])
-                    if densify:
-                        self.window.reduce_flat(eng.flat, eng.stat_delta[0])
-                        torch.maximum(g.max_radii2D, eng.stat_delta[0], out=g.max_radii2D)
-                        torch._foreach_add_([g.xyz_gradient_accum, g.denom], [eng.stat_delta[1], eng.stat_delta[2]])      # (one launch)
+                    # how the summed gradients become stepped parameters everywhere: one flat all-reduce + the identical step on every replica, or
+                    # (WindowParallel.optimizer; default from 500 k Gaussians on) reduce-scatter -> Adam on this rank's 1 / world of the elements ->
+                    # all-gather of the parameters; the statistics tail and the radii always travel by all-reduce (every replica prunes)
+                    shard = (not prune_now) and self.window.shard_optimizer(P)
+                    if shard and self._opt_mask is not None:      # bundle adjustment: frozen Gaussians keep a zero gradient (masked before the sum: the mask is the same everywhere)
+                        keep = self._opt_mask.to(eng.flat.dtype)
+                        for t in eng.grads.values():
+                            t.mul_(keep.view(-1, *([1] * (t.dim() - 1))))
+                    if shard:
+                        self._shard_buffers(eng, P)
+                        self.window.reduce_scatter_flat(eng.flat, 14 * P, eng.shard_g, tail=2 * P if densify else 0, rmax=eng.stat_delta[0] if densify else None)
+                    elif densify:
+                        self.window.reduce_flat(eng.flat[:16 * P], eng.stat_delta[0])
                     else:
                         self.window.reduce_flat(eng.flat[:14 * P])
+                    if densify:
+                        torch.maximum(g.max_radii2D, eng.stat_delta[0], out=g.max_radii2D)
+                        torch._foreach_add_([g.xyz_gradient_accum, g.denom], [eng.stat_delta[1], eng.stat_delta[2]])      # (one launch)
                     if self._ba_ids:
                         self._ba_window_step(eng, m, all_ids, ids)
-                    if not prune_now:
+                    if shard:
+                        self._sharded_step(eng, g, P)
+                    elif not prune_now:
                         fuse = (self.fuse_adam_project and iteration + 1 < num_iter and hasattr(eng, "adam_project") and eng.can_adam_project(g))
                         if fuse:
                             # the step and the NEXT view's projection + binning in one launch: the next step's keyframe picks are drawn now
@@ -796,6 +811,8 @@ class FusedMapper(Mapper):
                     eng.map_loop([view_of(ids[0])], g, lcfg, stats, None, grads=eng.grads, keep_tile_order=iteration > 0,
                                  want_loss=iteration == num_iter - 1)
                 if prune_now:
+                    if multi:
+                        self._sync_moments(eng)      # (sharded optimiser steps: the compaction moves rows across shard boundaries)
                     # on the device: predicate kernel, compaction plan, a 4-byte read-back of the new size, and -- only if
                     # something is pruned -- one scatter launch over parameters, moments and statistics (gaussian_model.py).
                     # The read-back blocks until the GPU has drained: the views of the run that follows (same keyframe picks, in the
@@ -819,6 +836,8 @@ class FusedMapper(Mapper):
                     if self._opt_mask is not None and self._opt_mask.shape[0] != g._xyz.shape[0]:
                         self._opt_mask = self._opt_mask[~pruned()].contiguous()
                 iteration += 1
+            if multi:
+                self._sync_moments(eng)      # whoever touches the map next (seeding, snapshot, checkpoint) finds whole replicas
 
     def _ba_window_step(self, eng, m, all_ids, my_ids):
         """Bundle adjustment with a sharded window: this rank's views wrote their pose gradients out (Mm3dgsMapView.dpose_out_or_null)
@@ -866,6 +885,92 @@ class FusedMapper(Mapper):
         if getattr(self, "_opt_mask", None) is not None:
             ma.opt_mask = self._opt_mask.data_ptr()
         return ma
+
+    _FLAT_GROUPS = (("xyz", 0, 3), ("f_dc", 3, 6), ("opacity", 6, 7), ("scaling", 7, 10), ("rotation", 10, 14))      # the engine's flat layout, in units of P
+
+    def _flat_groups(self, P):
+        """[(optimiser group, its parameter, its Adam state, a, b)]: the five stepped groups and their element ranges [a, b) in the
+        engine's flat gradient layout."""
+        opt = self.gaussians.optimizer
+        out = []
+        for name, a, b in self._FLAT_GROUPS:
+            group = next(gr for gr in opt.param_groups if gr["name"] == name)
+            p = group["params"][0]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            out.append((group, p, st, a * P, b * P))
+        return out
+
+    def _sharded_step(self, eng, g, P):
+        """One optimiser step of the sharded window with the optimiser itself sharded over the ranks by ELEMENT (the
+        reference's step is slam/mapper.py:931-948 on one view's gradients): the caller's reduce-scatter of the flat gradient [14 P] left
+        this rank's S = ceil(14 P / world) summed elements in eng.shard_g; mm3dgs_adam on exactly those elements of the parameters and of both moments (the slice cuts
+        through the five groups: one table entry per group it touches); all-gather of the stepped PARAMETERS.  The moments of elements
+        another rank owns go stale here and are gathered when somebody needs them (_sync_moments: before map surgery and at the end of
+        the loop).  Same arithmetic per element as the all-reduce path's mm3dgs_adam: bit-identical parameters (tested over gloo)."""
+        w = self.window
+        n = 14 * P
+        S, lo, hi = w.shard_bounds(n)
+        groups = self._flat_groups(P)
+        table = (_lib.Mm3dgsAdamGroup * 8)()
+        k, cuts = 0, []
+        step_val = None
+        for group, p, st, a, b in groups:
+            st["step"] += 1                                     # (every replica counts every step of every group, as the replicated path does)
+            step_val = int(st["step"].item()) if step_val is None else step_val
+            i0, i1 = max(lo, a), min(hi, b)
+            if i0 >= i1:
+                continue
+            e = table[k]; k += 1
+            e.param = p.data_ptr() + 4 * (i0 - a)
+            e.grad = eng.shard_g.data_ptr() + 4 * (i0 - lo)
+            e.exp_avg, e.exp_avg_sq = st["exp_avg"].data_ptr() + 4 * (i0 - a), st["exp_avg_sq"].data_ptr() + 4 * (i0 - a)
+            e.n, e.lr = i1 - i0, float(group["lr"])
+            cuts.append((p, a, i0, i1))
+        opt = g.optimizer
+        b1, b2 = opt.param_groups[0]["betas"]
+        if k:
+            _lib.check(eng.lib.mm3dgs_adam(table, k, step_val, float(b1), float(b2), float(opt.param_groups[0]["eps"]), _stream()))
+        for p, a, i0, i1 in cuts:
+            eng.shard_p[i0 - lo:i1 - lo].copy_(p.detach().view(-1)[i0 - a:i1 - a])
+        w.all_gather_flat(eng.pflat, eng.shard_p, n)
+        for group, p, st, a, b in groups:
+            p.detach().view(-1).copy_(eng.pflat[a:b])
+        self._moments_stale = True
+        w.sharded_steps += 1
+
+    def _shard_buffers(self, eng, P):
+        w = self.window
+        S = w.shard_bounds(14 * P)[0]
+        if getattr(eng, "_shard_S", None) != (S, w.world):
+            eng._shard_S = (S, w.world)
+            eng.shard_g = torch.zeros(S, device=eng.dev)
+            eng.shard_p = torch.zeros(S, device=eng.dev)
+            eng.pflat = torch.zeros(w.world * S, device=eng.dev)
+
+    def _sync_moments(self, eng):
+        """After sharded steps every rank holds fresh Adam moments for ITS elements only: gather both moment arrays so that the replicas
+        are whole again (before a pruning step compacts rows across shard boundaries, before a snapshot / checkpoint, at the end of the
+        loop).  Two all-gathers of 14 P floats, a few times per frame."""
+        if not getattr(self, "_moments_stale", False):
+            return
+        self._moments_stale = False
+        g, w = self.gaussians, self.window
+        P = int(g._xyz.shape[0])
+        n = 14 * P
+        S, lo, hi = w.shard_bounds(n)
+        groups = self._flat_groups(P)
+        for key in ("exp_avg", "exp_avg_sq"):
+            for group, p, st, a, b in groups:
+                i0, i1 = max(lo, a), min(hi, b)
+                if i0 < i1:
+                    eng.shard_p[i0 - lo:i1 - lo].copy_(st[key].view(-1)[i0 - a:i1 - a])
+            w.all_gather_flat(eng.pflat, eng.shard_p, n)
+            for group, p, st, a, b in groups:
+                st[key].view(-1).copy_(eng.pflat[a:b])
 
     def _adam_step(self, eng):
         g = self.gaussians

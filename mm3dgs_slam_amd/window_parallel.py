@@ -23,8 +23,21 @@ class WindowParallel:
     ``WindowParallel(0, 1, batch=G)`` is the single-GPU "window-batch = G" mode: the parity baseline of a G-rank run (the same
     G views per step, gradients summed locally instead of by the all-reduce)."""
 
-    def __init__(self, rank: int, world: int, group=None, batch: int = 1, always_reduce: bool = False):
+    #: maps of at least this many Gaussians take the sharded optimiser step under optimizer="auto" (SURVEY.md 8e: 1 M Gaussians = 56 MB of
+    #: gradients per step; at 157 k the fused Adam + projection launch of the all-reduce path is the cheaper step, DESIGN.md section 6)
+    SHARD_MIN_GAUSSIANS = 500_000
+
+    def __init__(self, rank: int, world: int, group=None, batch: int = 1, always_reduce: bool = False, optimizer: str = "auto"):
         self.rank, self.world, self.group, self.batch = rank, world, group, int(batch)
+        # optimizer: how a step's gradients become stepped parameters on every replica (native loops, fused.py):
+        #   "allreduce"      -- one flat all-reduce, then the identical Adam step over the whole map on every rank;
+        #   "reduce_scatter" -- reduce-scatter of the flat gradient, Adam on this rank's 1 / world of the ELEMENTS (its slice of the
+        #                       parameters and of both moments), all-gather of the stepped parameters: the same bytes over the links as
+        #                       the ring all-reduce moves, 1 / world of the optimiser's HBM traffic per rank;
+        #   "auto"           -- "reduce_scatter" from SHARD_MIN_GAUSSIANS Gaussians on when there is more than one rank.
+        assert optimizer in ("auto", "allreduce", "reduce_scatter"), optimizer
+        self.optimizer = optimizer
+        self.sharded_steps = 0
         # always_reduce: issue the collectives even with a single rank (an all-reduce over one rank is the identity): runs the
         # whole multi-GPU orchestration -- gradient-output loops, flat buffer, RCCL launch, separate Adam -- on a 1-GPU box
         self.always_reduce = bool(always_reduce)
@@ -124,6 +137,71 @@ class WindowParallel:
         """Sum of a small tensor over the ranks (bundle adjustment: the window's pose gradients), in place."""
         if self._collective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- sharded optimiser step (reduce-scatter -> Adam on 1 / world of the elements -> all-gather of the parameters) ----------------
+    def shard_optimizer(self, P: int) -> bool:
+        if self.optimizer == "reduce_scatter":
+            return True
+        return self.optimizer == "auto" and self.world > 1 and P >= self.SHARD_MIN_GAUSSIANS
+
+    def shard_bounds(self, n: int):
+        """(S, lo, hi): every rank owns S consecutive elements of a flat array of n (S a multiple of 4: 16-byte aligned slices); this
+        rank's are [lo, hi) -- hi clipped to n, the padding behind n belongs to the last rank(s) and is never used."""
+        S = -(-n // self.world)
+        S = (S + 3) // 4 * 4
+        lo = min(self.rank * S, n)
+        return S, lo, min(lo + S, n)
+
+    def _has(self, name):
+        if not hasattr(self, "_caps"):
+            self._caps = {}
+        if name not in self._caps:
+            backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
+            # gloo (the CPU tests) has no reduce-scatter: the sum of all elements by all-reduce, then this rank's slice -- the same values
+            self._caps[name] = backend != "gloo" or name != "reduce_scatter"
+        return self._caps[name]
+
+    def reduce_scatter_flat(self, flat, n, out, tail=0, rmax=None):
+        """out[:S] <- this rank's slice of the element-wise sum over the ranks of flat[:n]; flat[n:n + tail] (the densification statistics)
+        <- its sum over the ranks, whole, on every rank; rmax (the radii) <- its maximum.  flat must hold world * S elements (what lies
+        behind n is read by the reduce-scatter and ignored); afterwards flat[:n] is unspecified."""
+        S, lo, hi = self.shard_bounds(n)
+        assert flat.numel() >= max(self.world * S, n + tail) and out.numel() >= S
+        if not self._collective:
+            out[:hi - lo].copy_(flat[lo:hi])
+            return
+        ev = None
+        if self.timing and flat.is_cuda:
+            self._calls += 1
+            if self._calls % self._sample == 1:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+        if self._has("reduce_scatter"):
+            dist.reduce_scatter_tensor(out[:S], flat[:self.world * S], op=dist.ReduceOp.SUM, group=self.group)
+            if tail:
+                dist.all_reduce(flat[n:n + tail], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            # (ONE all-reduce over gradients + statistics, like the all-reduce path issues it: gloo's ring cuts a buffer into chunks by its
+            #  length and sums each chunk in its own rank order, so only the same span gives the same bits -- which is what lets the CPU
+            #  tests hold the sharded step to the replicated one bit for bit)
+            dist.all_reduce(flat[:n + tail], op=dist.ReduceOp.SUM, group=self.group)
+            out[:hi - lo].copy_(flat[lo:hi])
+        if rmax is not None:
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=self.group)
+        if ev is not None:
+            ev[1].record()
+            self._timed.append((ev, n * flat.element_size()))
+            if len(self._timed) > 256:
+                del self._timed[:-256]
+
+    def all_gather_flat(self, full, shard, n):
+        """full[:n] <- the ranks' shards in rank order (shard = this rank's S elements; full holds world * S)."""
+        S, lo, hi = self.shard_bounds(n)
+        assert full.numel() >= self.world * S and shard.numel() >= S
+        if not self._collective:
+            full[lo:hi].copy_(shard[:hi - lo])
+            return
+        dist.all_gather_into_tensor(full[:self.world * S], shard[:S], group=self.group)
 
     def reduce_flat(self, flat, rmax=None):
         """Native-loop variant: `flat` is (a prefix of) the engine's single gradient+statistics buffer (sum), `rmax` the radii

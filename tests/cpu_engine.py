@@ -105,7 +105,7 @@ class CpuEngine:
         if P != self.P:
             self.P, self.grads = P, None
         if need_grads and self.grads is None:
-            self.flat = torch.zeros(16 * P)
+            self.flat = torch.zeros(16 * P + 64)
             o = [0, 3 * P, 6 * P, 7 * P, 10 * P, 14 * P, 15 * P, 16 * P]
             v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
             self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))

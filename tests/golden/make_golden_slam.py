@@ -46,6 +46,17 @@ if LARGE:
     H, W, N_FRAMES, N_SEED = 120, 160, 8, 16000
     SHORT = {"no_transform": 4, "sh2_python": 4, "white_bg": 4}
     PREFIX = "g9L"
+# --shipped (round 5): 160x120 again, but with the schedule the reference SHIPS and the benchmark times (configs/TUM.yml:32,44-75: 100 tracking /
+# 150 mapping iterations, pruning_interval 50 -- with its no-op Adam steps at mapping iterations 0 and 50 --, min_opacity 0.005, kf_every 5,
+# min_covisibility 0.95, size_threshold 100) over 11 frames = three keyframes (0 / 5 / 10): ~2750 optimiser iterations per variant through
+# slam/tracker.py:94-177 and slam/mapper.py:718-950.  Written as g9S_*.npz in the --large storage format.
+SHIPPED = "--shipped" in sys.argv
+if SHIPPED:
+    sys.argv.remove("--shipped")
+    LARGE = True
+    H, W, N_FRAMES, N_SEED = 120, 160, 11, 16000
+    SHORT = {}
+    PREFIX = "g9S"
 QS = [0.02, 0.1, 0.25, 0.5, 0.75, 0.9, 0.98]
 _MAP = {"iters": 14, "kf_every": 2, "min_covisibility": 0.999, "densify_until_iter": 9, "pruning_interval": 4, "min_opacity": 0.4625,
         "size_threshold": 20}
@@ -83,6 +94,18 @@ VARIANTS = {
                           "rotation_lr": 0.002},
                 mapping=dict(_MAP, pearson_weight=0.001)),
 }
+
+
+if SHIPPED:
+    VARIANTS = {
+        # configs/TUM.yml as shipped (default_config's values ARE that file's hot-path settings): nothing overridden
+        "vigs": dict(),
+        # configs/UTMM.yml's hot-path settings on the shipped schedule: IMU pose prediction, Pearson term in tracking, isotropic Gaussians,
+        # 0.002 pose learning rates, size_threshold 200 (configs/UTMM.yml:31-77)
+        "imu": dict(pipeline={"force_isotropic": True},
+                    tracking={"dynamics_model": "imu", "use_depth_estimate_loss": True, "pearson_weight": 0.001, "position_lr": 0.002, "rotation_lr": 0.002},
+                    mapping={"pearson_weight": 0.001, "cam_t_lr": 0.002, "cam_q_lr": 0.002, "size_threshold": 200}),
+    }
 
 
 def summary(g):

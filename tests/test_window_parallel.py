@@ -54,20 +54,32 @@ def _run(slam, ba=False):
         slam.mapper.optimize_map(2, 6, [0] * (len(slam.mapper.keyframes) + 1) + [-1] if len(slam.mapper.keyframes) < 2 else [0, 1, -1], None, slam.estimate_pose_list[2], color, depth, None)
 
 
-def _worker(rank, world, port, out, native=False, ba=False):
+def _moments(slam):
+    opt = slam.gaussians.optimizer
+    out = {}
+    for gr in opt.param_groups:
+        st = opt.state.get(gr["params"][0], {})
+        if "exp_avg" in st:
+            out["m_" + gr["name"]], out["v_" + gr["name"]] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+    return out
+
+
+def _worker(rank, world, port, out, native=False, ba=False, optimizer="allreduce", tag="r"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2 if world <= 2 else 1)
     from mm3dgs_slam_amd.window_parallel import WindowParallel
     if native:
         _install_cpu_engine()
-    slam = _build(WindowParallel(rank, world), native, ba)
+    slam = _build(WindowParallel(rank, world, optimizer=optimizer), native, ba)
     _run(slam, ba)
     st = _state(slam)
     if native:
         from mm3dgs_slam_amd import fused
         st["view_log"] = list(fused._engine(slam.renderer).view_log)
-    torch.save(st, os.path.join(out, f"r{rank}.pt"))
+        st.update(_moments(slam))
+        st["sharded_steps"] = torch.tensor(slam.mapper.window.sharded_steps)
+    torch.save(st, os.path.join(out, f"{tag}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,10 +165,23 @@ def test_native_window_orchestration_eight_ranks_equal_window_batch_eight(tmp_pa
     states = [torch.load(tmp_path / f"r{r}.pt") for r in range(8)]
     logs = [s.pop("view_log") for s in states]
     a = states[0]
-    assert a["xyz"].shape[0] > 0
+    assert a["xyz"].shape[0] > 0 and int(a["sharded_steps"]) == 0
     for b in states[1:]:
         for k in a:
             assert torch.equal(a[k], b[k]), k
+    # Round 5 -- the same eight ranks with the OPTIMISER sharded (WindowParallel(optimizer="reduce_scatter"): reduce-scatter of the flat
+    # gradient, mm3dgs_adam on each rank's 1 / 8 of the elements -- slices that cut through the five parameter groups --, all-gather of
+    # the parameters, the moments gathered before every pruning step and at the end of each loop): bit for bit the all-reduce path's
+    # parameters, statistics, poses AND Adam moments, on every rank.  (gloo has no reduce-scatter: WindowParallel sums by all-reduce and
+    # keeps its slice there -- the same sums; what this holds is the sharded step, the parameter exchange and the moment bookkeeping.)
+    mp.spawn(_worker, args=(8, _free_port(), str(tmp_path), True, False, "reduce_scatter", "s"), nprocs=8, join=True)
+    for r in range(8):
+        s = torch.load(tmp_path / f"s{r}.pt")
+        assert s.pop("view_log") == logs[r]
+        assert int(s.pop("sharded_steps")) > 0
+        for k in a:
+            if k != "sharded_steps":
+                assert torch.equal(a[k], s[k]), (r, k, (a[k] - s[k]).abs().max())
     from mm3dgs_slam_amd.window_parallel import WindowParallel
     torch.set_num_threads(2)
     registry = _install_cpu_engine(monkeypatch.setattr)
@@ -299,3 +324,36 @@ def test_window_step_with_the_fused_adam_and_projection_call_equals_the_two_call
     assert logs[0] == logs[1]                      # the same views, in the same order, in every step
     for k in states[0]:
         assert torch.equal(states[0][k], states[1][k]), (k, (states[0][k] - states[1][k]).abs().max())
+
+
+@pytest.mark.parametrize("ba", [False, True])
+def test_sharded_optimiser_step_two_ranks_is_bit_identical_to_the_all_reduce_step(ba, tmp_path):
+    """Two gloo ranks, native orchestration over the CPU stand-in engine: WindowParallel(optimizer="reduce_scatter") against
+    optimizer="allreduce" -- parameters, statistics, poses and both Adam moments bit for bit, with and without bundle adjustment (whose
+    frozen-Gaussian mask is applied to the local gradients before the sum on the sharded path, to the summed gradients on the other)."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True, ba, "allreduce", "a"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), True, ba, "reduce_scatter", "s"), nprocs=2, join=True)
+    for r in range(2):
+        a, s = torch.load(tmp_path / f"a{r}.pt"), torch.load(tmp_path / f"s{r}.pt")
+        assert a.pop("view_log") == s.pop("view_log")
+        assert int(a.pop("sharded_steps")) == 0 and int(s.pop("sharded_steps")) > 0
+        assert any(k.startswith("m_") for k in a)
+        for k in a:
+            assert torch.equal(a[k], s[k]), (r, k, (a[k] - s[k]).abs().max())
+
+
+def test_shard_bounds_partition_the_flat_gradient():
+    from mm3dgs_slam_amd.window_parallel import WindowParallel
+    for world in (1, 2, 3, 8):
+        for n in (14 * 1, 14 * 37, 14 * 1530, 14 * 157649):
+            spans = [WindowParallel(r, world).shard_bounds(n) for r in range(world)]
+            S = spans[0][0]
+            assert all(s[0] == S for s in spans) and S % 4 == 0 and world * S >= n and world * S <= n + 4 * world + 3
+            covered = 0
+            for r, (_, lo, hi) in enumerate(spans):
+                assert lo == min(r * S, n) and lo <= hi <= n
+                covered += hi - lo
+            assert covered == n
+    w = WindowParallel(0, 8)
+    assert not w.shard_optimizer(157649) and w.shard_optimizer(1_000_000) and not WindowParallel(0, 1).shard_optimizer(1_000_000)
+    assert WindowParallel(0, 8, optimizer="allreduce").shard_optimizer(1_000_000) is False
