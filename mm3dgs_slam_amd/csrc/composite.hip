@@ -461,7 +461,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   //  loads -- barrier, table loads, stores: the tail of every workgroup -- and 2.9 for the loads; 2, 4 or 8 records in flight make no
   //  difference, and requesting a lane's table entries up here costs more than it saves: DESIGN.md section 4)
   static_assert(MODE == 0 || C == 6, "SLAM modes composite the 6-channel bundle");
-  constexpr int RECF = MODE == 0 ? NV : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats: packed at the record's real size (composite_common.h; generic: 6 + C)
+  constexpr int RECF = MODE == 0 ? GENERIC_RECF(C) : (MODE == 1 ? REC_MAP_F : REC_TRACK_F);   // record stride in floats: packed at the record's real size (composite_common.h; generic: 6 + C)
   // [buffer][wave][field A|B|C][row * 16 + entry] + [buffer][wave][row * 16 + entry] record indices: lane-contiguous
   // (conflict-free) writes, and ONE address register per splat for the row-uniform reads (fields are a constant 1 KB apart ->
   // immediate offsets).  (The caller's LDS block is shared with the scratch of the folded mapping-loss gradient pass, which
@@ -561,7 +561,13 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
 
   // The SLAM losses leave the silhouette and depth^2 channels without gradient (dL[4] = dL[5] = 0): a wave that sees only
   // zeros there runs a loop instance with those terms removed (exact: they would multiply by zero).
-  const bool z45_wave = MODE != 0 && __ballot(dL[C > 4 ? 4 : 0] != 0.f || dL[C > 5 ? 5 : 0] != 0.f) == 0ull;
+  // Likewise the background term of dL/dalpha, -T_final (bg . dL) / (1 - alpha): over a black background (the shipped configurations) it is
+  // zero for every pixel, and the same instance drops it (exact: x - 0 * r = x for the finite r = 1 / (1 - alpha), alpha <= 0.99).
+  const bool z45_wave = MODE != 0 && __ballot(dL[C > 4 ? 4 : 0] != 0.f || dL[C > 5 ? 5 : 0] != 0.f || Tf_bg != 0.f) == 0ull;
+  // A splat counts for this lane's pixel while  pos = todo - 1 - step < last_contributor,  step = base + j the wave-uniform position in the
+  // traversal:  step >= first_step  with the per-lane constant below -- one compare against a scalar instead of a subtraction and a compare per
+  // step.  (todo >= last_contributor unless the list was clamped to `count`; then first_step = 0: every listed splat counts.)
+  const uint32_t first_step = todo - min(todo, last_contributor);
   auto run_chunks = [&](auto z45_tag) {
   constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
@@ -577,14 +583,14 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti_in, const int j) {
       const uint32_t ti = MODE == 0 ? ti_in : __float_as_uint(Cc.z);
-      const bool row_on = base + (uint32_t)j < todo;          // this row still has an entry at this step
-      const uint32_t pos = todo - 1u - (base + (uint32_t)j);  // 0-based index in the row's list (garbage when !row_on)
+      const uint32_t step = base + (uint32_t)j;               // wave-uniform
+      const bool row_on = step < todo;                        // this row still has an entry at this step
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
       const float G = SPLAT_EXP(power);
       const float araw = B.y * G;
       const float alpha = fminf(0.99f, araw);
-      const bool valid = row_on && (pos < last_contributor) && !(power > 0.f) && !(alpha < ALPHA_MIN);
+      const bool valid = row_on && (step >= first_step) && !(power > 0.f) && !(alpha < ALPHA_MIN);
       float tot = 0.f;
       n_visit++;
       if (MODE != 0 || __ballot(valid) != 0ull) {   // SLAM modes: four rows with different splats -- a whole-wave miss is rare, the vote is not worth its cost
@@ -620,7 +626,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         for (int ch = 0; ch < (Z45 ? 4 : C); ch++) qd = fmaf(col[ch], dL[ch], qd);
         const float diff = qd - behind_dot;
         behind_dot = fmaf(a_eff, diff, behind_dot);
-        const float dLa = diff * Tr - Tf_bg * r;
+        const float dLa = Z45 ? diff * Tr : diff * Tr - Tf_bg * r;
         // screen-space geometry: only the moments of u = dL/dG * G are reduced; the consumer (preprocess_bwd) turns them
         // into d/dxy and d/dconic with the splat's own conic:  dxy = -(Q m1),  dconic = -(1/2 m_xx, m_xy, 1/2 m_yy)
         const float u = B.y * dLa * G_eff;

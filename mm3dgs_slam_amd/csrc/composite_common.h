@@ -9,6 +9,12 @@
 // alignment only), and a reader that fetches whole float4s past a record's end gets the head of the next record in lanes it ignores.
 #define REC_MAP_F 10
 #define REC_TRACK_F 7
+// generic path: 6 + C floats, packed (round-5 experiment -DMM3DGS_GENERIC_REC12: a 48-byte stride, 16-byte aligned records)
+#ifdef MM3DGS_GENERIC_REC12
+#define GENERIC_RECF(C) 12
+#else
+#define GENERIC_RECF(C) (6 + (C))
+#endif
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float4 ld4u(const float* p) { const f4u v = *(const f4u*)p; return make_float4(v.x, v.y, v.z, v.w); }

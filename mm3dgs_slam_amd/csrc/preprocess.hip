@@ -11,6 +11,7 @@
 
 #include "mm3dgs_math.h"
 #include "gather_records.h"
+#include "composite_common.h"
 
 // SH rows as float4s: a lane's [M,3] coefficient row is 12 M contiguous bytes (192 B at degree 3), so with scalar accesses
 // every one of its 3 M load (store) instructions touches 64 different cache lines for 4 useful bytes each.  With M in {4, 16}
@@ -224,7 +225,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       }
     }
     // (records packed at their real size: 6 moments / opacity terms + C colour gradients)
-    gather_records<3, 0, PP_BLOCK>(area, goff, r0, r1, sA, sB, rec_first, dsub, bn, N_cap, acc0, acc1, acc2, 0ull, 6 + C);
+    gather_records<3, 0, PP_BLOCK>(area, goff, r0, r1, sA, sB, rec_first, dsub, bn, N_cap, acc0, acc1, acc2, 0ull, GENERIC_RECF(C));
     // a record shorter than 12 floats: what the last float4 picked up past its end belongs to the next record
     if (C < 6) { if (C < 3) { acc2.x = 0.f; } if (C < 4) acc2.y = 0.f; if (C < 5) acc2.z = 0.f; acc2.w = 0.f; if (C < 2) acc1.w = 0.f; if (C < 1) acc1.z = 0.f; }
   }

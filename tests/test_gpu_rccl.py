@@ -28,27 +28,40 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 from mm3dgs_slam_amd.config import default_config
 from mm3dgs_slam_amd.slam import SLAM, SyntheticSequence
 from mm3dgs_slam_amd.window_parallel import WindowParallel
+from mm3dgs_slam_amd import fused
 res = {}
-for name, window in (("rccl", WindowParallel(0, 1, always_reduce=True)), ("plain", None)):
+for name, window in (("rccl", WindowParallel(0, 1, always_reduce=True, optimizer="allreduce")), ("plain", None),
+                     ("unfused", WindowParallel(0, 1, always_reduce=True, optimizer="allreduce")),
+                     ("sharded", WindowParallel(0, 1, always_reduce=True, optimizer="reduce_scatter"))):
+    fused.FusedMapper.fuse_adam_project = name != "unfused"      # "unfused": mm3dgs_adam + a self-projecting next call -- the Adam kernel the sharded step uses
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     cfg = default_config(device="cuda:0", height=120, width=160, tracking={"iters": 5}, mapping={"iters": 8, "kf_every": 1})
     seq = SyntheticSequence(cfg, 3, 6000, seed=6)
     slam = SLAM(cfg, seq, window=window)
     assert type(slam.mapper).__name__ == "FusedMapper"
-    calls = {"n": 0}
+    calls = {"n": 0, "rs": 0, "ag": 0}
     if window is not None:
-        real = dist.all_reduce
+        real, real_rs, real_ag = dist.all_reduce, dist.reduce_scatter_tensor, dist.all_gather_into_tensor
         def counted(*a, **k):
             calls["n"] += 1
             return real(*a, **k)
-        dist.all_reduce = counted
+        def counted_rs(*a, **k):
+            calls["rs"] += 1
+            return real_rs(*a, **k)
+        def counted_ag(*a, **k):
+            calls["ag"] += 1
+            return real_ag(*a, **k)
+        dist.all_reduce, dist.reduce_scatter_tensor, dist.all_gather_into_tensor = counted, counted_rs, counted_ag
     for i in range(3):
         slam.step(i)
     if window is not None:
-        dist.all_reduce = real
+        dist.all_reduce, dist.reduce_scatter_tensor, dist.all_gather_into_tensor = real, real_rs, real_ag
     g = slam.gaussians
     res[name] = {"xyz": g._xyz.detach().cpu(), "op": g._opacity.detach().cpu(), "sc": g._scaling.detach().cpu(), "acc": g.xyz_gradient_accum.cpu(),
-                 "radii": g.max_radii2D.cpu(), "poses": torch.stack([p.detach().cpu() for p in slam.estimate_pose_list[:3]]), "allreduces": calls["n"]}
+                 "radii": g.max_radii2D.cpu(), "poses": torch.stack([p.detach().cpu() for p in slam.estimate_pose_list[:3]]), "allreduces": calls["n"],
+                 "reduce_scatters": calls["rs"], "all_gathers": calls["ag"], "sharded_steps": 0 if window is None else window.sharded_steps}
+    st_ = slam.gaussians.optimizer.state[slam.gaussians._xyz]
+    res[name]["m_xyz"], res[name]["v_xyz"] = st_["exp_avg"].detach().cpu(), st_["exp_avg_sq"].detach().cpu()
 t = torch.ones(1 << 20, device="cuda:0")
 dist.all_reduce(t)
 res["backend"] = dist.get_backend()
@@ -85,3 +98,11 @@ def test_native_mapping_window_over_rccl_world_one_equals_the_in_kernel_adam_run
         off = d > 1e-6 + 1e-5 * b[k].abs()
         assert float(off.float().mean()) <= 1e-3, (k, float(off.float().mean()), float(d.max()))
         assert float(d.max()) <= 0.2, (k, float(d.max()))
+    # Round 5 -- the sharded optimiser step over RCCL: dist.reduce_scatter_tensor on the engine's flat gradient buffer, mm3dgs_adam on the
+    # rank's slice (all of it with one rank), dist.all_gather_into_tensor of the parameters, the moments gathered before every pruning step:
+    # bit for bit the all-reduce path stepped by the same Adam kernel ("unfused"), parameters AND moments.
+    u, sh = res["unfused"], res["sharded"]
+    assert sh["sharded_steps"] > 0 and sh["reduce_scatters"] == sh["sharded_steps"] and sh["all_gathers"] >= sh["sharded_steps"]
+    assert u["sharded_steps"] == 0 and u["reduce_scatters"] == 0
+    for k in ("xyz", "op", "sc", "acc", "radii", "poses", "m_xyz", "v_xyz"):
+        assert torch.equal(u[k], sh[k]), (k, float((u[k] - sh[k]).abs().max()))
