@@ -72,6 +72,12 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true",
                     help="1 GPU: initialise the process group anyway (world_size 1) and run the mapping loop through the multi-GPU orchestration "
                          "(gradient-output loops, the flat all-reduce over RCCL, separate Adam launch) -- the code path of --gpus N, measurable on one GPU")
+    ap.add_argument("--grow-to", type=int, default=-1,
+                    help="c3 / c4: map size at which the timed region starts (BASELINE.json quotes ~300 k / ~1 M).  The reference's seeding gives one Gaussian per "
+                         "valid frame-0 pixel (211 k at 640x330, 795 k at 1200x680); the stated sizes are maps GROWN by keyframes, so the run sweeps a wider "
+                         "scene (trajectory_desk, amp 1.6) at the full iteration budget, untimed, until the map has this many Gaussians.  -1: the configuration's "
+                         "stated size; 0: no growth phase (round 4's lines: the bounded trajectory on the frame-0 map)")
+    ap.add_argument("--grow-max-frames", type=int, default=160)
     ap.add_argument("--optimizer", choices=("auto", "allreduce", "reduce_scatter"), default="auto",
                     help="multi-GPU window: all-reduce + replicated Adam, or reduce-scatter -> Adam on 1 / N of the elements -> all-gather of the parameters "
                          "(auto: the latter from 500 k Gaussians on; window_parallel.py)")
@@ -405,6 +411,10 @@ def main():
         args.height, args.width = 680, 1200
         frac = args.seed_fraction or 1.0      # the reference's seeding: ~0.78 M Gaussians from frame 0, growing with every keyframe
         steady = 0
+    grow_to = 0
+    if c3 or c4:
+        grow_to = (300000 if c3 else 1000000) if args.grow_to < 0 else args.grow_to
+    grow_frames_max = args.grow_max_frames if grow_to else 0
 
     def build(frac_, n_frames, n_target, motion="bounded", top=None):
         if c3:
@@ -425,7 +435,7 @@ def main():
     log("process warm-up (6-frame SLAM run with a few iterations per frame: loads every operator once)")
     prewarm(dev, args.height, args.width, args.gaussians, frac)
     log("building the synthetic RGB-D sequence")
-    slam = build(frac, args.warmup + args.steps + 1 + steady, args.gaussians)
+    slam = build(frac, args.warmup + args.steps + 1 + steady + grow_frames_max, args.gaussians, motion="desk_wide" if grow_to else "bounded")
     log("frame 0 (seeding + first mapping, untimed)")
     _lib.profile_read()
     _lib.profile_enable(args.profile)       # (sampled from here on: the launches before the timed region are reported separately)
@@ -435,6 +445,17 @@ def main():
     torch.manual_seed(0); random.seed(0); np.random.seed(0)              # identical keyframe picks on every rank
     for i in range(1, 1 + args.warmup):
         slam.step(i)
+    # c3 / c4: grow the map to the configuration's stated size with keyframes (untimed, full budget), then time the frames that follow
+    grown = 0
+    P_seeded = int(slam.gaussians.get_xyz.shape[0])
+    while grow_to and grown < grow_frames_max and int(slam.gaussians.get_xyz.shape[0]) < grow_to:
+        slam.step(1 + args.warmup + grown)
+        grown += 1
+        if grown % 20 == 0:
+            log(f"  growing: frame {grown}, {slam.gaussians.get_xyz.shape[0]} Gaussians, {len(slam.mapper.keyframes)} keyframes")
+    if grow_to:
+        log(f"map grown from {P_seeded} to {slam.gaussians.get_xyz.shape[0]} Gaussians in {grown} untimed frames ({len(slam.mapper.keyframes)} keyframes)")
+    first_timed = 1 + args.warmup + grown
 
     phases = instrument_phases(slam) if args.phases else None
     prof_before = _lib.profile_read()       # frame 0 + warm-up frames
@@ -442,7 +463,7 @@ def main():
     barrier()
     log("timed region")
     t0 = time.perf_counter()
-    for i in range(1 + args.warmup, 1 + args.warmup + args.steps):
+    for i in range(first_timed, first_timed + args.steps):
         slam.step(i)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -474,7 +495,7 @@ def main():
     P_now = int(slam.gaussians.get_xyz.shape[0])
     # measured N (tile-splat pairs) of a representative render, for the algorithmic-bytes figure
     with torch.no_grad():
-        slam.renderer.render(slam.gaussians, slam.estimate_pose_list[args.warmup + args.steps])
+        slam.renderer.render(slam.gaussians, slam.estimate_pose_list[first_timed + args.steps - 1])
     hdr = rasterizer.last_header()
     N = hdr["num_rendered"]
     H, W, C = args.height, args.width, 6 if args.render_mode == "fused" else 3
@@ -496,7 +517,10 @@ def main():
                                 (f"Replica-room0-shaped synthetic RGB-D {W}x{H} (TUM intrinsics scaled to the image), {P_now} Gaussians, " if c4 else
                                  f"TUM fr1/desk-shaped synthetic RGB-D {W}x{H} (configs/TUM.yml intrinsics), {P_now} Gaussians, ")) +
                                f"full track+map per frame: {args.track_iters} tracking + {args.map_iters} mapping iterations "
-                               f"(reference budget), frame-0 seeding thinned to {frac:.2f} of the pixels, render_mode={args.render_mode}, "
+                               f"(reference budget), frame-0 seeding thinned to {frac:.2f} of the pixels, " +
+                               (f"map grown by keyframes from {P_seeded} (the reference's one Gaussian per valid frame-0 pixel) to the configuration's stated size over {grown} "
+                                f"untimed frames of a hand-held sweep (trajectory_desk, amplitudes x 1.6) that continues through the timed frames, " if grow_to else "") +
+                               f"render_mode={args.render_mode}, "
                                f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
                                f"the same run, `full_seed` = a second run seeded like the reference (one Gaussian per valid frame-0 pixel)",
                    "gaussians": P_now, "image": [H, W], "iterations_per_frame": views_per_frame,
@@ -578,7 +602,7 @@ def main():
         log(f"steady state: {steady} more frames of the same run")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        first = 1 + args.warmup + args.steps
+        first = first_timed + args.steps
         for i in range(first, first + steady):
             slam.step(i)
         torch.cuda.synchronize()

@@ -69,16 +69,17 @@ def trajectory_moving(n, step_t=0.014, step_r=0.014):
     return out
 
 
-def trajectory_desk(n, step_t=0.014, step_r_deg=0.8):
+def trajectory_desk(n, step_t=0.014, step_r_deg=0.8, amp=1.0):
     """A hand-held sweep at TUM fr1/desk's pace (the bench's `moving` line since round 4): the camera pans back and forth over the scene --
     yaw +-10 degrees at up to `step_r_deg` per frame (0.8), pitch +-4 degrees at up to 0.4 per frame -- while it translates sideways
     +-0.25 m at up to `step_t` m per frame (1.4 cm) and bobs a few centimetres.  At that pace the view shares less than
     `mapping.min_covisibility` (0.95) of the last keyframe within two or three frames, so `mapping.kf_every: 5` is what spaces the
     keyframes (slam/mapper.py:141-173, configs/TUM.yml:45-50) except at the turning points of the sweep.  The sequence needs a scene
     wider than the first view: SyntheticSequence(motion="desk") seeds its ground-truth map from a 1.8x wider / taller virtual frame.
-    Returns n 4x4 world->camera matrices."""
+    `amp` scales the three amplitudes at the same pace per frame (motion="desk_wide": 1.6 -- pan +-16 degrees, the whole 1.8x scene comes
+    into view over a sweep: the bench grows a map to a stated size with it).  Returns n 4x4 world->camera matrices."""
     out = []
-    ay, ap, ax = math.radians(10.0), math.radians(4.0), 0.25
+    ay, ap, ax = math.radians(10.0) * amp, math.radians(4.0) * amp, 0.25 * amp
     wy, wp, wx = math.radians(step_r_deg) / ay, math.radians(0.5 * step_r_deg) / ap, step_t / ax
     for i in range(n):
         yaw = ay * math.sin(wy * i)
@@ -107,7 +108,7 @@ class SyntheticSequence:
         dev = cfg["device"]
         H, W = int(cfg["desired_height"]), int(cfg["desired_width"])
         c = cfg["cam"]
-        if motion == "desk":
+        if motion in ("desk", "desk_wide"):
             Hg, Wg = int(round(1.8 * H)), int(round(1.8 * W))
             color, depth = synthetic.rgbd_frame(Hg, Wg, seed=seed, n_boxes=14)
             G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"] + 0.5 * (Wg - W), c["cy"] + 0.5 * (Hg - H),
@@ -116,7 +117,7 @@ class SyntheticSequence:
             color, depth = synthetic.rgbd_frame(H, W, seed=seed)
             G = synthetic.seed_gaussians(color, depth, c["fx"], c["fy"], c["cx"], c["cy"], n_gaussians, seed=seed)
         self.seed_params = {k: v.to(dev) for k, v in G.items()}
-        traj = {"moving": trajectory_moving, "desk": trajectory_desk}.get(motion, trajectory)
+        traj = {"moving": trajectory_moving, "desk": trajectory_desk, "desk_wide": lambda n: trajectory_desk(n, amp=1.6)}.get(motion, trajectory)
         self.poses = [get_tensor_from_camera(M).to(dev) for M in traj(n_frames)]
         self.frames = []
         renderer = renderer or Renderer(cfg)

@@ -100,8 +100,28 @@ def run_variant(variant, verbose=False, prefix="g9"):
 # (tools/g9_cpu_check.py --large, profiles/r04_g9L_cpu_float32_floor.txt): map size off by 32 - 74 of 8.5 k (0.4 - 0.9 %) from frame 0 on,
 # camera matrices 2e-4 .. 1.5e-3 (bundle adjustment 6e-3), map moments up to 8.5e-3.  The HIP loops stay INSIDE that floor: map size within
 # 28 (0.3 %), cameras 3e-6 .. 7e-5 while the rows agree and <= 2.7e-3 afterwards (bundle adjustment 6e-3 at frame 7), moments <= 3e-3;
-# keyframes, covisibility graph and the three RNG streams identical in all nine variants.  Bars for g9L: rows aligned -> camera 1e-4,
-# moments 5e-4; afterwards camera 5e-3 (bundle adjustment 1e-2), moments 1e-2; map size within 0.5 %.
+# keyframes, covisibility graph and the three RNG streams identical in all nine variants.
+# Round 5 ("what the test would let through is 2 - 50x what was measured"): the g9L bars are now PER FRAME, 3x what
+# profiles/r04_g9L_hip_loops.txt measured for that variant and frame (camera-matrix difference | largest moment difference; floors 1e-6 /
+# 1e-5) -- the native loops are deterministic (no atomics decide a value), so a run either reproduces those numbers or something changed.
+G9L_MEASURED = {
+    "vigs": [(9.31e-10, 3.75e-06), (1.08e-05, 5.13e-06), (2.53e-05, 1.08e-04), (4.89e-05, 2.11e-04), (1.64e-04, 1.16e-04), (2.87e-04, 1.16e-04), (4.57e-04, 7.96e-04), (2.07e-04, 1.42e-03)],
+    "vigs_rotfrozen": [(9.31e-10, 3.81e-06), (1.03e-05, 8.34e-07), (4.02e-05, 5.43e-04), (7.92e-05, 4.73e-04), (2.94e-04, 5.04e-04), (3.84e-04, 6.82e-04), (4.92e-04, 2.70e-03), (3.58e-04, 3.13e-03)],
+    "splatam": [(9.31e-10, 8.10e-07), (2.82e-06, 2.09e-05), (8.66e-06, 1.22e-04), (3.03e-05, 1.47e-04), (5.45e-04, 1.32e-04), (1.27e-03, 4.21e-04), (2.03e-03, 2.99e-04), (1.74e-03, 1.33e-03)],
+    "ba": [(9.31e-10, 3.75e-06), (4.97e-06, 1.67e-06), (5.83e-05, 8.94e-05), (2.35e-04, 1.56e-04), (6.58e-05, 5.15e-04), (1.46e-03, 3.40e-04), (2.27e-03, 2.63e-03), (6.08e-03, 2.11e-03)],
+    "imu": [(9.31e-10, 6.25e-05), (4.14e-05, 6.31e-05), (1.67e-04, 2.58e-04), (1.50e-04, 2.83e-04), (2.36e-04, 8.12e-04), (1.71e-04, 7.45e-04), (1.19e-04, 5.09e-04), (1.26e-04, 6.43e-04)],
+    "estdepth": [(9.31e-10, 7.03e-05), (6.54e-05, 7.10e-05), (2.04e-04, 4.70e-04), (8.68e-04, 4.25e-04), (1.26e-03, 7.14e-04), (2.71e-03, 7.30e-04), (6.98e-04, 1.20e-03), (1.45e-03, 1.45e-03)],
+    "white_bg": [(9.31e-10, 6.32e-05), (2.25e-05, 6.39e-05), (3.85e-05, 3.40e-04), (6.39e-05, 3.42e-04)],
+    "sh2_python": [(9.31e-10, 4.11e-06), (3.12e-06, 2.68e-06), (1.25e-05, 1.90e-04), (1.65e-05, 1.01e-04)],
+    "no_transform": [(9.31e-10, 1.02e-04), (1.42e-05, 1.03e-04), (3.65e-05, 2.08e-04), (7.26e-05, 2.73e-04)],
+}
+
+
+def _g9L_bars(variant, idx):
+    pose, mom = G9L_MEASURED[variant][idx]
+    return max(3.0 * pose, 1e-6), max(3.0 * mom, 1e-5)
+
+
 @pytest.mark.parametrize("prefix", ["g9", "g9L"])
 @pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])
 def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, prefix):
@@ -120,7 +140,7 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, pr
             assert aligned
         loose_ba = variant == "ba" and idx >= 3
         if large:
-            bar = 1e-2 if loose_ba else ((5e-4 if variant in ("ba", "white_bg") else 1e-4) if aligned else 5e-3)
+            bar = _g9L_bars(variant, idx)[0]
         else:
             # (no_transform: in that mode the pose gradient carries the covariance-rotation terms too, which largely cancel over the map; its
             #  float32 floor is ~10x the camera-frame mode's -- tests/test_gpu_fused.py, world-frame population -- and the runs separate
@@ -128,9 +148,9 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, pr
             bar = 1e-2 if loose_ba else (((5e-4 if variant in ("ba", "white_bg", "no_transform") else 1e-4) if aligned else 1e-3))
         assert r["pose_diff"] < bar, (idx, r["pose_diff"], bar)
         if large:
-            tol = 5e-4 if (aligned and not loose_ba) else 1e-2
-        else:
-            tol = (5e-4 if variant == "no_transform" else 1e-4) if (aligned and not loose_ba) else 5e-3
+            assert float(np.abs(r["moments"] - r["moments_ref"]).max()) <= _g9L_bars(variant, idx)[1], (idx, r["moments"], r["moments_ref"])
+            continue
+        tol = (5e-4 if variant == "no_transform" else 1e-4) if (aligned and not loose_ba) else 5e-3
         assert np.all(np.abs(r["moments"] - r["moments_ref"]) <= tol + tol * np.abs(r["moments_ref"])), (idx, r["moments"], r["moments_ref"])
     graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
     assert graph == [str(s) for s in G["graph"]]

@@ -50,3 +50,36 @@ for t in np.argsort(-tw):
     load[c] += tw[t]; cnt[c] += 1
 print(f"CU load (sum of its tiles' wave steps), greedy heaviest-first: max/mean {load.max() / load.mean():.3f};  launch order: "
       f"{np.array([tw[np.arange(T)[c::256]].sum() for c in range(256)]).max() / (tw.sum() / 256):.3f}")
+
+# ---- round 5: the SIMD level.  A launch ends when its busiest SIMD ends; SIMD s of a CU runs wave s of each of the CU's workgroups (if the
+# placement is wave w -> SIMD (w + c) % 4: tools/ubench/simd_placement.hip), i.e. ONE 8x8 sub-tile of each of its ~5 tiles.  Model the
+# product's placement (workgroup b -> XCD b % 8, the k-th workgroup of an XCD -> CU k % 32; tile -> workgroup through the load-balanced table,
+# modelled here as heaviest-first dealing) and ask what a per-tile ROTATION of the sub-tiles over the waves (wave w composites sub-tile
+# (w + r) % 4: two bits per table entry) could win: greedy, tile by tile, the rotation that minimises the CU's busiest SIMD so far.
+def simd_model(order_of_cu):
+    ident, rot = [], []
+    for tiles in order_of_cu:
+        s0 = np.zeros(4); s1 = np.zeros(4)
+        for t in tiles:
+            s0 += wave[t]
+            best = min(range(4), key=lambda r: (s1 + np.roll(wave[t], r)).max())
+            s1 += np.roll(wave[t], best)
+        ident.append(s0); rot.append(s1)
+    return np.array(ident), np.array(rot)
+
+per = (T + 7) // 8
+cus = []
+for x in range(8):
+    span = list(range(x * per, min(T, (x + 1) * per)))
+    span.sort(key=lambda t: -tw[t])
+    # serpentine dealing of the heaviest-first list over the XCD's 32 CUs
+    buckets = [[] for _ in range(32)]
+    for i, t in enumerate(span):
+        r, c = divmod(i, 32)
+        buckets[c if r % 2 == 0 else 31 - c].append(t)
+    cus += buckets
+ident, rot = simd_model(cus)
+mean = wave.sum() / 1024.0
+print(f"busiest SIMD / mean SIMD (wave steps; mean {mean:.0f}): sub-tile = wave {ident.max() / mean:.3f};  with a per-tile rotation {rot.max() / mean:.3f};  "
+      f"busiest CU / mean CU {ident.sum(axis=1).max() / (4 * mean):.3f}")
+print(f"  a tile's four waves: mean of (max / mean over its sub-tiles) {np.mean(wave.max(axis=1) / np.maximum(wave.mean(axis=1), 1)):.3f}")
