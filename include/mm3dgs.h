@@ -186,6 +186,11 @@ typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); 
    * (device; the pose the optimisation started from).  NULL or both weights 0: no residual.  At q == q0 the angle term's
    * autograd gradient is NaN in the reference (acos'(1) = -inf times 0); here it is taken as 0 there. */
   const float* prior_pose; float prior_w_t, prior_w_q;
+  /* ABI 206, optional: the best pose candidate of the loop (slam/tracker.py:88-91,161-181 -- the reference computes it and, by a
+   * rebinding bug, discards it; this repository's `keep_best_candidate` option keeps it).  best[8] = { loss, pose[7] }, initialised by the
+   * caller to { 1e20, starting pose }: after every step, if the iteration's total loss (image terms + prior; evaluated at the pose BEFORE
+   * the step, as the reference compares it) is below best[0], best <- { loss, the pose AFTER the step }.  NULL: not tracked. */
+  float* best;
 } Mm3dgsPoseAdam;
 
 /* The SLAM entry points (mm3dgs_slam_*) render the reference's bundle -- RGB and, as channels 3..5, the depth pass [z, 1, z^2] of
@@ -367,8 +372,8 @@ const char* mm3dgs_last_error(void);
    201: Mm3dgsLossConfig grew by the three splatam fields | 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
    203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations are void
    204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / MM3DGS_FWD_KEEP_TILE_ORDER
-   205: Mm3dgsHeader.overflow_seen (appended) */
-#define MM3DGS_ABI_VERSION 205
+   205: Mm3dgsHeader.overflow_seen (appended) | 206: Mm3dgsPoseAdam.best (appended) */
+#define MM3DGS_ABI_VERSION 206
 int mm3dgs_version(void);
 
 #ifdef __cplusplus

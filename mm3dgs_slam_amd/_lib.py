@@ -48,7 +48,7 @@ class Mm3dgsMapAdam(C.Structure):
 class Mm3dgsPoseAdam(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("lr_q", C.c_double),
                 ("lr_t", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("prior_pose", C.c_void_p), ("prior_w_t", C.c_float), ("prior_w_q", C.c_float)]
+                ("prior_pose", C.c_void_p), ("prior_w_t", C.c_float), ("prior_w_q", C.c_float), ("best", C.c_void_p)]
 
 
 class Mm3dgsMapView(C.Structure):

@@ -371,6 +371,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     if (pose_adam->prior_pose && (pose_adam->prior_w_t != 0.f || pose_adam->prior_w_q != 0.f)) {
       pa.prior = pose_adam->prior_pose; pa.prior_w_t = pose_adam->prior_w_t; pa.prior_w_q = pose_adam->prior_w_q;
     }
+    pa.best = pose_adam->best;
   }
   MapAdam ma;
   memset(&ma, 0, sizeof(ma));

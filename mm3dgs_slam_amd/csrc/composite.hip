@@ -511,7 +511,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
       float* exch = (float*)(smem_raw + sizeof(LossGradSmem));
       float g4[4];
       bool in_raster;
-      loss_grad_tile(tl.cfg, tl.out, tl.gt, tl.ref, tl.dmaps, tl.sums, tile, cam.gx, lsm, g4, in_raster);
+      if (PROBE(cam, 10)) { g4[0] = g4[1] = g4[2] = g4[3] = 1e-3f; in_raster = true; }      // (probe builds, bit 10: timing without the loss prologue)
+      else loss_grad_tile(tl.cfg, tl.out, tl.gt, tl.ref, tl.dmaps, tl.sums, tile, cam.gx, lsm, g4, in_raster);
 #pragma unroll
       for (int ch = 0; ch < 4; ch++) exch[ch * 256 + tid] = g4[ch];
       __syncthreads();
@@ -535,7 +536,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   for (uint32_t e = todo + q; e < count; e += 16) {
     zero_record<NV>(dsub + (size_t)list[e].y * RECF);
   }
-  if (maxtodo != 0) {   // wave-uniform (a wave without work still takes part in the workgroup's per-tile combine below)
+  if (maxtodo != 0 && !PROBE(cam, 9)) {   // wave-uniform; (probe builds, bit 9: timing without the main loop) (a wave without work still takes part in the workgroup's per-tile combine below)
 
   const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : (SEP_REDUCE2 ? SepReduce2<MODE == 1>::slot(q) : SepReduce<MODE == 1>::slot(q));
   float ym_0 = 0.f, ym_1a = 0.f, ym_1b = 0.f;

@@ -9,12 +9,10 @@
 // alignment only), and a reader that fetches whole float4s past a record's end gets the head of the next record in lanes it ignores.
 #define REC_MAP_F 10
 #define REC_TRACK_F 7
-// generic path: 6 + C floats, packed (round-5 experiment -DMM3DGS_GENERIC_REC12: a 48-byte stride, 16-byte aligned records)
-#ifdef MM3DGS_GENERIC_REC12
-#define GENERIC_RECF(C) 12
-#else
+// generic path: 6 + C floats, packed.  (A 48-byte stride -- 16-byte aligned records -- was measured in round 5 on the 1080p / 3 M pass: the backward
+// compositor's WRITE_SIZE is unchanged, 2.34 GB -- every record leaves the L2 as one 64-byte write either way, 37 M records x 64 B -- and the launch
+// takes 1551 us instead of 1276: the consumer reads a third more bytes.  profiles/r05_c5_rec12.txt)
 #define GENERIC_RECF(C) (6 + (C))
-#endif
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float4 ld4u(const float* p) { const f4u v = *(const f4u*)p; return make_float4(v.x, v.y, v.z, v.w); }

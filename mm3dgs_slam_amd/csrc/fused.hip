@@ -1001,6 +1001,9 @@ __device__ __forceinline__ void pose_finish_body(const float* __restrict__ posep
       float* l4 = pls.loss4 ? pls.loss4 : ad_loss4;
       if (l4) l4[0] += ad.prior_w_t * t_l + ad.prior_w_q * ang;    // after the image terms were written (same stream)
     }
+    // the iteration's total loss (image terms of the launches before this one, or of the deferred masked L1 above, + the prior): only read
+    // when a best candidate is kept
+    float* const l4_total = pls.loss4 ? pls.loss4 : ad_loss4;
     if (dpose) for (int i = 0; i < 7; i++) dpose[i] = grad[i];
     // (an iteration whose forward overflowed its capacity is void, see slam_bwd_body: the pose keeps its value AND its Adam state)
     if (ad.pose && ovf_word == 0u) {
@@ -1017,7 +1020,15 @@ __device__ __forceinline__ void pose_finish_body(const float* __restrict__ posep
         const float vi = av[i] * b2 + gi * gi * omb2;
         ad.m[i] = mi; ad.v[i] = vi;
         const float denom = sqrtf(vi) / bc2s + ad.eps;
-        ad.pose[i] = pcur[i] - (i < 4 ? ss_q : ss_t) * (mi / denom);
+        pcur[i] = pcur[i] - (i < 4 ? ss_q : ss_t) * (mi / denom);
+        ad.pose[i] = pcur[i];
+      }
+      if (ad.best && l4_total) {      // Mm3dgsPoseAdam.best: the loss at the pose the render used against the best so far, the candidate is the stepped pose
+        const float lt = l4_total[0];
+        if (lt < ad.best[0]) {
+          ad.best[0] = lt;
+          for (int i = 0; i < 7; i++) ad.best[1 + i] = pcur[i];
+        }
       }
     }
   }

@@ -14,7 +14,7 @@ struct SlamGrads {
 // Adam scalars as torch.optim.Adam applies them: formed in double on the host, rounded once to float.
 //   omb1 = 1 - beta1 (lerp weight), beta2, omb2 = 1 - beta2, step_size = lr / (1 - beta1^t) per group, bc2s = sqrt(1 - beta2^t)
 struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; const uint8_t* opt_mask; };
-struct PoseAdam { float* pose; float* m; float* v; int* step; double lr_q, lr_t, beta1, beta2; float eps; const float* prior; float prior_w_t, prior_w_q; };
+struct PoseAdam { float* pose; float* m; float* v; int* step; double lr_q, lr_t, beta1, beta2; float eps; const float* prior; float prior_w_t, prior_w_q; float* best; };
 struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float step_size; };
 struct AdamArgs { AdamGroup grp[8]; int ngroups; float omb1, beta2, omb2, eps, bc2s; };
 struct LossCfg {

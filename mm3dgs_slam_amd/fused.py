@@ -8,9 +8,9 @@ collapsed into a handful of C-ABI calls with no host synchronisation inside the 
 ``optimize_map`` whenever the covariances come from scales + rotations and the ACTIVE SH degree is 0 (the reference never
 raises it): both branches of ``transform_means_python`` (round 4: world-frame means natively), models that carry SH rows,
 ``convert_SHs_python``, the IMU residual, bundle adjustment -- also with a sharded mapping window (round 4) -- and the
-``method: splatam`` losses and pruning schedule.  What is left (``compute_cov3D_python``, a resumed checkpoint with an active
-SH degree > 0, ``keep_best_candidate``) falls back to the torch-graph loop with a warning; that loop stays the parity
-reference for these kernels (tests/test_gpu_fused.py).
+``method: splatam`` losses and pruning schedule, and (round 5) ``keep_best_candidate`` (the arg-min over the iterations' losses is
+kept on the device).  What is left (``compute_cov3D_python``, a resumed checkpoint with an active SH degree > 0) falls back to the
+torch-graph loop with a warning; that loop stays the parity reference for these kernels (tests/test_gpu_fused.py).
 """
 from __future__ import annotations
 
@@ -340,13 +340,9 @@ class FusedTracker(Tracker):
 
     def optimize_cam(self, idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth=None, est_depth=None):
         trk = self.cfg["tracking"]
-        if self.keep_best_candidate and num_iter > 0 and "keep_best_candidate" not in FusedEngine._warned:
-            FusedEngine._warned.add("keep_best_candidate")
-            import warnings
-            warnings.warn("mm3dgs: keep_best_candidate=True (this repository's option; the reference computes the candidate and discards it, "
-                          "slam/tracker.py:161-181) is outside the native tracking loop: tracking runs the torch-graph loop around the generic HIP "
-                          "rasterizer -- correct, but about 30x slower")
-        if (num_iter == 0 or self.keep_best_candidate or not FusedEngine.eligible(self.cfg, self.gaussians)):
+        # (keep_best_candidate -- this repository's option for what slam/tracker.py:88-91,161-181 computes and then discards -- runs natively
+        #  since round 5: the pose-finish kernel keeps the arg-min over the iterations' losses on the device, Mm3dgsPoseAdam.best)
+        if (num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians)):
             return super().optimize_cam(idx, num_iter, optimizer, camera_tensor_q, camera_tensor_T, gt_color, gt_depth, est_depth)
         eng = _engine(self.renderer)
         dev = eng.dev
@@ -375,6 +371,10 @@ class FusedTracker(Tracker):
                 ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
                 ad.lr_q, ad.lr_t = float(trk["rotation_lr"]), float(trk["position_lr"])
                 ad.beta1, ad.beta2, ad.eps = 0.9, 0.999, 1e-8
+                best = None
+                if self.keep_best_candidate:
+                    best = torch.cat([torch.full((1,), 1e20, device=dev), pose0]).contiguous()      # { loss, pose }: slam/tracker.py:88-91
+                    ad.best = best.data_ptr()
                 if trk["use_imu_loss"] and self.cfg["method"].lower() != "splatam":      # rel_pose_loss against the pose the optimisation starts from (slam/tracker.py:87,146-155; not in the splatam branch)
                     ad.prior_pose, ad.prior_w_t, ad.prior_w_q = pose0.data_ptr(), float(trk["imu_T_weight"]), float(trk["imu_q_weight"])
                 eng.track_loop(num_iter, pose, g, lcfg, gt_color, ref, ad)
@@ -391,6 +391,8 @@ class FusedTracker(Tracker):
                     break
             else:
                 raise RuntimeError("mm3dgs: tracking loop kept overflowing its binning capacity")
+            if best is not None:
+                pose = best[1:8]
             camera_tensor_q.data.copy_(pose[:4])
             camera_tensor_T.data.copy_(pose[4:])
             if self.cfg["debug"]["get_runtime_stats"]:

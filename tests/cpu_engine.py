@@ -133,6 +133,7 @@ class CpuEngine:
         pbuf, m, v = _view(ad.pose, 7), _view(ad.m, 7), _view(ad.v, 7)
         step = _view(ad.step, 1, C.c_int32)
         prior = _view(ad.prior_pose, 7).clone() if ad.prior_pose else None
+        best = _view(ad.best, 8) if ad.best else None          # Mm3dgsPoseAdam.best: { loss, pose[7] }
         frozen = _FrozenMap(g)
         for _ in range(n_iter):
             with torch.enable_grad():          # (fused.py calls the loops under no_grad: the library needs no autograd)
@@ -148,6 +149,9 @@ class CpuEngine:
                 step[0] = t
                 _adam(pbuf[:4], p.grad[:4], m[:4], v[:4], t, ad.lr_q, ad.beta1, ad.beta2, ad.eps)
                 _adam(pbuf[4:], p.grad[4:], m[4:], v[4:], t, ad.lr_t, ad.beta1, ad.beta2, ad.eps)
+                if best is not None and float(loss) < float(best[0]):      # the loss at the rendered pose, the candidate = the stepped pose
+                    best[0] = float(loss)
+                    best[1:] = pbuf
             self.out, self.loss = out6.detach(), torch.tensor([float(loss), 0.0, 0.0, 0.0])
         self.calls.append(("track", n_iter))
 
