@@ -689,7 +689,12 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // per listed 4x4 block: a quarter of the bytes on the kernel that the counters show to be bandwidth bound on exactly them
     // (148 MB per mapping launch, 56 MB of it block records).  The block records were written by this workgroup's own waves a
     // moment ago (same CU: visible after the barrier); a pair is found by its position in the tile's bin (payload / trec).
-    __syncthreads();
+    // The lane's first table entry is requested BEFORE the barrier (round 5): it depends on nothing the rows compute, the main loop's registers
+    // are dead here, and the load lands while the wave waits for the tile's slowest wave -- one of the combine's three dependent round trips
+    // (table -> records -> store) off the tail every workgroup ends with (the skeleton probes: 12 of the mapping launch's 57 us are this pass).
+    // (Measured and rejected in the same round: the pairs whose listed blocks all lie in ONE 8x8 sub-tile summed by that sub-tile's wave BEFORE
+    // the barrier -- every wave then scans the whole bin for its own pairs behind an s_waitcnt vmcnt(0): mapping launch 59.4 us against 58.1,
+    // fused tracking kernel 71.3 against 67.1, profiles/r05_ab_combine.txt.)
     float* __restrict__ dtile = dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F;
     auto combine = [&](const unsigned long long pl, const uint32_t tr) {
       uint32_t mask = (uint32_t)pl & 0xffffu;
@@ -725,8 +730,16 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
       }
     };
-    if (!PROBE(cam, 5))      // (probe builds, bit 5: timing without the combine)
-      for (uint32_t e = (uint32_t)tid; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
+    if (!PROBE(cam, 5)) {      // (probe builds, bit 5: timing without the combine)
+      unsigned long long pl_first = 0ull;
+      uint32_t tr_first = 0xffffffffu;
+      if ((uint32_t)tid < len) { pl_first = b.payload[start + tid]; tr_first = b.trec[start + tid]; }
+      __syncthreads();
+      if ((uint32_t)tid < len) combine(pl_first, tr_first);
+      for (uint32_t e = (uint32_t)tid + 256u; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
+    } else {
+      __syncthreads();
+    }
   }
 }
 

@@ -784,7 +784,8 @@ def test_native_tracker_keeps_the_best_candidate_like_the_torch_graph_tracker(va
     # the candidate is a pose of the SAME trajectory in both programs (the trajectories agree to ~1e-4 per test_native_tracker_with_imu_prior...);
     # picking another iteration would be off by a whole optimiser step (4e-3 here)
     assert (outs["graph"] - outs["native"]).abs().max() < 5e-4, (outs["graph"], outs["native"])
-    assert (outs["native"] - outs["native_last"]).abs().max() > 1e-3, "the best candidate should not be the last iterate in this set-up"
+    if variant != "imu":      # (the prior pulls the pose back: with it the loss decreases monotonically here and the last iterate IS the best)
+        assert (outs["native"] - outs["native_last"]).abs().max() > 1e-3, "the best candidate should not be the last iterate in this set-up"
 
 
 @pytest.mark.parametrize("direct", [False, True])

@@ -37,7 +37,9 @@ class _Frames:
 
 def run_variant(variant, verbose=False, prefix="g9"):
     """Drives the native loops over the fixture's frames; returns the per-frame measurements (also used by tools/g9_native_check.py).
-    prefix "g9": the 64x48 fixtures; "g9L": the 160x120 ones (80 tiles, ~8.6 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6)."""
+    prefix "g9": the 64x48 fixtures; "g9L": the 160x120 ones (80 tiles, ~8.6 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6); "g9S": 160x120 at
+    the SHIPPED schedule (configs/TUM.yml: 100 tracking / 150 mapping iterations, pruning_interval 50, min_opacity 0.005, kf_every 5,
+    min_covisibility 0.95; 11 frames, keyframes 0 / 5 / 10, 19.2 k Gaussians)."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor as M
     from mm3dgs_slam_amd.slam import SLAM
@@ -168,3 +170,45 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, pr
     after = np.array([random.random(), float(np.random.rand()), float(torch.rand(1))])
     assert np.allclose(after, G["rng_after"]), (after, G["rng_after"])
     assert getattr(slam.mapper, "loop_reruns", 0) >= 0
+
+
+# Round 5 (missing #2): the schedule the reference SHIPS and the benchmark times -- 100 tracking + 150 mapping iterations per
+# frame, pruning_interval 50 with its no-op Adam steps at mapping iterations 0 and 50, min_opacity 0.005, kf_every 5, min_covisibility 0.95
+# (/root/reference/configs/TUM.yml:32,44-50,73-75; the `imu` variant: configs/UTMM.yml's hot-path settings on the same schedule) -- held to
+# slam/tracker.py:94-177 and slam/mapper.py:718-950 end to end: 11 frames at 160x120 (one Gaussian per pixel: 19.2 k), three keyframes,
+# ~2750 optimiser iterations per variant (tests/golden/make_golden_slam.py --shipped: about an hour of the CPU oracle per variant).
+# With min_opacity 0.005 nothing sits near the pruning threshold, so the two maps keep the same rows much longer than in the g9L set.
+G9S_MEASURED = {}      # variant -> [(camera-matrix difference, largest moment difference) per frame], filled from the first GPU run (bars: 3x)
+
+
+@pytest.mark.parametrize("variant", ["vigs", "imu"])
+def test_native_hip_loops_reproduce_the_reference_classes_at_the_shipped_schedule(variant):
+    from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
+    from tests import g9_util
+    if not os.path.exists(os.path.join(HERE, "golden", f"g9S_{variant}.npz")):
+        pytest.skip("fixture not generated (tests/golden/make_golden_slam.py --shipped)")
+    slam, G, rows = run_variant(variant, prefix="g9S")
+    want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
+    assert want_kf[-1] == [0, 5, 10]
+    for r in rows:
+        idx = r["idx"]
+        assert r["keyframes"] == want_kf[idx], (idx, r["keyframes"], want_kf[idx])
+        assert abs(r["P"] - r["P_ref"]) <= max(2, 0.005 * r["P_ref"]), (idx, r["P"], r["P_ref"])
+        pose_bar, mom_bar = (5e-3, 1e-2)
+        if variant in G9S_MEASURED:
+            pose_bar, mom_bar = max(3.0 * G9S_MEASURED[variant][idx][0], 1e-6), max(3.0 * G9S_MEASURED[variant][idx][1], 1e-5)
+        assert r["pose_diff"] < pose_bar, (idx, r["pose_diff"], pose_bar)
+        assert float(np.abs(r["moments"] - r["moments_ref"]).max()) <= mom_bar, (idx, r["moments"], r["moments_ref"])
+    graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]
+    assert graph == [str(s) for s in G["graph"]]
+    for kf, ref in zip(slam.mapper.keyframes, G["keyframe_poses"]):
+        d = (get_camera_from_tensor(kf.pose.detach().cpu().float()) - get_camera_from_tensor(torch.from_numpy(ref))).abs().max()
+        assert d < 5e-3, (kf.idx, float(d))
+    g = slam.gaussians
+    for name, t in (("xyz", g._xyz), ("opacity", g._opacity), ("scaling", g._scaling), ("rotation", g._rotation), ("f_dc", g._features_dc)):
+        got, ref = g9_util.final_quantiles(G, name, t)
+        for col in range(got.shape[1]):
+            a, b = got[:, col], ref[:, col]
+            assert (a - b).abs().max() < 0.02 * max(1.0, float(b.abs().max())), (name, col, a, b)
+    after = np.array([random.random(), float(np.random.rand()), float(torch.rand(1))])
+    assert np.allclose(after, G["rng_after"]), (after, G["rng_after"])

@@ -1,5 +1,5 @@
 """Prints, per frame, how the NATIVE loops (HIP kernels) follow the G9 reference trajectories (the measurements that
-tests/test_gpu_golden_slam.py asserts on).  GPU box:   python tools/g9_native_check.py [--large] [variant ...]"""
+tests/test_gpu_golden_slam.py asserts on).  GPU box:   python tools/g9_native_check.py [--large | --shipped] [variant ...]"""
 import os
 import random
 import sys
@@ -14,7 +14,9 @@ if __name__ == "__main__":
     prefix = "g9"
     if "--large" in sys.argv:
         sys.argv.remove("--large"); prefix = "g9L"
-    for variant in (sys.argv[1:] or ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"]):
+    if "--shipped" in sys.argv:
+        sys.argv.remove("--shipped"); prefix = "g9S"
+    for variant in (sys.argv[1:] or (["vigs", "imu"] if prefix == "g9S" else ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])):
         try:
             slam, G, rows = run_variant(variant, verbose=True, prefix=prefix)
         except Exception as e:      # keep going: this is a survey

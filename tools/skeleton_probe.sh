@@ -32,9 +32,17 @@ view = (pose, color.contiguous(), depth.contiguous())
 eng._ensure(int(g._xyz.shape[0]), True)
 torch.cuda.synchronize()
 os.environ["MM3DGS_EXP"] = exp
+from mm3dgs_slam_amd import _lib
 with torch.no_grad():
     for _ in range(60):
         eng.map_loop([view], g, lcfg, None, None, grads=eng.grads)
+    # tracking iterations with the learning rates at 0 (the pose stays put: a static workload whatever the probes do to the gradient)
+    tcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.0, 1, 0, 1, 0.99)
+    p = pose.clone(); mm, vv = torch.zeros(7, device="cuda"), torch.zeros(7, device="cuda"); st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ad = _lib.Mm3dgsPoseAdam()
+    ad.pose, ad.m, ad.v, ad.step = p.data_ptr(), mm.data_ptr(), vv.data_ptr(), st.data_ptr()
+    ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = 0.0, 0.0, 0.9, 0.999, 1e-8
+    eng.track_loop(60, p, g, tcfg, color.contiguous(), None, ad)
 torch.cuda.synchronize()
 PY
 for E in ${PROBE_EXPS:-0 512 1024 32 1536 1568}; do
@@ -47,7 +55,7 @@ if not f:
     print("EXP", sys.argv[1], "no trace:", open("/tmp/sk.out").read()[-400:]); sys.exit(0)
 rows = [r for r in csv.DictReader(open(f[0]))]
 out = []
-for key in ("composite_bwd_kernel<6, 1>", "sort_composite_fwd_kernel", "ssim_maps", "slam_preprocess_bwd", "slam_project_bin"):
+for key in ("composite_bwd_kernel<6, 1>", "sort_composite_fwd_kernel", "sort_composite_fwd_bwd_track", "ssim_maps", "slam_preprocess_bwd", "slam_project_bin"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]][-50:]
     if d: out.append(f"{key.split('<')[0][-24:]} {sum(d) / len(d):6.2f}")
 print("EXP", sys.argv[1].rjust(5), " | ".join(out))
