@@ -696,6 +696,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // the barrier -- every wave then scans the whole bin for its own pairs behind an s_waitcnt vmcnt(0): mapping launch 59.4 us against 58.1,
     // fused tracking kernel 71.3 against 67.1, profiles/r05_ab_combine.txt.)
     float* __restrict__ dtile = dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F;
+    // (Also measured and rejected in round 5: four lanes per pair, one per 16-byte chunk of a record, so that one load instruction fetches a record
+    // with adjacent lanes -- a third of the cache-line requests, but a lane group then walks four pairs one after the other: mapping launch 58.6 us
+    // against 58.1, fused tracking kernel 69.2 against 67.1.  The pass is a latency chain per pair, not a request-rate limit: one pair per lane it is.)
     auto combine = [&](const unsigned long long pl, const uint32_t tr) {
       uint32_t mask = (uint32_t)pl & 0xffffu;
       const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);

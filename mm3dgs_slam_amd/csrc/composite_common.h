@@ -7,13 +7,10 @@
 // (28 B) in tracking -- round 1 wrote 48 / 32 B (the backward compositor's HBM traffic was 3.4x its algorithmic bytes).  Records
 // are then only 4-byte aligned: the wide accesses go through 4-byte-aligned vector types (global_load / store_dwordx4 need dword
 // alignment only), and a reader that fetches whole float4s past a record's end gets the head of the next record in lanes it ignores.
-#ifdef MM3DGS_REC_ALIGNED      // round-5 experiment: 48 / 32-byte strides (a 16-byte aligned record never straddles more than one 64-byte line boundary)
-#define REC_MAP_F 12
-#define REC_TRACK_F 8
-#else
+// (Round 5 re-measured the aligned alternative, 48 / 32-byte strides: mapping backward 59.7 us against 58.0, backward projection 31.1 against 30.7 --
+// the bytes cost more than the line straddles, profiles/r05_ab_rec48.txt.)
 #define REC_MAP_F 10
 #define REC_TRACK_F 7
-#endif
 // generic path: 6 + C floats, packed.  (A 48-byte stride -- 16-byte aligned records -- was measured in round 5 on the 1080p / 3 M pass: the backward
 // compositor's WRITE_SIZE is unchanged, 2.34 GB -- every record leaves the L2 as one 64-byte write either way, 37 M records x 64 B -- and the launch
 // takes 1551 us instead of 1276: the consumer reads a third more bytes.  profiles/r05_c5_rec12.txt)
