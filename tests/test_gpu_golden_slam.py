@@ -37,9 +37,10 @@ class _Frames:
 
 def run_variant(variant, verbose=False, prefix="g9"):
     """Drives the native loops over the fixture's frames; returns the per-frame measurements (also used by tools/g9_native_check.py).
-    prefix "g9": the 64x48 fixtures; "g9L": the 160x120 ones (80 tiles, ~8.6 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6); "g9S": 160x120 at
+    prefix "g9": the 64x48 fixtures; "g9L": the 160x120 ones (80 tiles, ~8.6 k Gaussians, 8 frames, keyframes 0 / 2 / 4 / 6); "g9D": 160x120 at
     the SHIPPED schedule (configs/TUM.yml: 100 tracking / 150 mapping iterations, pruning_interval 50, min_opacity 0.005, kf_every 5,
-    min_covisibility 0.95; 11 frames, keyframes 0 / 5 / 10, 19.2 k Gaussians)."""
+    min_covisibility 0.95) on the hand-held sweep of the bench's `moving` line: 11 frames, keyframes 0 / 5 / 10, 19.2 k Gaussians + what the
+    keyframes seed."""
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor as M
     from mm3dgs_slam_amd.slam import SLAM
@@ -176,18 +177,21 @@ def test_native_hip_loops_reproduce_the_reference_classes_end_to_end(variant, pr
 # frame, pruning_interval 50 with its no-op Adam steps at mapping iterations 0 and 50, min_opacity 0.005, kf_every 5, min_covisibility 0.95
 # (/root/reference/configs/TUM.yml:32,44-50,73-75; the `imu` variant: configs/UTMM.yml's hot-path settings on the same schedule) -- held to
 # slam/tracker.py:94-177 and slam/mapper.py:718-950 end to end: 11 frames at 160x120 (one Gaussian per pixel: 19.2 k), three keyframes,
-# ~2750 optimiser iterations per variant (tests/golden/make_golden_slam.py --shipped: about an hour of the CPU oracle per variant).
-# With min_opacity 0.005 nothing sits near the pruning threshold, so the two maps keep the same rows much longer than in the g9L set.
-G9S_MEASURED = {}      # variant -> [(camera-matrix difference, largest moment difference) per frame], filled from the first GPU run (bars: 3x)
+# ~2750 optimiser iterations per variant (tests/golden/make_golden_slam.py --shipped-desk: more than an hour of the CPU oracle per variant).
+# The camera follows mm3dgs_slam_amd.slam.trajectory_desk over a 1.8x wider scene: on the bounded trajectory of the other sets the view never
+# loses 5 % of the last keyframe, and the shipped keyframe rule (slam/mapper.py:141-173: covisibility below min_covisibility AND kf_every frames
+# since the last keyframe) would never spawn a second one.  With min_opacity 0.005 nothing sits near the pruning threshold, so the two maps
+# keep the same rows much longer than in the g9L set.
+G9D_MEASURED = {}      # variant -> [(camera-matrix difference, largest moment difference) per frame], filled from the first GPU run (bars: 3x)
 
 
 @pytest.mark.parametrize("variant", ["vigs", "imu"])
 def test_native_hip_loops_reproduce_the_reference_classes_at_the_shipped_schedule(variant):
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
     from tests import g9_util
-    if not os.path.exists(os.path.join(HERE, "golden", f"g9S_{variant}.npz")):
-        pytest.skip("fixture not generated (tests/golden/make_golden_slam.py --shipped)")
-    slam, G, rows = run_variant(variant, prefix="g9S")
+    if not os.path.exists(os.path.join(HERE, "golden", f"g9D_{variant}.npz")):
+        pytest.skip("fixture not generated (tests/golden/make_golden_slam.py --shipped-desk)")
+    slam, G, rows = run_variant(variant, prefix="g9D")
     want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
     assert want_kf[-1] == [0, 5, 10]
     for r in rows:
@@ -195,8 +199,8 @@ def test_native_hip_loops_reproduce_the_reference_classes_at_the_shipped_schedul
         assert r["keyframes"] == want_kf[idx], (idx, r["keyframes"], want_kf[idx])
         assert abs(r["P"] - r["P_ref"]) <= max(2, 0.005 * r["P_ref"]), (idx, r["P"], r["P_ref"])
         pose_bar, mom_bar = (5e-3, 1e-2)
-        if variant in G9S_MEASURED:
-            pose_bar, mom_bar = max(3.0 * G9S_MEASURED[variant][idx][0], 1e-6), max(3.0 * G9S_MEASURED[variant][idx][1], 1e-5)
+        if variant in G9D_MEASURED:
+            pose_bar, mom_bar = max(3.0 * G9D_MEASURED[variant][idx][0], 1e-6), max(3.0 * G9D_MEASURED[variant][idx][1], 1e-5)
         assert r["pose_diff"] < pose_bar, (idx, r["pose_diff"], pose_bar)
         assert float(np.abs(r["moments"] - r["moments_ref"]).max()) <= mom_bar, (idx, r["moments"], r["moments_ref"])
     graph = [",".join(map(str, sorted(slam.mapper.covisibility_graph[k]))) for k in range(len(slam.mapper.keyframes))]

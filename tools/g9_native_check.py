@@ -15,8 +15,8 @@ if __name__ == "__main__":
     if "--large" in sys.argv:
         sys.argv.remove("--large"); prefix = "g9L"
     if "--shipped" in sys.argv:
-        sys.argv.remove("--shipped"); prefix = "g9S"
-    for variant in (sys.argv[1:] or (["vigs", "imu"] if prefix == "g9S" else ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])):
+        sys.argv.remove("--shipped"); prefix = "g9D"
+    for variant in (sys.argv[1:] or (["vigs", "imu"] if prefix == "g9D" else ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "white_bg", "sh2_python", "no_transform"])):
         try:
             slam, G, rows = run_variant(variant, verbose=True, prefix=prefix)
         except Exception as e:      # keep going: this is a survey

@@ -68,22 +68,26 @@ def main():
     name_of = {"sort_composite_fwd_kernelILi6E": ("sort + forward compositor", "fwd"), "composite_bwd_kernelILi6ELi1E": ("mapping backward compositor", "bwd"),
                "composite_bwd_kernelILi6ELi2E": ("tracking backward compositor", "bwd"), "sort_composite_fwd_bwd_track": ("fused tracking kernel", None),
                "composite_bwd_kernelILi3ELi0E": ("generic backward compositor, C = 3", None), "composite_fwd_kernelILi3E": ("generic forward compositor, C = 3", None)}
-    print(f"{'kernel':44s} {'loop':>5s} {'VALU':>5s} {'DPP':>4s} {'trans':>5s} {'mad64':>5s} {'SALU':>5s} {'LDS':>4s} {'VMEM':>5s} {'VALU ns/step':>13s} {'floor us':>9s}")
+    print(f"{'kernel':44s} {'loop':>11s} {'VALU':>5s} {'DPP':>4s} {'trans':>5s} {'mad64':>5s} {'SALU':>5s} {'LDS':>4s} {'VMEM':>5s} {'VALU ns/step':>13s} {'floor us':>9s}")
     for mangled, ins in kernels.items():
         label = next((v for k, v in name_of.items() if k in mangled), None)
         if label is None:
             continue
         marks = [i for i, (op, _) in enumerate(ins) if op.startswith("v_exp_f32")]
-        loop = 0
+        loop, seen = 0, set()
         for a, b in zip(marks, marks[1:]):
-            if b - a > 220:
-                continue          # different loops
+            if b - a > 125:
+                continue          # markers of different loops (a step is 50 - 100 instructions)
             c = collections.Counter(classify(op, text) for op, text in ins[a:b])
             ns = sum(c[k] * NS[k] for k in NS)
             is_bwd = c["dpp"] > 0
+            if not is_bwd and "fwd" in seen:
+                continue
+            seen.add("fwd" if not is_bwd else "bwd")
             n_steps = steps["bwd" if is_bwd else "fwd"]
-            loop += 1
-            print(f"{label[0]:44s} {('bwd' if is_bwd else 'fwd') + str(loop):>5s} {c['valu']:5d} {c['dpp']:4d} {c['trans']:5d} {c['mad64']:5d} {c['salu']:5d} {c['lds']:4d} {c['vmem']:5d} "
+            loop += 1 if is_bwd else 0
+            inst = ("general" if loop == 1 else "fast") if is_bwd else "-"      # backward: the general loop instance, then the one for waves whose pixels carry no silhouette / depth^2 / background gradient (the SLAM losses)
+            print(f"{label[0]:44s} {('bwd ' + inst if is_bwd else 'fwd'):>11s} {c['valu']:5d} {c['dpp']:4d} {c['trans']:5d} {c['mad64']:5d} {c['salu']:5d} {c['lds']:4d} {c['vmem']:5d} "
                   f"{ns:13.1f} {n_steps * ns / 1024 / 1e3:9.1f}")
     print(f"(wave steps per launch: forward {steps['fwd']}, backward {steps['bwd']} -- tools/xcd_balance.py on the benchmark map at frame 8: 263 654 wave steps for 992 024 row steps;\n"
           " lanes useful per (row, splat) step: ~7 of 16 -- the splat's { alpha >= 1/255 } region inside a 4x4 block, tools/pair_stats.py)")
