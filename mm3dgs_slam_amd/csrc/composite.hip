@@ -725,7 +725,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
           if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
         }
       }
-      if (tr != 0xffffffffu) {
+      if (tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
         float* o = dtile + (size_t)tr * RECF;
         const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
         *(f4u*)o = q0;

@@ -249,7 +249,7 @@ struct CamDev {
 // selects them by bit; in the product build PROBE() is the constant 0, the probed branches fold away and the variable is never read.
 //   bit 0: backward compositor without its record stores | 1: sort phase only | 2: no list emission | 3: no sort | 4: combine without its
 //   record gather | 5: no combine | 6: binning without the shared big-splat list | 7: only the own pairs counted | 8: no > 32-tile counting
-//   9: backward compositor without its main loop | 10: mapping backward compositor without the loss prologue
+//   9: backward compositor without its main loop | 10: mapping backward compositor without the loss prologue | 11: combine without its stores
 #ifdef MM3DGS_PROBES
 #define PROBE(cam, bit) ((((cam).probes) >> (bit)) & 1)
 #define PROBE_WORD(cam) ((cam).probes)
