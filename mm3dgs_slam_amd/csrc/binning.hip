@@ -265,7 +265,7 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
 // advance together: sum over the four 8x8 sub-tiles of the longest of their four block lists) -- from whatever view was rendered last;
 // the table is a permutation whatever the loads are, so a stale or meaningless load only costs speed.  One workgroup per XCD.
 #define ORDER_MAX_PER 160     // five rounds of 32 CU slots: beyond that the workgroups of a launch are placed dynamically
-// Round 4 experiment, measured and NOT adopted (-DMM3DGS_ORDER_LOAD_SPANS, tools/build_variant.sh): the eight spans cut by LOAD instead of
+// Round 4 experiment, measured and NOT adopted (its branch left the sources in round 5): the eight spans cut by LOAD instead of
 // by tile count.  On a camera that moves, keyframes seed the newly seen side of the image and the tile lists there grow: with equal-count
 // spans one XCD carries 1.05 - 1.11 x the mean wave steps (tools/xcd_balance.py on the bench's `moving` scenario; 1.02 - 1.03 on the bounded
 // trajectory), load-cut contiguous spans bring that to 1.005 (a span then holds up to TILE_SPAN_SLOTS tiles, the compositors launch

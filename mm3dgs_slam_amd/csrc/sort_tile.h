@@ -48,8 +48,7 @@ __device__ __forceinline__ void bitonic_any_len(KeyAt&& at, int len, int tid, in
 // The partner of a compare-exchange at distance J comes through the VALU's own lane crossbars instead of the LDS one (ds_bpermute_b32:
 // 26 ns of latency per dependent step, 10 ns of LDS pipe per instruction at 4 waves per SIMD; v_mov_b32_dpp: 2 ns, tools/ubench): distances
 // 1, 2 (quad_perm) and 8 (row_ror:8) are one DPP move per dword, 4 is two (mirror of the 8-lane half, then of the quads), 16 and 32 are
-// gfx950's v_permlane16_swap / v_permlane32_swap of two copies of the dword (-DMM3DGS_SORT_BPERMUTE: the ds_bpermute exchanges, as before
-// round 4).  Any correct network yields the same order (keys are unique).
+// gfx950's v_permlane16_swap / v_permlane32_swap of two copies of the dword (before round 4: ds_bpermute exchanges, sort + forward +0.9 us).  Any correct network yields the same order (keys are unique).
 template <int J>
 __device__ __forceinline__ uint32_t lane_xor_dpp(uint32_t v) {
   static_assert(J == 1 || J == 2 || J == 4 || J == 8, "distances inside a 16-lane row");
