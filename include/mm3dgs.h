@@ -78,6 +78,8 @@ typedef struct Mm3dgsHeader {
                                  every launch of THAT iteration's forward.  The fused backward projection + next projection launch reads
                                  this copy: its second half bins the NEXT view and may raise `overflow` while workgroups of its first half
                                  are still starting -- with the copy, all of them take the same step / no-step decision */
+  uint32_t mean_wave_steps;   /* ABI 207: mean list walk of a compositing wave (8x8 sub-tile) in the render the workgroup -> tile table was built from
+                                 (written with the table, 0: unknown): the compositors raise the issue priority of waves whose walk is well above it */
 } Mm3dgsHeader;
 
 struct Mm3dgsLossConfig;   /* defined with mm3dgs_loss below; the SLAM loop entry points take a pointer to it */
@@ -372,8 +374,8 @@ const char* mm3dgs_last_error(void);
    201: Mm3dgsLossConfig grew by the three splatam fields | 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
    203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations are void
    204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / MM3DGS_FWD_KEEP_TILE_ORDER
-   205: Mm3dgsHeader.overflow_seen (appended) | 206: Mm3dgsPoseAdam.best (appended) */
-#define MM3DGS_ABI_VERSION 206
+   205: Mm3dgsHeader.overflow_seen (appended) | 206: Mm3dgsPoseAdam.best (appended) | 207: Mm3dgsHeader.mean_wave_steps (appended) */
+#define MM3DGS_ABI_VERSION 207
 int mm3dgs_version(void);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ class Mm3dgsHeader(C.Structure):
     _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("max_tile_len", C.c_uint32),
                 ("max_num_rendered", C.c_uint32), ("fwd_wave_iters", C.c_uint32), ("bwd_wave_iters", C.c_uint32),
                 ("bwd_wave_visits", C.c_uint32), ("bin_cap", C.c_uint32), ("max_group_records", C.c_uint32), ("tile_order_tiles", C.c_uint32),
-                ("overflow_seen", C.c_uint32)]
+                ("overflow_seen", C.c_uint32), ("mean_wave_steps", C.c_uint32)]
 
 
 class Mm3dgsSlamInputs(C.Structure):

@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   __syncthreads();
   // the slots of this XCD beyond its span: no tile
   for (int i = per + tid; i < slam_span_slots(T); i += 256) iv.tile_order[(size_t)i * 8 + x] = 0u;
-  if (x == 0 && tid == 0) iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
+  if (x == 0 && tid == 0) {
+    iv.hdr->tile_order_tiles = key;      // (the image size, not T: the table's offset in image_state depends on H * W)
+    iv.hdr->mean_wave_steps = T > 0 ? (pre[T] - (uint32_t)T) / (4u * (uint32_t)T) : 0u;      // (loads carry + 1 per tile; four waves per tile)
+  }
   if (j >= per) return;
   int rank = 0;                                        // descending load, ties by index: a permutation of [0, per)
   for (int k = 0; k < per; k++) {

@@ -85,6 +85,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   uint32_t id_nxt = CH + q < count ? list[CH + q].x : 0u;
   int cur = 0;
 
+  wave_prio_by_steps(maxcount, iv.hdr->mean_wave_steps);
   for (uint32_t base = 0; base < maxcount; base += CH, cur ^= 1) {
     // issue the gathers for the following chunks before touching this one; they land while it is composited
     const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + CH + q < count);
@@ -131,6 +132,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
     if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
     id_nxt = id_nn;
   }
+  wave_prio_reset();
   if (cam.stats && lane == 0) atomicAdd(&iv.hdr->fwd_wave_iters, n_iter);
   float fin[C];
 #pragma unroll
@@ -676,8 +678,10 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     ent_nxt = ent_nn;
   }
   };
+  wave_prio_by_steps(maxtodo, iv.hdr->mean_wave_steps);
   if (z45_wave) run_chunks(std::true_type{});
   else run_chunks(std::false_type{});
+  wave_prio_reset();
   if (cam.stats && lane == 0) {
     atomicAdd(&iv.hdr->bwd_wave_visits, n_visit);
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);

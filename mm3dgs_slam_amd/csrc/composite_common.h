@@ -71,6 +71,22 @@ __device__ __forceinline__ float splat_power(float dx, float dy, float ca, float
   return fmaf(-0.5f, fmaf(ca * dx, dx, cc * dy * dy), -cb * dx * dy);
 }
 
+// Issue priority of a compositing wave by the length of its walk (round 5).  The five waves of a SIMD share its vector pipe round-robin, so a wave with an
+// unusually long list ends up running ALONE after its neighbours have left -- at half the pipe's rate: a lone wave cannot issue back to back
+// (tools/ubench/valu_rate.hip: 2.7 ns per instruction with one wave per SIMD, 1.35 with four).  With a higher priority it runs at its own pace from the start
+// and the short waves fill the slots it leaves.  The reference length is the mean walk of the render the workgroup -> tile table was built from
+// (Mm3dgsHeader.mean_wave_steps, written by tile_order_kernel; 0 = unknown: no priorities -- the generic entry points).  A scheduling hint only: results are
+// unaffected.  Thresholds 1.125 / 1.375 / 1.75 x the mean, measured against 1.06 / 1.25 / 1.5, 1.25 / 1.5 / 2 and 1.5 / 2 / 3 and against absolute step
+// counts (profiles/r05_ab_wave_priority.txt): fused tracking kernel 67.2 -> 64.2 us, mapping backward 57.9 -> 56.8, sort + forward 32.7 -> 31.5; the hand-held
+// sweep, whose newly seeded side carries tile lists of twice the mean, 24.6 -> 25.9 frames/s.
+__device__ __forceinline__ void wave_prio_by_steps(uint32_t steps, uint32_t mean_steps) {
+  if (mean_steps == 0u) return;
+  if (16u * steps >= 28u * mean_steps) __builtin_amdgcn_s_setprio(3);
+  else if (16u * steps >= 22u * mean_steps) __builtin_amdgcn_s_setprio(2);
+  else if (16u * steps >= 18u * mean_steps) __builtin_amdgcn_s_setprio(1);
+}
+__device__ __forceinline__ void wave_prio_reset() { __builtin_amdgcn_s_setprio(0); }
+
 struct SplatRec { float4 A, B, C; };  // A: px py conA conB | B: conC opacity c0 c1 | C: c2..c5
 
 template <int C>
