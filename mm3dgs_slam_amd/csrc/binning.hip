@@ -358,9 +358,32 @@ __global__ void __launch_bounds__(256) tile_order_kernel(ImageView iv, int T, ui
   const int i = r * 32 + c;                            // index of the workgroup inside the XCD: blockIdx = 8 i + x
   iv.tile_order[(size_t)i * 8 + x] = (uint32_t)(lo_t + j) + 1u;
 }
+// Grids of several rounds of workgroups (configs[3]: 1200x680 = 3225 tiles = 2.5 rounds at five workgroups per CU; up to 11264 tiles): which CU slot a
+// workgroup lands on is decided by the dispatcher as slots free up, so there is nothing to deal, and the arithmetic map stays (round 5 measured the one order a
+// table could still impose -- every XCD's span by descending load, longest-processing-time-first -- at 795 k Gaussians: 7.98 frames/s against 8.08, the
+// compositors 1.5 % slower: neighbouring tiles share splats, and the order that balances the tail scatters them over time; profiles/r05_c4_lpt_order.txt).
+// What this kernel leaves is the mean list walk the compositing waves' priorities refer to.
+__global__ void __launch_bounds__(256) mean_wave_steps_kernel(ImageView iv, int T) {
+  __shared__ uint32_t wsum[4];
+  const int tid = threadIdx.x;
+  uint32_t sum = 0;
+  for (int t = tid; t < T; t += 256) {
+    const uint4* sc = (const uint4*)(iv.subcount + (size_t)t * NLIST);
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint4 q = sc[w]; sum += max(max(q.x, q.y), max(q.z, q.w)); }
+  }
+  sum = wave_scan_incl(sum);
+  if ((tid & 63) == 63) wsum[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) iv.hdr->mean_wave_steps = T > 0 ? (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (4u * (uint32_t)T) : 0u;
+}
 bool launch_tile_order(int T, int H, int W, ImageView iv, hipStream_t s) {
   const int per = (T + 7) >> 3;
-  if (T < 64 || per > ORDER_MAX_PER || tile_order_key(H, W) == 0u) return false;     // (tiny grids: nothing to balance; big ones: several rounds of placement)
+  if (T < 64 || tile_order_key(H, W) == 0u) return false;     // (tiny grids: nothing to balance)
+  if (per > ORDER_MAX_PER) {                                   // (several rounds of dynamic placement: no table, only the priorities' reference)
+    hipLaunchKernelGGL(mean_wave_steps_kernel, dim3(1), dim3(256), 0, s, iv, T);
+    return false;
+  }
   hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(256), 0, s, iv, T, tile_order_key(H, W));
   return true;
 }
