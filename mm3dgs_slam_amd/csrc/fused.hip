@@ -377,6 +377,8 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   const uint32_t incl = wave_scan_incl((uint32_t)max(c.area - OWN, 0));
   const uint32_t S = PROBE(cam, 6) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // (probe builds, bit 6: without the shared list)
   if (S) {   // wave-uniform
+    // (a raised issue priority for these waves -- the launch's tail on a grown map -- changes nothing: 36.0 / 19.0 us either way on the hand-held sweep,
+    //  round 5; the per-Gaussian kernels run 2.4 waves per SIMD and wait on memory, not on issue slots)
     __shared__ uint32_t s_pref[FB / 64][64];
     __shared__ PairCtx s_ctx[FB / 64][64];
     s_pref[wvi][lane] = incl;
