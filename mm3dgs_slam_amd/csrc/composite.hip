@@ -681,7 +681,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   wave_prio_by_steps(maxtodo, iv.hdr->mean_wave_steps);
   if (z45_wave) run_chunks(std::true_type{});
   else run_chunks(std::false_type{});
-  wave_prio_reset();
+  wave_prio_reset();      // (the combine at top priority instead: no gain, 56.8 -> 57.0 us)
   if (cam.stats && lane == 0) {
     atomicAdd(&iv.hdr->bwd_wave_visits, n_visit);
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);
