@@ -683,6 +683,7 @@ class FusedMapper(Mapper):
                 break
             self.loop_reruns = getattr(self, "loop_reruns", 0) + 1
             g.restore(snap)
+            self._moments_stale = False      # (the snapshot was taken with whole replicas: sharded optimiser steps of the failed attempt are gone with it)
             _random.setstate(rng_state)
             stack = None
             view_cache.clear(); ba_state.clear()       # (pose buffers and their Adam state start over)
