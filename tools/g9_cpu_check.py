@@ -1,7 +1,8 @@
 """How far does a SECOND float32 program drift from the G9 reference trajectories?  This repository's torch-graph Tracker / Mapper with the
 same CPU oracle rasterizer the fixtures were generated with (tests/test_golden_slam.py's setup) -- the reference's arithmetic up to the
 order of a few sums -- printed per frame like tools/g9_native_check.py prints the HIP loops.  The numbers are the noise floor the bars of
-tests/test_gpu_golden_slam.py are read against.     python tools/g9_cpu_check.py [--large] [variant ...]"""
+tests/test_gpu_golden_slam.py are read against.     python tools/g9_cpu_check.py [--large | --shipped] [--threads N] [variant ...]
+(--shipped: the g9D set, ~2750 iterations per variant: more than an hour; --threads: another OpenMP team size = other summation orders)"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,12 +13,17 @@ from tests.test_golden_slam import _Frames
 prefix = "g9"
 if "--large" in sys.argv:
     sys.argv.remove("--large"); prefix = "g9L"
+if "--shipped" in sys.argv:
+    sys.argv.remove("--shipped"); prefix = "g9D"
+if "--threads" in sys.argv:
+    i = sys.argv.index("--threads"); torch.set_num_threads(int(sys.argv[i + 1])); del sys.argv[i:i + 2]
 from mm3dgs_slam_amd.config import default_config
 from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor as M
 from mm3dgs_slam_amd.slam import SLAM
 for variant in (sys.argv[1:] or ["vigs"]):
     F = g9_util.load_frames(prefix); G = g9_util.load_variant(prefix, variant)
-    overrides = eval(str(G["overrides"]), {"__builtins__": {}})
+    import ast
+    overrides = ast.literal_eval(str(G["overrides"]))
     cfg = default_config(device="cpu", height=F["H"], width=F["W"], **overrides)
     n = G["est_poses"].shape[0]
     seq = _Frames(F["color"][:n], F["depth"][:n], F["gt_poses"][:n], F["imu"][:n], F["tstamps"][:n])
