@@ -85,7 +85,8 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   uint32_t id_nxt = CH + q < count ? list[CH + q].x : 0u;
   int cur = 0;
 
-  wave_prio_by_steps(maxcount, iv.hdr->mean_wave_steps);
+  const uint32_t mean_steps = iv.hdr->mean_wave_steps;
+  wave_prio_by_steps(maxcount, mean_steps);
   for (uint32_t base = 0; base < maxcount; base += CH, cur ^= 1) {
     // issue the gathers for the following chunks before touching this one; they land while it is composited
     const SplatRec rec_n = load_rec<C>(g.splat, id_nxt, base + CH + q < count);
@@ -571,6 +572,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   // traversal:  step >= first_step  with the per-lane constant below -- one compare against a scalar instead of a subtraction and a compare per
   // step.  (todo >= last_contributor unless the list was clamped to `count`; then first_step = 0: every listed splat counts.)
   const uint32_t first_step = todo - min(todo, last_contributor);
+  const uint32_t mean_steps_b = iv.hdr->mean_wave_steps;
   auto run_chunks = [&](auto z45_tag) {
   constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {
@@ -678,7 +680,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     ent_nxt = ent_nn;
   }
   };
-  wave_prio_by_steps(maxtodo, iv.hdr->mean_wave_steps);
+  wave_prio_by_steps(maxtodo, mean_steps_b);
   if (z45_wave) run_chunks(std::true_type{});
   else run_chunks(std::false_type{});
   wave_prio_reset();      // (the combine at top priority instead: no gain, 56.8 -> 57.0 us)

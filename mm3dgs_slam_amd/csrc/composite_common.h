@@ -86,6 +86,8 @@ __device__ __forceinline__ void wave_prio_by_steps(uint32_t steps, uint32_t mean
   else if (16u * steps >= 18u * mean_steps) __builtin_amdgcn_s_setprio(1);
 }
 __device__ __forceinline__ void wave_prio_reset() { __builtin_amdgcn_s_setprio(0); }
+// (Re-deciding the priority every chunk from what is LEFT of the walk against what is left of a mean walk -- longest-remaining-first -- measured no better:
+// sort + forward 31.9 against 31.5 us, the other two unchanged, the hand-held sweep the same; round 5.)
 
 struct SplatRec { float4 A, B, C; };  // A: px py conA conB | B: conC opacity c0 c1 | C: c2..c5
 
