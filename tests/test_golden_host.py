@@ -260,3 +260,28 @@ def test_g11_depth_alignment_matches_the_reference_least_squares():
         ref = torch.from_numpy(F[f"c{k}_scaled"])
         ok = mask & torch.isfinite(ref) & (ref.abs() < 50)
         assert ((scaled - ref).abs()[ok] <= 1e-3 * ref.abs()[ok] + 1e-4).all(), k
+
+
+def test_depth_alignment_ignores_masked_out_garbage_and_survives_a_singular_fit():
+    """a NaN / inf of the monocular estimate at a pixel OUTSIDE the mask must not reach the normal equations (the reference gathers
+    the valid pixels only, utils/depth_utils.py:44-96), and a system without a solution (no valid pixel; a constant estimate) yields the identity
+    fit instead of NaN that would flow into seeding and the Pearson target."""
+    from mm3dgs_slam_amd.depth_utils import get_scale_shift_LS
+    g = torch.Generator().manual_seed(3)
+    depth = 1.0 + 3.0 * torch.rand(24, 32, generator=g)
+    est = 0.7 / depth + 0.05                      # scale 0.7... of the INVERSE depth: est = a / z + b  <=>  1 / z = (est - b) / a
+    mask = torch.rand(24, 32, generator=g) > 0.3
+    clean = get_scale_shift_LS(est, depth, mask)
+    dirty_est = est.clone()
+    dirty_est[~mask] = float("nan")
+    dirty_est[0, 0] = float("inf") if not bool(mask[0, 0]) else dirty_est[0, 0]
+    dirty = get_scale_shift_LS(dirty_est, depth, mask)
+    assert torch.isfinite(dirty[0]).all() and torch.isfinite(dirty[1]).all()
+    assert torch.allclose(clean[0], dirty[0]) and torch.allclose(clean[1], dirty[1])
+    assert torch.allclose(clean[0] * est + clean[1], 1.0 / depth, atol=1e-4)          # and the fit is the right one
+    # no valid pixel / a constant estimate: scale 1, shift 0, flagged
+    for e, m in ((est, torch.zeros_like(mask)), (torch.full_like(est, 0.25), mask)):
+        s, t = get_scale_shift_LS(e, depth, m)
+        assert float(s) == 1.0 and float(t) == 0.0 and not bool(get_scale_shift_LS.fit_ok)
+    get_scale_shift_LS(est, depth, mask)
+    assert bool(get_scale_shift_LS.fit_ok)
