@@ -108,8 +108,11 @@ VARIANTS = {
 
 if SHIPPED:
     VARIANTS = {
-        # configs/TUM.yml as shipped (default_config's values ARE that file's hot-path settings): nothing overridden
+        # configs/TUM.yml's hot-path settings (default_config's values ARE that file's) with sensor depth: nothing overridden
         "vigs": dict(),
+        # configs/TUM.yml to the letter: `use_gt_depth: false` (:8) -- the tracker gets the monocular estimate (unused: tracking.use_depth_estimate_loss
+        # is false, :38), the mapper seeds from and regresses (Pearson, :54-55) on its rescaled version
+        "tum": dict(use_gt_depth=False),
         # configs/UTMM.yml's hot-path settings on the shipped schedule: IMU pose prediction, Pearson term in tracking, isotropic Gaussians,
         # 0.002 pose learning rates, size_threshold 200 (configs/UTMM.yml:31-77)
         "imu": dict(pipeline={"force_isotropic": True},

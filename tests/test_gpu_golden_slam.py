@@ -193,7 +193,7 @@ G9D_MEASURED = {      # variant -> [(camera-matrix difference, largest moment di
 }
 
 
-@pytest.mark.parametrize("variant", ["vigs", "imu"])
+@pytest.mark.parametrize("variant", ["vigs", "imu", "tum"])
 def test_native_hip_loops_reproduce_the_reference_classes_at_the_shipped_schedule(variant):
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
     from tests import g9_util

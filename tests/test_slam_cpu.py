@@ -533,7 +533,7 @@ def test_native_tracking_loop_host_side_keeps_the_best_candidate(monkeypatch):
     from oracle.raster_ref import RefRasterizer
     from tests import cpu_engine
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
-    cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 12, "position_lr": 0.01, "rotation_lr": 0.01}, mapping={"iters": 3, "kf_every": 1})
+    cfg = default_config(device="cpu", height=32, width=48, tracking={"iters": 12, "position_lr": 0.05, "rotation_lr": 0.03}, mapping={"iters": 3, "kf_every": 1})      # (steps larger than the offset: the loss goes up and down)
     seq = SyntheticSequence(cfg, 2, 500, seed=5, renderer=Renderer(cfg, rasterizer_cls=RefRasterizer))
     slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer, render_mode="reference", native_loops=False)
     slam.step(0)
@@ -551,6 +551,6 @@ def test_native_tracking_loop_host_side_keeps_the_best_candidate(monkeypatch):
         outs[name] = torch.cat([q.detach(), T.detach()])
     assert any(c[0] == "track" for e in registry.values() for c in e.calls)
     # (the same iteration wins in both programs; the two render the bundle in different pass structures, and Adam at these learning rates
-    #  carries their last-bit differences to ~1e-5 over 12 steps -- another iteration would be off by a whole step, 1e-2)
-    assert torch.allclose(outs["graph"], outs["native"], rtol=0, atol=1e-4), (outs["graph"], outs["native"])
+    #  carries their last-bit differences forward over 12 steps -- another iteration would be off by a whole step, 3e-2 .. 5e-2)
+    assert torch.allclose(outs["graph"], outs["native"], rtol=0, atol=2e-3), (outs["graph"], outs["native"])
     assert (outs["graph"] - outs["graph_last"]).abs().max() > 1e-3
