@@ -585,6 +585,12 @@ def main():
                         r_["traffic_kind"] = "L2-miss (fabric) bytes: HBM + Infinity-Cache hits"
                         r_["fabric_GBps"] = r_["traffic"] / (r_["avg_launch_us"] * 1e-6) / 1e9
                         r_["traffic_over_algorithmic"] = r_["traffic"] / r_["algorithmic_bytes_per_launch"]
+            if r_["kernel"].startswith("sort_composite_fwd"):
+                # the contract's forward figure prices a 6-pass global radix sort (24 N r + 8 N) this design never runs -- the tile bins
+                # are sorted in LDS.  The same fraction on the bytes that exist (the contract's figure minus that term), next to the contract's:
+                moved = r_["algorithmic_bytes_per_launch"] - (24 * N * r_passes + 8 * N)
+                r_["bytes_without_the_contracts_radix_sort"] = moved
+                r_["frac_without_the_contracts_radix_sort"] = moved / (r_["avg_launch_us"] * 1e-6) / 1e9 / 8000.0
             if r_["kernel"].startswith("composite_bwd_kernel<6,1>"):
                 # SURVEY.md 8d's secondary ceiling: per-(pixel, Gaussian) evaluations E = 256 * N before any early-out, ~25 flop + 1 exp
                 # each, against the dense f32 VALU peak -- the ceiling this kernel actually runs into (profiles/r01_sq_counters.md)
