@@ -70,6 +70,16 @@ def last_header():
                 bwd_wave_iters=int(h[5]), bwd_wave_visits=int(h[6]))
 
 
+def last_depths():
+    """View depths [P] (float32) the most recent forward sorted its tile lists by (geom_state: csrc/mm3dgs_common.h geom_view); the entries
+    of culled Gaussians (radii == 0) are unwritten.  Diagnostics / tests."""
+    geom, P = _last.get("geom"), _last.get("P", 0)
+    if geom is None:
+        return None
+    off = (P * 48 + 255) // 256 * 256
+    return geom[off:off + 4 * P].view(torch.float32)
+
+
 def set_binning_policy(mode: str = "exact", headroom: float = 2.0):
     if mode not in ("exact", "async"):
         raise ValueError("mode must be 'exact' or 'async'")
@@ -193,7 +203,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record()
                 _pending.append((ev, hdr, n_cap, (key, max(P, 1))))
-        _last["img"] = img
+        _last["img"], _last["geom"], _last["P"] = img, geom, P
         ctx.rs = rs
         ctx.dims = (P, M, Cn, n_cap)
         ctx.save_for_backward(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj, cpos,

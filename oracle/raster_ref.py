@@ -209,6 +209,52 @@ def bin_ref(pre):
     return rep[order], ranges
 
 
+def _composite_tile(pre, ids, tx, ty, bg):
+    """One 16x16 tile: front-to-back compositing of the depth-ordered splats `ids` over `bg`.  Returns the tile's colours
+    [C,16,16], its final transmittance [16,16] and, per pixel, the list position of the last contributor + 1 [16,16]."""
+    dt = pre["xy"].dtype
+    C = pre["colors"].shape[1]
+    lx = torch.arange(TILE, dtype=dt)
+    pxs = (tx * TILE + lx)[None, :].expand(TILE, TILE).reshape(-1)
+    pys = (ty * TILE + lx)[:, None].expand(TILE, TILE).reshape(-1)
+    xy = pre["xy"][ids]
+    con = pre["conic"][ids]
+    op = pre["opacity"][ids]
+    dx = xy[None, :, 0] - pxs[:, None]
+    dy = xy[None, :, 1] - pys[:, None]
+    power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
+    G = torch.exp(torch.clamp(power, max=0.0))
+    araw = op[None, :] * G
+    alpha = araw + (torch.clamp(araw, max=0.99) - araw).detach()      # straight-through 0.99 clamp
+    valid = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
+    a = torch.where(valid, alpha, torch.zeros_like(alpha))
+    Tincl = torch.cumprod(1.0 - a, dim=1)
+    Text = torch.cat([torch.ones(a.shape[0], 1, dtype=dt), Tincl], 1)      # T before j, and after the last
+    done_here = valid & (Tincl.detach() < 1e-4)
+    done_cum = torch.cumsum(done_here.to(torch.int32), 1) > 0
+    active = valid & ~done_cum
+    wgt = torch.where(active, a * Text[:, :-1], torch.zeros_like(a))
+    col = wgt @ pre["colors"][ids]
+    L = a.shape[1]
+    any_done = done_cum[:, -1]
+    first_done = torch.argmax(done_cum.to(torch.int32), 1)
+    stop = torch.where(any_done, first_done, torch.full_like(first_done, L))
+    Tfin = torch.gather(Text, 1, stop[:, None])[:, 0]
+    out = col + Tfin[:, None] * bg[None, :]
+    pos = torch.arange(1, L + 1, dtype=torch.int32)[None, :]
+    last = torch.max(torch.where(active, pos, torch.zeros_like(pos)), 1).values
+    return out.t().reshape(C, TILE, TILE), Tfin.detach().reshape(TILE, TILE), last.reshape(TILE, TILE)
+
+
+def _background(pre, s: RefSettings):
+    dt = pre["xy"].dtype
+    C = pre["colors"].shape[1]
+    bg = s.bg.to(dt).reshape(-1)
+    if bg.numel() < C:                       # extra channels (fused depth bundle) get a zero background
+        bg = torch.cat([bg, torch.zeros(C - bg.numel(), dtype=dt)])
+    return bg
+
+
 def composite_ref(pre, point_list, ranges, s: RefSettings):
     """Front-to-back alpha compositing, one 16x16 tile at a time.  Returns image [C,H,W], final_T [H,W],
     n_contrib [H,W] (position in the tile list of the last contributor + 1)."""
@@ -216,13 +262,10 @@ def composite_ref(pre, point_list, ranges, s: RefSettings):
     H, W = int(s.image_height), int(s.image_width)
     gx, gy = pre["grid"]
     C = pre["colors"].shape[1]
-    bg = s.bg.to(dt).reshape(-1)
-    if bg.numel() < C:                       # extra channels (fused depth bundle) get a zero background
-        bg = torch.cat([bg, torch.zeros(C - bg.numel(), dtype=dt)])
+    bg = _background(pre, s)
     rows = []
     finalT = torch.ones(gy * TILE, gx * TILE, dtype=dt)
     ncontrib = torch.zeros(gy * TILE, gx * TILE, dtype=torch.int32)
-    lx = torch.arange(TILE, dtype=dt)
     for ty in range(gy):
         row = []
         for tx in range(gx):
@@ -231,53 +274,126 @@ def composite_ref(pre, point_list, ranges, s: RefSettings):
             if hi == lo:
                 row.append((bg[:, None, None]).expand(C, TILE, TILE))
                 continue
-            ids = point_list[lo:hi]
-            pxs = (tx * TILE + lx)[None, :].expand(TILE, TILE).reshape(-1)
-            pys = (ty * TILE + lx)[:, None].expand(TILE, TILE).reshape(-1)
-            xy = pre["xy"][ids]
-            con = pre["conic"][ids]
-            op = pre["opacity"][ids]
-            dx = xy[None, :, 0] - pxs[:, None]
-            dy = xy[None, :, 1] - pys[:, None]
-            power = -0.5 * (con[None, :, 0] * dx * dx + con[None, :, 2] * dy * dy) - con[None, :, 1] * dx * dy
-            G = torch.exp(torch.clamp(power, max=0.0))
-            araw = op[None, :] * G
-            alpha = araw + (torch.clamp(araw, max=0.99) - araw).detach()      # straight-through 0.99 clamp
-            valid = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
-            a = torch.where(valid, alpha, torch.zeros_like(alpha))
-            Tincl = torch.cumprod(1.0 - a, dim=1)
-            Text = torch.cat([torch.ones(a.shape[0], 1, dtype=dt), Tincl], 1)      # T before j, and after the last
-            done_here = valid & (Tincl.detach() < 1e-4)
-            done_cum = torch.cumsum(done_here.to(torch.int32), 1) > 0
-            active = valid & ~done_cum
-            wgt = torch.where(active, a * Text[:, :-1], torch.zeros_like(a))
-            col = wgt @ pre["colors"][ids]
-            L = a.shape[1]
-            any_done = done_cum[:, -1]
-            first_done = torch.argmax(done_cum.to(torch.int32), 1)
-            stop = torch.where(any_done, first_done, torch.full_like(first_done, L))
-            Tfin = torch.gather(Text, 1, stop[:, None])[:, 0]
-            out = col + Tfin[:, None] * bg[None, :]
-            row.append(out.t().reshape(C, TILE, TILE))
-            pos = torch.arange(1, L + 1, dtype=torch.int32)[None, :]
-            last = torch.max(torch.where(active, pos, torch.zeros_like(pos)), 1).values
-            finalT[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = Tfin.detach().reshape(TILE, TILE)
-            ncontrib[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = last.reshape(TILE, TILE)
+            out, Tfin, last = _composite_tile(pre, point_list[lo:hi], tx, ty, bg)
+            row.append(out)
+            finalT[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = Tfin
+            ncontrib[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = last
         rows.append(torch.cat(row, 2))
     img = torch.cat(rows, 1)[:, :H, :W]
     return img.contiguous(), finalT[:H, :W].contiguous(), ncontrib[:H, :W].contiguous()
 
 
+def _take(t, idx):
+    return None if t is None else t[idx]
+
+
+def tile_rects_ref(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, s: RefSettings, chunk=1 << 18):
+    """Integer decisions of the projection stage for ALL Gaussians, without autograd and in chunks (3 M Gaussians with 16 SH
+    coefficients in float64 fit comfortably): radii [P] int32, tile rectangle (minx, miny, maxx, maxy) [P] int64 each, view depth
+    [P], and the number of (tile, splat) pairs of every tile [gy, gx] (a 2-D difference array over the rectangles)."""
+    P = means3D.shape[0]
+    radii, rect, depth = [], [[], [], [], []], []
+    with torch.no_grad():
+        for a in range(0, max(P, 1), chunk):
+            sl = slice(a, min(a + chunk, P))
+            pre = preprocess_ref(means3D[sl], None, opacities[sl], _take(shs, sl), _take(colors_precomp, sl), _take(scales, sl),
+                                 _take(rotations, sl), _take(cov3D_precomp, sl), s)
+            radii.append(pre["radii"]); depth.append(pre["depth"])
+            live = pre["tiles"] > 0
+            for k in range(4):       # (a culled Gaussian has the empty rectangle)
+                rect[k].append(torch.where(live, pre["rect"][k], torch.zeros_like(pre["rect"][k])))
+            grid = pre["grid"]
+    radii, depth = torch.cat(radii), torch.cat(depth)
+    rminx, rminy, rmaxx, rmaxy = (torch.cat(r) for r in rect)
+    gx, gy = grid
+    diff = torch.zeros((gy + 1) * (gx + 1), dtype=torch.int64)
+    for (yy, xx, sign) in ((rminy, rminx, 1), (rminy, rmaxx, -1), (rmaxy, rminx, -1), (rmaxy, rmaxx, 1)):
+        diff.index_add_(0, yy * (gx + 1) + xx, torch.full_like(yy, sign))
+    counts = diff.reshape(gy + 1, gx + 1).cumsum(0).cumsum(1)[:gy, :gx]
+    return radii, (rminx, rminy, rmaxx, rmaxy), depth, counts
+
+
+def rasterize_tiles_ref(means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, s: RefSettings, tiles,
+                        depth_key=None):
+    """The rasterizer restricted to the 16x16 tiles `tiles` (tile ids ty * gx + tx), for inputs too large for the whole-image oracle
+    (the BASELINE configurations: 640x480 / 150 k ... 1920x1080 / 3 M Gaussians).  The projection stage's integer decisions are taken
+    for ALL Gaussians (tile_rects_ref: radii are complete); the differentiable projection, the (tile, depth, id) order and the
+    compositing run for the chosen tiles only, over exactly the splats whose tile rectangle holds them -- per tile the same
+    arithmetic as rasterize_ref (every step of the rule is per Gaussian or per tile; both go through preprocess_ref /
+    _composite_tile).  Returns (image [C,H,W] with zeros outside the chosen tiles, radii [P], aux); gradients flow to the full
+    input tensors through the index selection, so a loss over the chosen tiles' pixels yields the same gradients as the whole-image
+    oracle would for a gradient image that is zero elsewhere.
+
+    depth_key ([P], optional): the values the (depth, id) order is taken from instead of this evaluation's own view depths.  A map
+    seeded from a surface packs the hundreds of splats of a tile into centimetres of depth; neighbours in the order are then closer
+    than float32 resolves, and ANY float32 rasterizer -- the CUDA lineage's as much as the one under test -- breaks those near-ties
+    by its own last-bit rounding.  The full-size tests hand in the float32 depths the implementation under test sorted by (after
+    checking them against this evaluation's float64 depths, to float32 rounding), so that what is compared is the arithmetic under the
+    same integer decision -- "no gradient through integer decisions" holds for the order either way."""
+    H, W = int(s.image_height), int(s.image_width)
+    radii, (rminx, rminy, rmaxx, rmaxy), depth, counts = tile_rects_ref(means3D, opacities, shs, colors_precomp, scales, rotations,
+                                                                         cov3D_precomp, s)
+    gy, gx = counts.shape
+    if callable(tiles):      # chosen from the pair counts (tests pick the heaviest tile, ...)
+        tiles = tiles(counts)
+    tiles = [int(t) for t in tiles]
+    touch = torch.zeros(means3D.shape[0], dtype=torch.bool)
+    for t in tiles:
+        tx, ty = t % gx, t // gx
+        touch |= (rminx <= tx) & (tx < rmaxx) & (rminy <= ty) & (ty < rmaxy)
+    sel = torch.nonzero(touch).flatten()            # ascending: the subset keeps the Gaussian-index order (ties of the depth sort)
+    pre = preprocess_ref(means3D[sel], _take(means2D, sel), opacities[sel], _take(shs, sel), _take(colors_precomp, sel), _take(scales, sel),
+                         _take(rotations, sel), _take(cov3D_precomp, sel), s)
+    assert torch.equal(pre["radii"], radii[sel])
+    C = pre["colors"].shape[1]
+    bg = _background(pre, s)
+    img = torch.zeros(C, gy * TILE, gx * TILE, dtype=means3D.dtype)
+    finalT = torch.ones(gy * TILE, gx * TILE, dtype=means3D.dtype)
+    ncontrib = torch.zeros(gy * TILE, gx * TILE, dtype=torch.int32)
+    lists = {}
+    prx0, pry0, prx1, pry1 = pre["rect"]
+    for t in tiles:
+        tx, ty = t % gx, t // gx
+        ysl, xsl = slice(ty * TILE, (ty + 1) * TILE), slice(tx * TILE, (tx + 1) * TILE)
+        inside = torch.nonzero((pre["tiles"] > 0) & (prx0 <= tx) & (tx < prx1) & (pry0 <= ty) & (ty < pry1)).flatten()
+        if inside.numel() == 0:
+            img[:, ysl, xsl] = bg[:, None, None].expand(C, TILE, TILE)
+            lists[t] = sel[inside]
+            continue
+        key = pre["depth"] if depth_key is None else depth_key[sel]
+        ids = inside[torch.sort(key[inside], stable=True).indices]      # depth, ties keep Gaussian-index order
+        assert int(counts[ty, tx]) == ids.numel()
+        out, Tfin, last = _composite_tile(pre, ids, tx, ty, bg)
+        img[:, ysl, xsl] = out
+        finalT[ysl, xsl] = Tfin
+        ncontrib[ysl, xsl] = last
+        lists[t] = sel[ids]
+    mask = torch.zeros(gy * TILE, gx * TILE, dtype=torch.bool)
+    for t in tiles:
+        tx, ty = t % gx, t // gx
+        mask[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = True
+    aux = dict(tiles=tiles, tile_mask=mask[:H, :W].contiguous(), tile_counts=counts, touched=sel, lists=lists, depth=depth,
+               final_T=finalT[:H, :W].contiguous(), n_contrib=ncontrib[:H, :W].contiguous(), num_rendered=int(counts.sum()))
+    return img[:, :H, :W].contiguous(), radii, aux
+
+
 def rasterize_ref(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                  cov3D_precomp=None, settings: Optional[RefSettings] = None, return_aux: bool = False):
+                  cov3D_precomp=None, settings: Optional[RefSettings] = None, return_aux: bool = False, tiles=None, depth_key=None):
     """Oracle counterpart of ``GaussianRasterizer.forward`` as called at ``slam/renderer.py:196-214``.
 
     Extension used by the fused path: when *both* ``shs`` and ``colors_precomp`` are given, channels are
-    ``[rgb(SH) | colors_precomp]`` and extra channels get a zero background."""
+    ``[rgb(SH) | colors_precomp]`` and extra channels get a zero background.
+
+    ``tiles``: a list of tile ids (ty * ceil(W / 16) + tx), or a callable that picks them from the [gy, gx] pair counts -- composite only those tiles (rasterize_tiles_ref: the sizes of
+    BASELINE.json's configurations); pixels outside them are returned as zeros."""
     if shs is None and colors_precomp is None:
         raise ValueError("Please provide excatly one of either SHs or precomputed colors!")
     if (scales is None or rotations is None) == (cov3D_precomp is None):
         raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    if tiles is not None:
+        img, radii, aux = rasterize_tiles_ref(means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                                              settings, tiles, depth_key=depth_key)
+        return (img, radii, aux) if return_aux else (img, radii)
     pre = preprocess_ref(means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
                          settings)
     plist, ranges = bin_ref(pre)
@@ -292,9 +408,11 @@ class RefRasterizer(torch.nn.Module):
     """Drop-in shaped like ``diff_gaussian_rasterization.GaussianRasterizer`` but running the CPU oracle.
     Injected explicitly by tests / the cpu_baseline leg; never selected automatically."""
 
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, tiles=None, depth_key=None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.depth_key = depth_key      # rasterize_tiles_ref: the values the depth order is taken from
+        self.tiles = tiles      # None: the whole image; a list of tile ids (or a callable on the pair counts): rasterize_tiles_ref
 
     def markVisible(self, positions):
         V = self.raster_settings.viewmatrix.to(positions.dtype)
@@ -309,7 +427,8 @@ class RefRasterizer(torch.nn.Module):
         s = RefSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), rs.bg,
                         float(rs.scale_modifier), rs.viewmatrix, rs.projmatrix, int(rs.sh_degree), rs.campos,
                         bool(rs.prefiltered), bool(rs.debug))
-        return rasterize_ref(means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, s)
+        return rasterize_ref(means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, s, tiles=self.tiles,
+                             depth_key=self.depth_key)
 
 
 def dense_render_ref(means3D, opacities, colors, scales, rotations, s: RefSettings):

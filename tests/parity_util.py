@@ -69,7 +69,9 @@ def leaves(case, dtype, device):
     return out
 
 
-def run_oracle(case, dtype=torch.float64, weights=None, need_grad=True):
+def run_oracle(case, dtype=torch.float64, weights=None, need_grad=True, tiles=None, depth_key=None):
+    """tiles: a list of tile ids -- the tile-sampled oracle (oracle.raster_ref.rasterize_tiles_ref): the image is zero outside them,
+    and so must `weights` be for the gradients to mean anything (tile_weights)."""
     L = leaves(case, dtype, "cpu")
     s = RefSettings(case["H"], case["W"], case["tanx"], case["tany"], case["bg"].to(dtype), case["scale_modifier"],
                     L["view"], L["proj"], case["sh_degree"], L["campos"])
@@ -77,7 +79,7 @@ def run_oracle(case, dtype=torch.float64, weights=None, need_grad=True):
     if L["extras"] is not None:
         cp = L["extras"] if cp is None else torch.cat([cp, L["extras"]], 1)
     img, radii, aux = rasterize_ref(L["means3D"], L["means2D"], L["opacities"], L["shs"], cp, L["scales"], L["rotations"],
-                                    L["cov3D"], s, return_aux=True)
+                                    L["cov3D"], s, return_aux=True, tiles=tiles, depth_key=depth_key)
     grads = {}
     if need_grad:
         if weights is None:
@@ -85,6 +87,61 @@ def run_oracle(case, dtype=torch.float64, weights=None, need_grad=True):
         (img * weights.to(dtype)).sum().backward()
         grads = {k: (v.grad if v is not None else None) for k, v in L.items()}
     return img.detach(), radii, aux, grads
+
+
+def tile_mask(H, W, tiles):
+    """[H,W] bool: the pixels of the 16x16 tiles `tiles` (ids ty * ceil(W / 16) + tx)."""
+    gx = (W + 15) // 16
+    m = torch.zeros(H, W, dtype=torch.bool)
+    for t in tiles:
+        tx, ty = int(t) % gx, int(t) // gx
+        m[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    return m
+
+
+CLEAN_PIXEL_TOL = 4e-6     # largest |difference| / (1 + |value|) over the pixels of a tile whose float32 decisions (1/255, T < 1e-4) all agree with float64
+                           # (float32 accumulation: ~1e-6); ONE differing 1/255 decision moves its pixel by alpha c T ~ 2e-3 T
+FLIP_TILE_TOL = 2e-2       # image rel-L2 of a tile that does carry such a decision
+
+
+def tile_errors(img_a, img_b, tiles):
+    """Per 16x16 tile of `tiles`: (rel-L2 of img_a against img_b ([C,H,W]), max over its pixels of |a - b| / (1 + |b|))."""
+    H, W = img_b.shape[-2:]
+    gx = (W + 15) // 16
+    out = {}
+    for t in tiles:
+        tx, ty = int(t) % gx, int(t) // gx
+        ys, xs = slice(ty * 16, (ty + 1) * 16), slice(tx * 16, (tx + 1) * 16)
+        a, b = img_a[:, ys, xs].double(), img_b[:, ys, xs].double()
+        out[int(t)] = (rel_l2(a, b), float(((a - b).abs() / (1.0 + b.abs())).max()) if a.numel() else 0.0)
+    return out
+
+
+def clean_tiles(errs):
+    return [t for t, (_, px) in errs.items() if px <= CLEAN_PIXEL_TOL]
+
+
+def pick_tiles(counts, n=32, seed=0):
+    """Tile sample for the full-size parity tests: the heaviest tile (longest list), the lightest non-empty one, the four image
+    corners (the bottom / right ones are partial tiles when H or W is not a multiple of 16) and seeded random ones, `n` in all.
+    counts: [gy, gx] pairs per tile (oracle.raster_ref.tile_rects_ref)."""
+    gy, gx = counts.shape
+    flat = counts.reshape(-1)
+    chosen = [int(flat.argmax())]
+    nz = torch.nonzero(flat > 0).flatten()
+    if nz.numel():
+        chosen.append(int(nz[flat[nz].argmin()]))
+    chosen += [0, gx - 1, (gy - 1) * gx, gy * gx - 1]
+    g = torch.Generator().manual_seed(seed)
+    for t in torch.randperm(gy * gx, generator=g).tolist():
+        if len(set(chosen)) >= n:
+            break
+        chosen.append(int(t))
+    out = []
+    for t in chosen:
+        if t not in out:
+            out.append(t)
+    return out[:n]
 
 
 def loss_weights(shape, seed):

@@ -208,21 +208,27 @@ def _setup_slam_like(P, H, W, iso, seed):
     return cfg, g, Renderer(cfg), pose, color.to(DEV), depth.to(DEV)
 
 
-def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, slam_like=False, iso=False, world=False):
+def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, slam_like=False, iso=False, world=False, setup=None, n_tiles=0, raw=False):
     """rel-L2 errors of the native SLAM path (pose transform, activations, depth bundle, compositors, chain rules: one fused forward +
     backward) against the float64 CPU oracle driven through the torch-graph Renderer.  direct: second render of the engine (direct bins)
     instead of its first (packed bins).  floor: also the errors of the ORACLE evaluated in float32 against itself in float64 on the same
     scene (what float32 arithmetic costs there, whatever the implementation), as "f32:" keys.  Gradient image: white noise on a stress
     scene (strongly anisotropic splats, random opacities), or -- slam_like -- the gradient of the mapping loss (0.8 L1 + 0.2 (1 - SSIM) on the
     colours + 0.05 (1 - Pearson) on the depth channel, slam/mapper.py:856-873) against the frame the map was seeded from, evaluated at the
-    float64 oracle's image and handed to both sides."""
+    float64 oracle's image and handed to both sides.
+    setup: a prepared (cfg, model, Renderer, pose, colour target, depth target) instead of the seeded scenes.  n_tiles > 0: the
+    TILE-SAMPLED oracle (oracle.raster_ref.rasterize_tiles_ref: the projection's integer decisions for every Gaussian, the
+    differentiable projection / depth order / compositing for n_tiles tiles -- the heaviest, the lightest, the image corners, seeded
+    random ones) for maps of BASELINE.json's sizes; the gradient image is then zero outside those tiles on both sides, derived
+    (slam_like) from the HIP image, and "img" compares the sampled tiles' pixels."""
     import copy
+    import functools
     import mm3dgs_slam_amd.pose_utils as P_
     import mm3dgs_slam_amd.renderer as rmod
     from mm3dgs_slam_amd.fused import FusedEngine
     from mm3dgs_slam_amd.renderer import Renderer
     from oracle.raster_ref import RefRasterizer
-    cfg, g, R, pose, color, depth = _setup_slam_like(P, H, W, iso, seed) if slam_like else _setup(P=P, H=H, W=W, seed=seed)
+    cfg, g, R, pose, color, depth = setup if setup is not None else (_setup_slam_like(P, H, W, iso, seed) if slam_like else _setup(P=P, H=H, W=W, seed=seed))
     if world:      # pipeline.transform_means_python: false (slam/renderer.py:117-124): world-frame means under the full view matrix
         cfg["pipeline"]["transform_means_python"] = False
         assert R.cfg["pipeline"]["transform_means_python"] is False
@@ -234,19 +240,40 @@ def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, sl
         si = eng.forward(pose, g, need_grads=True)
         assert eng.direct
     keys = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
+    depth_key = None
+    if n_tiles:      # the float32 view depths the kernels sorted by (geom_state: csrc/mm3dgs_common.h geom_view) -> the oracle's depth ORDER
+        off = (eng.P * 48 + 255) // 256 * 256
+        depth_key = eng.geom[off:off + 4 * eng.P].view(torch.float32).clone().cpu()
     ccfg = copy.deepcopy(cfg)
     ccfg["device"] = "cpu"
     W6 = {}      # the gradient image: drawn (stress scenes) or derived from the float64 oracle's image (SLAM-like scenes), then shared
+    sample = {}  # tile-sampled oracle: the tiles, chosen at the oracle's first pass from its own pair counts
+
+    def choose_tiles(counts):      # (called with the pair counts at every oracle pass; the choice is made once)
+        if "tiles" not in sample:
+            sample["tiles"] = pu.pick_tiles(counts, n_tiles, seed)
+            sample["mask"] = pu.tile_mask(eng.H, eng.W, sample["tiles"])
+            sample["max_list"] = int(counts.max())
+        return sample["tiles"]
 
     def gradient_image(ref64):
+        if n_tiles:      # (the oracle's image is zero outside its tiles: the loss is evaluated at the HIP image -- a weight image both sides share)
+            # gradients only on the tiles whose float32 decisions (depth order of surface splats a float32 ulp apart, 1/255, T < 1e-4) agree with
+            # float64: tests/test_gpu_fullsize.py says why
+            sample["errs"] = pu.tile_errors(eng.out.detach().cpu(), ref64.detach(), sample["tiles"])
+            sample["clean"] = pu.clean_tiles(sample["errs"])
+            sample["mask"] = pu.tile_mask(eng.H, eng.W, sample["clean"])
+            ref64 = eng.out.detach().double().cpu()
         if not slam_like:
-            return torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).double().cpu()
+            w = torch.randn(6, eng.H, eng.W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).double().cpu()
+            return w * sample["mask"] if n_tiles else w
         from mm3dgs_slam_amd.loss_utils import l1_loss, pearson_loss, ssim
         x = ref64.detach().clone().requires_grad_(True)
         gt, gd = color.double().cpu(), depth.double().cpu()
         loss = 0.8 * l1_loss(x[:3], gt) + 0.2 * (1.0 - ssim(x[:3], gt)) + 0.05 * pearson_loss(x[3], gd, mask=gd > 0, invert_estimate=False)
         loss.backward()
-        return x.grad.float().double()          # float32-representable: both sides see the same numbers
+        w = x.grad.float().double()          # float32-representable: both sides see the same numbers
+        return w * sample["mask"] if n_tiles else w
 
     def oracle(dt):
         class PC:
@@ -257,7 +284,7 @@ def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, sl
         pc._xyz, pc._scaling, pc._rotation = leaf["_xyz"], leaf["_scaling"], leaf["_rotation"]
         pc.get_xyz, pc.get_opacity, pc.get_scaling = leaf["_xyz"], torch.sigmoid(leaf["_opacity"]), torch.exp(leaf["_scaling"])
         pc.get_rotation, pc.get_features = torch.nn.functional.normalize(leaf["_rotation"]), leaf["_features_dc"]
-        Rc = Renderer(ccfg, rasterizer_cls=RefRasterizer)
+        Rc = Renderer(ccfg, rasterizer_cls=functools.partial(RefRasterizer, tiles=choose_tiles, depth_key=depth_key) if n_tiles else RefRasterizer)
         Rc.projection_matrix, Rc.background, Rc._eye = Rc.projection_matrix.to(dt), Rc.background.to(dt), Rc._eye.to(dt)
         orig = rmod.get_camera_from_tensor
 
@@ -281,12 +308,27 @@ def native_vs_oracle(seed=0, direct=False, P=3000, H=120, W=160, floor=False, sl
     eng.backward(si, grads=eng.grads, dpose=eng.dpose)
     assert eng.check_capacity()
     names = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation"))
-    m = {"img": pu.rel_l2(eng.out, ref), "d_pose": pu.rel_l2(eng.dpose, dp)}
+    sel = pu.tile_mask(eng.H, eng.W, sample["tiles"]) if n_tiles else slice(None)
+    m = {"img": pu.rel_l2(eng.out.cpu()[:, sel], ref[:, sel]), "d_pose": pu.rel_l2(eng.dpose, dp)}
+    if n_tiles:
+        m["tiles"], m["max_list"], m["tile_errors"] = list(sample["tiles"]), sample["max_list"], sample["errs"]
+        m["clean_tiles"], m["img_worst_tile"] = len(sample["clean"]), max(e for e, _ in sample["errs"].values())
+        m["img_clean_tiles_max"] = max([sample["errs"][t][0] for t in sample["clean"]], default=0.0)
+        # the sort depths against the float64 view depth z = (R(q / |q|) x + t)_z (float32 rounding of a three-term sum)
+        q64 = pose.detach().double().cpu()
+        z64 = g._xyz.detach().double().cpu() @ P_.quad2rotation(q64[None, :4])[0][2] + q64[6]
+        vis = (eng.radii > 0).cpu()
+        m["depth_key_rel_err"] = float(((depth_key[vis].double() - z64[vis]).abs() / z64[vis].abs()).max())
     for name, key in names:
         m["d_" + name] = pu.rel_l2(eng.grads[name], lg[key])
+    if raw:      # (diagnostics: the gradient arrays themselves)
+        m["raw"] = {"hip": {name: eng.grads[name].detach().cpu().clone() for name, _ in names}, "oracle": {name: lg[key] for name, key in names},
+                    "lists": None, "radii": eng.radii.cpu().clone()}
     if floor:
         ref32, dp32, lg32 = oracle(torch.float32)
-        m["f32:img"], m["f32:d_pose"] = pu.rel_l2(ref32, ref), pu.rel_l2(dp32, dp)
+        if raw:
+            m["raw"]["f32"] = {name: lg32[key] for name, key in names}
+        m["f32:img"], m["f32:d_pose"] = pu.rel_l2(ref32[:, sel], ref[:, sel]), pu.rel_l2(dp32, dp)
         for name, key in names:
             m["f32:d_" + name] = pu.rel_l2(lg32[key], lg[key])
     return m

@@ -19,6 +19,39 @@ def test_tiled_composite_equals_explicit_pixel_loop():
     assert (img - ref).abs().max() < 1e-12
 
 
+def test_tile_sampled_oracle_equals_the_whole_image_oracle_on_its_tiles():
+    """rasterize_ref(..., tiles=[...]) -- what the full-size parity tests run (tests/test_gpu_fullsize.py) -- is the whole-image oracle
+    restricted to those tiles: same pixels bit for bit, same radii, and for a gradient image that is zero outside the tiles the same
+    gradients of every input (SH colours, a posed camera with view / projection / campos gradients, extra channels)."""
+    from oracle.raster_ref import tile_rects_ref
+    case = pu.make_case(P=900, H=70, W=100, seed=11, sh_degree=2, posed=True, extras=3)      # 7 x 5 tiles, the last row / column partial
+    img_full, radii_full, aux_full, _ = pu.run_oracle(case, need_grad=False)
+    s = _settings(case)
+    cp = case["extras"]
+    radii, rect, depth, counts = tile_rects_ref(case["means3D"], case["opacities"], case["shs"], cp, case["scales"], case["rotations"], None, s)
+    assert torch.equal(radii, radii_full) and int(counts.sum()) == aux_full["num_rendered"]
+    rg = aux_full["ranges"]
+    assert torch.equal(counts.reshape(-1), rg[1:] - rg[:-1])
+    tiles = pu.pick_tiles(counts, n=9, seed=1)
+    assert len(tiles) == 9 and int(counts.reshape(-1).argmax()) in tiles and 34 in tiles
+    m = pu.tile_mask(case["H"], case["W"], tiles)
+    w = pu.loss_weights(img_full.shape, 7) * m
+    img_t, radii_t, aux_t, g_t = pu.run_oracle(case, weights=w, tiles=tiles)
+    _, _, _, g_f = pu.run_oracle(case, weights=w)
+    assert torch.equal(radii_t, radii_full)
+    assert torch.equal(img_t[:, m], img_full[:, m]) and float(img_t[:, ~m].abs().max()) == 0.0
+    assert torch.equal(aux_t["n_contrib"][m], aux_full["n_contrib"][m]) and torch.equal(aux_t["final_T"][m], aux_full["final_T"][m])
+    for t in tiles:
+        assert torch.equal(aux_t["lists"][t], aux_full["point_list"][int(rg[t]):int(rg[t + 1])])
+    for k, gf in g_f.items():
+        if gf is None:
+            continue
+        assert g_t[k] is not None, k
+        # (the per-Gaussian sums run over the same terms in the same order; the camera gradients sum over another set of Gaussians)
+        assert pu.rel_l2(g_t[k], gf) < 1e-12, (k, pu.rel_l2(g_t[k], gf))
+    assert float(g_f["means3D"].abs().max()) > 0
+
+
 def test_autograd_matches_finite_differences():
     # sparse scene: no pixel saturates, so the T<1e-4 stop (a genuine discontinuity) is not crossed by the probe
     case = pu.make_case(P=40, H=32, W=32, seed=4, posed=True, log_scale=-2.8)
