@@ -258,7 +258,7 @@ static void slam_refresh_tile_order(const Mm3dgsCamera* cam, void* image_state, 
 
 static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in, float* out_color, int32_t* radii,
                              void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int flags, void* stream,
-                             const TrackLoss* tl, float* track_dsub = nullptr, bool projected = false) {
+                             const TrackLoss* tl, float* track_dsub = nullptr, bool projected = false, bool pose_chain = false) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
   if (!out_color || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL buffer");
@@ -283,17 +283,17 @@ static int slam_forward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
   cd.trec_cap = db.on ? db.trec_cap : 0u;
   if (db.on) {
     // projected: the previous mapping iteration's backward launch already projected and binned this view (slam_bwd_project_kernel)
-    if (!projected) { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s); }
+    if (!projected) { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_project_bin(cd, P, slam_in(in), radii, g, iv, b, db.bin_cap, db.rec_cap, db.slot_bits, s, pose_chain); }
     { ProfScope ps(track_dsub ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
-      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap, db.slot_bits);
+      if (track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, 1, s, *tl, db.nblocks, track_dsub, db.bin_cap, db.slot_bits, pose_chain);
       else launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, 1, s, tl, db.nblocks, db.bin_cap, db.slot_bits); }
     return check_launch("slam_forward");
   }
-  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s); }
+  { ProfScope ps(MM3DGS_PROF_PREPROCESS_FWD, s); launch_slam_preprocess_fwd(cd, P, slam_in(in), radii, g, iv, s, nullptr, false, pose_chain); }
   if (!cd.fused_scan) { ProfScope ps(MM3DGS_PROF_SCAN, s); launch_scan_tiles(cd.gx * cd.gy, P, g, iv, s, (flags & MM3DGS_FWD_STATE_CLEAN) ? 1 : 0); }
   { ProfScope ps(MM3DGS_PROF_BIN_SORT, s); launch_scatter_sort(cd, P, g, iv, b, N_capacity, nullptr, s, fused_sort); }
   { ProfScope ps((fused_sort && track_dsub) ? MM3DGS_PROF_TRACK_FWD_BWD : MM3DGS_PROF_COMPOSITE_FWD, s);
-    if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, (cd.fused_scan || cd.state_clean) ? 1 : 0, s, *tl, 0, track_dsub);
+    if (fused_sort && track_dsub) launch_sort_composite_fwd_bwd_track(cd, g, iv, b, N_capacity, out_color, (cd.fused_scan || cd.state_clean) ? 1 : 0, s, *tl, 0, track_dsub, 0, DIRECT_SLOT_BITS_MAX, pose_chain);
     else if (fused_sort) launch_sort_composite_fwd6(cd, g, iv, b, N_capacity, out_color, (cd.fused_scan || cd.state_clean) ? 1 : 0, s, tl);
     else launch_composite_fwd(cd, 6, g, iv, b, N_capacity, out_color, s); }
   return check_launch("slam_forward");
@@ -338,7 +338,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
                               const float* dL_dout, void* backward_scratch, const Mm3dgsSlamGrads* grads, float* dL_dpose,
                               const Mm3dgsPoseAdam* pose_adam, const Mm3dgsMapAdam* map_adam, int flags, void* stream, const TrackLoss* tl,
                               float* prior_loss4 = nullptr, int dl_planes = 6, bool compositor_done = false, const float* fuse_next_pose = nullptr,
-                              bool* fused_out = nullptr) {
+                              bool* fused_out = nullptr, bool pose_chain = false) {
   PoseLossScale pls = {nullptr, 0, 0.f, nullptr};
   if (tl && tl->defer_scale) { pls.rows = tl->partial; pls.nrows = ((tl->cfg.W + 15) / 16) * ((tl->cfg.H + 15) / 16); pls.w_l1 = tl->cfg.w_l1; pls.loss4 = tl->loss4; }
   int rc = check_slam(cam, P, in);
@@ -379,9 +379,17 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     if (int rc2 = map_adam_dev(map_adam, ma)) return rc2;
   const bool tracking = sg.d_xyz == nullptr && !ma.on;
   if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
+  if (pose_chain && !tracking) return fail(-1, "internal: the pose chain is a tracking-mode path");
   if (!compositor_done)
   { ProfScope ps(tracking ? MM3DGS_PROF_COMPOSITE_BWD_TRACK : MM3DGS_PROF_COMPOSITE_BWD, s);
-    launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes); }
+    launch_composite_bwd_slam(cd, tracking, g, iv, b, N_capacity, dL_dout, bw.dsub, s, tl, dl_planes, pose_chain); }
+  if (pose_chain) {
+    // the tracking compositor applied the pose chain per (block, splat) and left one pose-gradient row per TILE at the head of the scratch: no
+    // gradient records, no backward projection -- the pose finish sums the rows (GeomView.poserec, composite.hip)
+    ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s);
+    launch_slam_pose_finish(bw.dsub, cd.gx * cd.gy, in->pose, dL_dpose, pa, s, pls.rows ? &pls : nullptr, prior_loss4, &iv.hdr->overflow);
+    return check_launch("slam_backward");
+  }
   // mapping run, direct bins, in-kernel Adam, no pose step: this launch also projects and bins the NEXT iteration's view
   const bool fuse = fuse_next_pose && !tracking && ma.on && db_bwd.on && !dL_dpose && !pa.pose && !sg.d_xyz;
   if (fused_out) *fused_out = fuse;
@@ -469,9 +477,15 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   if (fuse_track) {
     track_dsub = bwd_view(backward_scratch, P, N_capacity).dsub;
   }
+  // round 6: the pose chain -- the projection writes every splat's { Kp, Kq, x }, the tracking compositor applies it per (block, splat) and leaves one
+  // pose row per tile: no gradient records, no per-tile combine, no backward-projection launch (three launches per iteration).  The shipped mode only
+  // (means pre-transformed: the world-frame mode's pose gradient also runs through the covariance rotation); MM3DGS_NO_POSE_CHAIN keeps the record path
+  // (read per call: tests compare both in one process)
+  const bool pose_chain = composite_has_pose_chain() && !in->world_means && backward_scratch && !env_flag("MM3DGS_NO_POSE_CHAIN", 0) &&
+                          bwd_bytes_impl(P, N_capacity) >= (size_t)tiles_x(cam->image_width) * tiles_y(cam->image_height) * 32 * sizeof(float);
   if (n_iter > 0) slam_refresh_tile_order(cam, image_state, fwd_flags, stream);
   for (int it = 0; it < n_iter; it++) {
-    int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr, track_dsub);
+    int rc = slam_forward_impl(cam, P, in, out_color, radii, geom_state, image_state, binning_state, N_capacity, fwd_flags, stream, fold ? &tl : nullptr, track_dsub, false, pose_chain);
     if (rc) return rc;
     if (fold) {
       if (!tl.defer_scale) {
@@ -483,7 +497,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
       if (rc) return rc;
     }
     rc = slam_backward_impl(cam, P, in, radii, geom_state, image_state, binning_state, N_capacity, dL_dout, backward_scratch, &none,
-                            nullptr, pose_adam, nullptr, fwd_flags, stream, fold ? &tl : nullptr, loss4, 6, fuse_track);
+                            nullptr, pose_adam, nullptr, fwd_flags, stream, fold ? &tl : nullptr, loss4, 6, fuse_track, nullptr, nullptr, pose_chain);
     if (rc) return rc;
   }
   return 0;

@@ -440,10 +440,46 @@ struct SepReduce2 {
 // MODE 2: SLAM tracking: [M0 Mx Mxx cz | My Mxy Myy] at a 32-byte stride: opacity / colour gradients are never consumed.
 // (a device function: the tracking loop runs it in the same launch as the sort and the forward compositor, see below)
 #define BWD_STG_BYTES (sizeof(float4) * 2 * 4 * 3 * STG_N + sizeof(uint32_t) * 2 * 4 * 64)   // staged splat records + record indices: 26 KB
-template <int C, int MODE>
+
+// ---- round 6: the SLAM modes' backward in TWO PHASES per sub-chunk of list entries ---------------------------------------------------------------
+// The one-phase loop (kept as the generic mode's, and under -DMM3DGS_BWD_ONE_PHASE as the SLAM modes' A/B baseline) reduces the ten / seven record
+// values over the 16 lanes of a row after EVERY (row, splat) step: 18 / 12 DPP adds, the products that feed them and a 10-lane scatter store -- 33 of
+// the step's 64 vector instructions (profiles/r05_isa_budget.txt), although per (pixel, splat) only TWO numbers are new: u = dL/dG G and w = alpha T.
+// Here phase 1 (lane = pixel, as before) writes (u, w) of SUB consecutive steps to a wave-private LDS tile, and phase 2 turns the tile around:
+// lane = (list entry, part of the 4x4 block), 16 / SUB lanes per entry, each walking its SUB pixels with the entry's centre in registers and the pixels'
+// dL from a wave-private LDS table -- plain fmas into ten accumulators, one DPP add per value and part to merge them, and the record leaves as two wide
+// stores from the lanes that hold it.  Deterministic (fixed order: x inside a pixel row, rows ascending, parts ascending).  The summation order differs
+// from the one-phase reduction's in the last bits.
+#ifdef MM3DGS_BWD_ONE_PHASE
+#define BWD_TWO_PHASE 0
+#else
+#define BWD_TWO_PHASE 1
+#endif
+// (developer timing probes of the two-phase loop, variant builds only -- results INVALID: -DMM3DGS_BWD2_PROBE=<bits>  1: no phase 2 | 2: phase 2 without its
+//  record stores | 4: phase 1 without the (u, w) tile writes | 8: phase 2 on constants instead of its tile / table reads)
+#ifndef MM3DGS_BWD2_PROBE
+#define MM3DGS_BWD2_PROBE 0
+#endif
+#define TP_STRIDE 65      // float2 per step row of the (u, w) tile: 64 lanes + 1 (the SUB lanes of a phase-2 group read SUB different rows at one column: the odd stride spreads them over the banks)
+template <int MODE>
+struct Bwd2Lds {      // wave-private slice of the workgroup's LDS block (bytes)
+  static constexpr int OFF_A = 0;                                  // float4[STG_N]: px py conA conB          (single buffer: the next chunk is parked after the last read of this one)
+  static constexpr int OFF_B = OFF_A + STG_N * 16;                 // float4[STG_N]: conC opacity c0 c1
+  static constexpr int OFF_CZ = OFF_B + STG_N * 16;                // float2[STG_N]: c2 z                      (z^2 = z * z is recomputed: one rounded product, as the projection stored it)
+  static constexpr int OFF_TP = OFF_CZ + STG_N * 8;                // float2[8][TP_STRIDE]: (u, w) of a sub-chunk
+  static constexpr int OFF_T5 = OFF_TP + 4 * TP_STRIDE * 8;        // float[64]: dL5 per pixel -- the general instance runs SUB = 4 and keeps its fifth table in the tile's unused half
+  static constexpr int OFF_T = OFF_TP + 8 * TP_STRIDE * 8;         // mapping: float4[64] (dL0 dL1 dL2 dL3) per pixel; tracking: float[64] (dL3)
+  static constexpr int SLICE = OFF_T + (MODE == 1 ? 64 * 16 : 64 * 4);
+};
+#define BWD2_BYTES(MODE) (4 * Bwd2Lds<MODE>::SLICE)      // mapping 31616 B, tracking 28544 B: five workgroups per CU (160 KB in 1280-byte granules: at most 32000)
+// POSE (tracking, two-phase loop only): the pose chain of fused.hip's pose_chain_record -- phase 2 applies the splat's { Kp, Kq, x } (GeomView.poserec) to
+// the block's moments and adds dm (x) [x; 1] to per-lane accumulators; at the end the workgroup writes ONE row of twelve floats, dsub[tile][32], for the
+// pose finish.  No gradient record is written, none zeroed, no per-tile combine, and no backward-projection launch follows.
+template <int C, int MODE, bool POSE = false>
 __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, const GeomView& g, const ImageView& iv, const BinView& b,
                                                    uint32_t N_cap, const float* __restrict__ dL_dout, float* __restrict__ dsub, int has_tl,
                                                    const TrackLoss& tl, int dl_planes, unsigned char* smem_raw, const SortShared* span = nullptr) {
+  static_assert(!POSE || (MODE == 2 && BWD_TWO_PHASE), "the pose chain lives in the tracking mode's two-phase loop");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // wave = 8x8 sub-tile wv of the tile; 16-lane row = 4x4 block `row` of the sub-tile, walking its own list
   const int row = lane >> 4, q = lane & 15;
@@ -536,9 +572,191 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   float behind_dot = 0.f;  // (colour accumulated behind the current list position) . dL
 
   // entries behind `todo` receive no gradient: their records are zero
+  if constexpr (!POSE)
   for (uint32_t e = todo + q; e < count; e += 16) {
     zero_record<NV>(dsub + (size_t)list[e].y * RECF);
   }
+  float pacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // POSE: this lane's share of the tile's pose row (lanes 0-7 of a row: dR rows 0, 1; lanes 8-15: dR row 2, dt)
+  if constexpr (MODE != 0 && BWD_TWO_PHASE) {
+  if (maxtodo != 0) {   // wave-uniform (a wave without work still takes part in the workgroup's per-tile combine below)
+    using LY = Bwd2Lds<MODE>;
+    unsigned char* const wbase = smem_raw + (size_t)wv * LY::SLICE;
+    float4* const sA = (float4*)(wbase + LY::OFF_A);
+    float4* const sB = (float4*)(wbase + LY::OFF_B);
+    float2* const sCZ = (float2*)(wbase + LY::OFF_CZ);
+    float2* const tp = (float2*)(wbase + LY::OFF_TP);
+    float* const t5 = (float*)(wbase + LY::OFF_T5);
+    // the pixels' dL for phase 2 (wave-private: a wave only ever reads its own four blocks)
+    if constexpr (MODE == 1) ((float4*)(wbase + LY::OFF_T))[lane] = make_float4(dL[0], dL[1], dL[2], dL[3]);
+    else ((float*)(wbase + LY::OFF_T))[lane] = dL[3];
+    const bool z45_wave = __ballot(dL[4] != 0.f || dL[5] != 0.f || Tf_bg != 0.f) == 0ull;      // see the one-phase loop below
+    if (!z45_wave) t5[lane] = dL[5];
+    const uint32_t first_step = todo - min(todo, last_contributor);
+    const uint32_t mean_steps_b = iv.hdr->mean_wave_steps;
+    const float X0 = pxf - (float)(q & 3), Y0 = pyf - (float)(q >> 2);      // pixel centre of the block's corner (exact)
+    uint32_t n_visit = 0;
+    // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front); lane q parks entry q and keeps
+    // its gradient-record index in a register
+    uint32_t my_idx;
+    {
+      const uint2 e0 = (uint32_t)q < todo ? list[todo - 1u - q] : make_uint2(0u, 0u);
+      const SplatRec r0 = load_rec<C>(g.splat, e0.x, (uint32_t)q < todo);
+      sA[slane] = r0.A; sB[slane] = r0.B; sCZ[slane] = make_float2(r0.C.x, r0.C.y);
+      my_idx = POSE ? e0.x : e0.y;      // (pose chain: the entry's Gaussian, whose { Kp, Kq, x } phase 2 gathers)
+    }
+    uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
+    auto run2 = [&](auto z45_tag) {
+      constexpr bool Z45 = decltype(z45_tag)::value;
+      constexpr int SUB = Z45 ? 8 : 4;           // entries per phase-2 pass
+      constexpr int NL = 16 / SUB;               // lanes per entry = parts of the 4x4 block; each walks SUB pixels = SUB / 4 pixel rows
+      const int e = q & (SUB - 1), part = q / SUB;
+      const int r17 = row * STG_ROW;
+      for (uint32_t base = 0; base < maxtodo; base += CH) {
+        const SplatRec rec_n = load_rec<C>(g.splat, ent_nxt.x, base + CH + q < todo);
+        const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
+        for (int sub = 0; sub < cnt; sub += SUB) {
+          const int cs = min(SUB, cnt - sub);
+          // ---- phase 1: lane = pixel; one (row, splat) step = the splat's alpha, the transmittance in front of it, dL/dalpha -> (u, w)
+          float2* tpw = tp + lane;
+          auto splat_px = [&](const float4& A, const float4& B, const float2& CZ, const int j) {
+            const uint32_t step = base + (uint32_t)j;               // wave-uniform
+            const bool row_on = step < todo;                        // this row still has an entry at this step
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = splat_power(dx, dy, A.z, A.w, B.x);
+            const float G = SPLAT_EXP(power);
+            const float alpha = fminf(0.99f, B.y * G);
+            const bool valid = row_on && (step >= first_step) && !(power > 0.f) && !(alpha < ALPHA_MIN);
+            n_visit++;
+            const float a_eff = valid ? alpha : 0.f;
+            const float G_eff = valid ? G : 0.f;
+            const float r = __builtin_amdgcn_rcpf(1.f - a_eff);
+            Tr *= r;  // transmittance in front of this splat
+            const float w = a_eff * Tr;
+            // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: ONE running scalar (behind_dot), see the one-phase loop
+            float qd = fmaf(B.z, dL[0], 0.f);
+            qd = fmaf(B.w, dL[1], qd);
+            qd = fmaf(CZ.x, dL[2], qd);
+            qd = fmaf(CZ.y, dL[3], qd);
+            if constexpr (!Z45) { qd = fmaf(1.f, dL[4], qd); qd = fmaf(CZ.y * CZ.y, dL[5], qd); }
+            const float diff = qd - behind_dot;
+            behind_dot = fmaf(a_eff, diff, behind_dot);
+            const float dLa = Z45 ? diff * Tr : diff * Tr - Tf_bg * r;
+            const float u = B.y * dLa * G_eff;
+            if (!(MM3DGS_BWD2_PROBE & 4)) *tpw = make_float2(u, w);
+            tpw += TP_STRIDE;
+          };
+          {
+            float4 A0 = sA[r17 + sub], B0 = sB[r17 + sub];
+            float2 Z0 = sCZ[r17 + sub];
+            for (int j = sub; j < sub + cs; j += 2) {
+              const int j1 = j + 1 < sub + cs ? j + 1 : j;
+              const float4 A1 = sA[r17 + j1], B1 = sB[r17 + j1];
+              const float2 Z1 = sCZ[r17 + j1];
+              splat_px(A0, B0, Z0, j);
+              if (j + 1 < sub + cs) {
+                const int j2 = j + 2 < sub + cs ? j + 2 : j1;
+                A0 = sA[r17 + j2]; B0 = sB[r17 + j2]; Z0 = sCZ[r17 + j2];
+                splat_px(A1, B1, Z1, j1);
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // ---- phase 2: lane = (entry sub + e of the row's chunk, part of the block): the entry's record from the (u, w) tile
+          if (!(MM3DGS_BWD2_PROBE & 1)) {
+#pragma clang fp contract(off)
+            const int ent = sub + e;
+            const bool on2 = base + (uint32_t)ent < todo;
+            const float2 cxy = *(const float2*)&sA[r17 + ent];
+            const uint32_t idx = (uint32_t)__builtin_amdgcn_ds_bpermute((row * 16 + ent) << 2, (int)my_idx);
+            float4 k0, k1, k2, k3, k4;
+            if constexpr (POSE) {      // requested here, consumed after the moments are merged
+              const float4* pr = (const float4*)(g.poserec + (size_t)(on2 ? idx : 0u) * POSEREC_F);
+              k0 = pr[0]; k1 = pr[1]; k2 = pr[2]; k3 = pr[3]; k4 = pr[4];
+            }
+            float dxv[4], dxx[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) { dxv[x] = cxy.x - (X0 + (float)x); dxx[x] = dxv[x] * dxv[x]; }
+            float M0 = 0.f, Mx = 0.f, Mxx = 0.f, My = 0.f, Mxy = 0.f, Myy = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cz = 0.f, cz5 = 0.f;
+            const float2* tpr = tp + e * TP_STRIDE + row * 16 + part * SUB;
+            const int pcol = row * 16 + part * SUB;
+#pragma unroll
+            for (int yy = 0; yy < SUB / 4; yy++) {
+              float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int x = 0; x < 4; x++) {
+                const float2 uw = (MM3DGS_BWD2_PROBE & 8) ? make_float2(cxy.x, cxy.y) : tpr[yy * 4 + x];
+                s0 = s0 + uw.x;
+                s1 = __builtin_fmaf(uw.x, dxv[x], s1);
+                s2 = __builtin_fmaf(uw.x, dxx[x], s2);
+                if constexpr (MODE == 1) {
+                  const float4 d4 = (MM3DGS_BWD2_PROBE & 8) ? make_float4(X0, Y0, X0, Y0) : ((const float4*)(wbase + LY::OFF_T))[pcol + yy * 4 + x];
+                  c0 = __builtin_fmaf(uw.y, d4.x, c0);
+                  c1 = __builtin_fmaf(uw.y, d4.y, c1);
+                  c2 = __builtin_fmaf(uw.y, d4.z, c2);
+                  cz = __builtin_fmaf(uw.y, d4.w, cz);
+                } else {
+                  cz = __builtin_fmaf(uw.y, ((const float*)(wbase + LY::OFF_T))[pcol + yy * 4 + x], cz);
+                }
+                if constexpr (!Z45) cz5 = __builtin_fmaf(uw.y, t5[pcol + yy * 4 + x], cz5);
+              }
+              const float dyv = cxy.y - (Y0 + (float)(part * (SUB / 4) + yy));
+              M0 = M0 + s0; Mx = Mx + s1; Mxx = Mxx + s2;
+              My = __builtin_fmaf(s0, dyv, My);
+              Mxy = __builtin_fmaf(s1, dyv, Mxy);
+              Myy = __builtin_fmaf(s0 * dyv, dyv, Myy);
+            }
+            if constexpr (!Z45) cz = __builtin_fmaf(2.f * sCZ[r17 + ent].y, cz5, cz);      // d/dz of the [z, 1, z^2] bundle: sum w (dL3 + 2 z dL5)
+            // merge the parts (ascending): afterwards every lane of the entry holds the totals
+            auto merge = [&](float v) {
+              if constexpr (NL == 2) return v + dpp_all<ROW_ROR8>(v);
+              else { v = v + dpp_all<ROW_ROR4>(v); return v + dpp_all<ROW_ROR8>(v); }
+            };
+            M0 = merge(M0); Mx = merge(Mx); Mxx = merge(Mxx); My = merge(My); Mxy = merge(Mxy); Myy = merge(Myy); cz = merge(cz);
+            if constexpr (MODE == 1) { c0 = merge(c0); c1 = merge(c1); c2 = merge(c2); }
+            if constexpr (POSE) {
+              // dm = Kp (Mx, My) + Kq (Mxx, Mxy, Myy) + e_z cz;  the pose row collects dm (x) [x; 1]
+              // (selects, not products: the lanes without an entry gathered record 0, which may never have been written)
+              const float dm0 = on2 ? (k0.x * Mx + k0.y * My + k1.z * Mxx + k1.w * Mxy + k2.x * Myy) : 0.f;
+              const float dm1 = on2 ? (k0.z * Mx + k0.w * My + k2.y * Mxx + k2.z * Mxy + k2.w * Myy) : 0.f;
+              const float dm2 = on2 ? (k1.x * Mx + k1.y * My + k3.x * Mxx + k3.y * Mxy + k3.z * Myy + cz) : 0.f;
+              const float x0 = on2 ? k3.w : 0.f, x1 = on2 ? k4.x : 0.f, x2 = on2 ? k4.y : 0.f;
+              const bool owner = NL == 2 || (part & 1) == 0;          // four lanes per entry: parts 0 and 2 carry the two halves
+              const bool hi = (NL == 2 ? part : (part >> 1)) != 0;
+              const float ma = owner ? (hi ? dm2 : dm0) : 0.f, mb = owner ? (hi ? 1.f : dm1) : 0.f;
+              // lanes 0-7 of the row (hi = 0): dR row 0 = dm0 x, dR row 1 = dm1 x;   lanes 8-15 (hi = 1): dR row 2 = dm2 x, dt = dm
+              pacc[0] = __builtin_fmaf(ma, x0, pacc[0]); pacc[1] = __builtin_fmaf(ma, x1, pacc[1]); pacc[2] = __builtin_fmaf(ma, x2, pacc[2]);
+              pacc[3] = __builtin_fmaf(mb, hi ? dm0 : x0, pacc[3]); pacc[4] = __builtin_fmaf(mb, hi ? dm1 : x1, pacc[4]); pacc[5] = __builtin_fmaf(mb, hi ? dm2 : x2, pacc[5]);
+            } else
+            if (on2 && !(MM3DGS_BWD2_PROBE & 2)) {
+              float* const o = dsub + ((MM3DGS_BWD2_PROBE & 32) ? (size_t)lane : ((MM3DGS_BWD2_PROBE & 64) ? ((size_t)NLIST * start + (size_t)L * len + (size_t)(todo - 1u - (base + (uint32_t)ent))) : (size_t)idx)) * RECF;
+              if constexpr (MODE == 1) {      // [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy]
+                if (MM3DGS_BWD2_PROBE & 16) { if (part == 0) { const f4u v0 = {M0 + Mx + Mxx + c0, c1 + c2 + cz + My, Mxy, Myy}; *(f4u*)o = v0; } } else {
+                if (part == 0) { const f4u v0 = {M0, Mx, Mxx, c0}; *(f4u*)o = v0; }
+                if (part == 1) { const f4u v1 = {c1, c2, cz, My}; *(f4u*)(o + 4) = v1; }
+                if (part == (NL == 2 ? 0 : 2)) { const f2u v2 = {Mxy, Myy}; *(f2u*)(o + 8) = v2; } }
+              } else {                        // [M0 Mx Mxx cz | My Mxy Myy]
+                if (part == 0) { const f4u v0 = {M0, Mx, Mxx, cz}; *(f4u*)o = v0; }
+                if (part == 1) { const f2u v1 = {My, Mxy}; *(f2u*)(o + 4) = v1; o[6] = Myy; }
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();      // the tile is rewritten by the next sub-chunk's phase 1
+        }
+        if (base + CH >= maxtodo) break;      // (wave-uniform)
+        sA[slane] = rec_n.A; sB[slane] = rec_n.B; sCZ[slane] = make_float2(rec_n.C.x, rec_n.C.y);
+        my_idx = POSE ? ent_nxt.x : ent_nxt.y;
+        ent_nxt = ent_nn;
+      }
+    };
+    wave_prio_by_steps(maxtodo, mean_steps_b);
+    if (z45_wave) run2(std::true_type{});
+    else run2(std::false_type{});
+    wave_prio_reset();
+    if (cam.stats && lane == 0) { atomicAdd(&iv.hdr->bwd_wave_visits, n_visit); atomicAdd(&iv.hdr->bwd_wave_iters, n_visit); }
+  }
+  } else
   if (maxtodo != 0 && !PROBE(cam, 9)) {   // wave-uniform; (probe builds, bit 9: timing without the main loop) (a wave without work still takes part in the workgroup's per-tile combine below)
 
   const int my_slot = MODE == 0 ? WaveReduce<NV>::slot(q) : (SEP_REDUCE2 ? SepReduce2<MODE == 1>::slot(q) : SepReduce<MODE == 1>::slot(q));
@@ -689,7 +907,28 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     atomicAdd(&iv.hdr->bwd_wave_iters, n_red);
   }
   }   // maxtodo != 0
-  if constexpr (MODE != 0) {
+  if constexpr (POSE) {
+    // ---- the tile's pose row: lanes 0-7 of every row hold their share of components 0-5, lanes 8-15 of components 6-11 (zeros in the lanes that
+    // carried nothing); double from here on -- the terms cancel across a tile -- in a fixed order: inside the 8-lane groups, across the four rows,
+    // across the four waves
+    double dsum[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double v = (double)pacc[k];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      dsum[k] = v;
+    }
+    __syncthreads();      // every wave has left its main loop: the staging memory is free
+    double* const wtot = (double*)smem_raw;      // [4 waves][12]
+    if (lane == 0 || lane == 8) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) wtot[wv * 12 + (lane == 8 ? 6 : 0) + k] = dsum[k];
+    }
+    __syncthreads();
+    if (tid < 12) dsub[(size_t)tile * 32 + tid] = (float)((wtot[tid] + wtot[12 + tid]) + (wtot[24 + tid] + wtot[36 + tid]));
+  }
+  if constexpr (MODE != 0 && !POSE) {
     // ---- per-tile combine (SLAM modes): one record per (tile, splat) pair = the sum of the pair's block records, in ascending
     // block order (deterministic).  The backward projection then reads ONE record per pair (contiguous per Gaussian) instead of one
     // per listed 4x4 block: a quarter of the bytes on the kernel that the counters show to be bandwidth bound on exactly them
@@ -752,15 +991,16 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   }
 }
 
-template <int C, int MODE>
-__global__ void __launch_bounds__(256)
+template <int C, int MODE, bool POSE = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, const float* __restrict__ dL_dout,
                      float* __restrict__ dsub, int has_tl, TrackLoss tl, int dl_planes) {
   constexpr size_t LOSS_BYTES = MODE == 1 ? sizeof(LossGradSmem) + 4 * 256 * sizeof(float) : 0;
   // (generic mode: 32 KB on purpose -- five workgroups per CU; with the 26 KB the staging buffers need, six fit and the 1080p /
   //  3 M-Gaussian pass ran 14 % slower: every workgroup gathers ~1000 splat records by id, and six of them overflow the L1)
   constexpr size_t MIN_BYTES = MODE == 0 ? 32768 : 0;
-  constexpr size_t NEED = BWD_STG_BYTES > LOSS_BYTES ? BWD_STG_BYTES : LOSS_BYTES;
+  constexpr size_t STG_BYTES = (MODE != 0 && BWD_TWO_PHASE) ? (size_t)BWD2_BYTES(MODE == 0 ? 1 : MODE) : (size_t)BWD_STG_BYTES;
+  constexpr size_t NEED = STG_BYTES > LOSS_BYTES ? STG_BYTES : LOSS_BYTES;
   __shared__ __align__(16) unsigned char smem_raw[NEED > MIN_BYTES ? NEED : MIN_BYTES];
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
@@ -768,20 +1008,23 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   // every launch of this iteration's forward has retired: what the sticky overflow word holds NOW is what the whole backward projection that
   // follows must act on (Mm3dgsHeader.overflow_seen; its fused second half bins the next view and may raise the word itself)
   if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) iv.hdr->overflow_seen = iv.hdr->overflow;
-  composite_bwd_body<C, MODE>(tile, cam, g, iv, b, N_cap, dL_dout, dsub, has_tl, tl, dl_planes, smem_raw);
+  composite_bwd_body<C, MODE, POSE>(tile, cam, g, iv, b, N_cap, dL_dout, dsub, has_tl, tl, dl_planes, smem_raw);
 }
 
 // A tracking iteration with the masked-L1 loss alone (its 1/n is applied to the pose gradient afterwards, so the per-pixel loss
 // gradient needs nothing from other tiles): sort, forward compositing and backward compositing of a tile in ONE launch.  The
 // backward pass picks its pixel's final transmittance, contributor count and colours up from memory the same lane wrote a
 // moment ago; one launch, its ramp and the backward prologue's cold misses less per iteration.
-__global__ void __launch_bounds__(256)
+template <bool POSE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
 sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N_cap, float* __restrict__ out, int clean,
                                     TrackLoss tl, int direct_blocks, float* __restrict__ dsub, uint32_t direct_cap, int slot_bits) {
-  __shared__ __align__(16) unsigned char smem[BWD_STG_BYTES];     // >= forward staging (24 KB) >= sort keys (+ payloads)
+  constexpr size_t TRACK_BWD_BYTES = BWD_TWO_PHASE ? (size_t)BWD2_BYTES(2) : (size_t)BWD_STG_BYTES;
+  __shared__ __align__(16) unsigned char smem[TRACK_BWD_BYTES];     // >= forward staging (25.5 KB) >= sort keys + runs + payloads (24 KB)
   __shared__ SortShared sh;
   __shared__ double red[4][12];
-  static_assert(BWD_STG_BYTES >= sizeof(float4) * 2 * 4 * 3 * STG_N, "LDS union too small for the forward staging buffers");
+  static_assert(TRACK_BWD_BYTES >= sizeof(float4) * 2 * 4 * 3 * STG_N, "LDS union too small for the forward staging buffers");
+  static_assert(TRACK_BWD_BYTES >= 3 * RANK_SORT_MAX * sizeof(unsigned long long), "LDS union too small for the sort's keys, runs and payloads");
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
@@ -789,7 +1032,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   __syncthreads();
   composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, &tl, red, &sh);
   __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free
-  composite_bwd_body<6, 2>(tile, cam, g, iv, b, N_cap, nullptr, dsub, 1, tl, 6, smem, &sh);
+  composite_bwd_body<6, 2, POSE>(tile, cam, g, iv, b, N_cap, nullptr, dsub, 1, tl, 6, smem, &sh);
 }
 
 template <int C>
@@ -813,11 +1056,16 @@ static void launch_bwd_c(const CamDev& cam, GeomView g, ImageView iv, BinView b,
 // how many workgroups share a CU (occupancy sensitivity of the kernels; results are unaffected)
 static size_t slam_lds_pad() { static const int pad = env_flag("MM3DGS_SLAM_LDS_PAD", 0); return (size_t)pad; }
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes) {
+                               float* dsub, hipStream_t s, const TrackLoss* tl, int dl_planes, bool pose_chain) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = slam_grid(cam, T);
   TrackLoss none = {};
+#if BWD_TWO_PHASE
+  if (tracking && pose_chain)
+    hipLaunchKernelGGL((composite_bwd_kernel<6, 2, true>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
+  else
+#endif
   if (tracking)
     hipLaunchKernelGGL((composite_bwd_kernel<6, 2>), dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, dL, dsub, tl ? 1 : 0, tl ? *tl : none, dl_planes);
   else
@@ -834,12 +1082,19 @@ void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, Bin
 }
 
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
-                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap, int slot_bits) {
+                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap, int slot_bits, bool pose_chain) {
   uint32_t ncap = (uint32_t)(N_cap > 0xffffffffull ? 0xffffffffull : N_cap);
   int T = cam.gx * cam.gy;
   int grid = slam_grid(cam, T);
-  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel, dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
+#if BWD_TWO_PHASE
+  if (pose_chain)
+    hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel<true>, dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
+  else
+#endif
+  hipLaunchKernelGGL(sort_composite_fwd_bwd_track_kernel<false>, dim3(grid), dim3(256), slam_lds_pad(), s, cam, g, iv, b, ncap, out, clean, tl, direct_blocks, dsub, direct_cap, slot_bits);
 }
+// whether this build's tracking compositors carry the pose chain (the one-phase A/B build does not)
+bool composite_has_pose_chain() { return BWD_TWO_PHASE != 0; }
 
 void launch_composite_fwd(const CamDev& cam, int C, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out,
                           hipStream_t s) {

@@ -93,8 +93,69 @@ __device__ __forceinline__ void pose_view_matrix(const PoseDev& ps, float V[16])
   }
   V[15] = 1.f;
 }
+// The tracking compositor's pose chain (round 6).  With the map frozen and the means pre-transformed (the shipped mode), dL/d(camera-space mean) of a
+// splat is LINEAR in the moments its gradient records hold:   dm = Kp (Mx, My) + Kq (Mxx, Mxy, Myy) + e_z cz   -- Kp = the screen-position
+// chain (pixel centre <- homogeneous point <- p, times the conic: gpx = -(qa Mx + qb My), gpy = -(qc My + qb Mx)), Kq = the covariance chain
+// (conic <- 2D covariance <- J(p) S3 J(p)^T, the +-1.3 tanfov clamp included), both exactly the expressions of slam_bwd_body evaluated on unit
+// inputs.  The projection stage writes { Kp, Kq, x } per visible Gaussian; the compositor applies it per (block, splat) and sums dm (x) [x; 1]
+// straight into the tile's pose-gradient row: no gradient record leaves the compositor, no per-tile combine, no backward projection launch.
+__device__ __forceinline__ void pose_chain_record(const CamDev& cam, const float* __restrict__ PV, const float p[3], const float x[3], const Ewa& e,
+                                                  const float S3[3][3], float qa, float qb, float qc, float pw, float hx, float hy,
+                                                  float* __restrict__ rec) {
+  // covariance chain: (gA, gB, gC) = d/d(conic) -> dm, column by column (unit inputs through slam_bwd_body's expressions)
+  const float a = e.a, b = e.b, c = e.c;
+  const float det = a * c - b * b, id2 = 1.f / (det * det);
+  const float tz = e.t[2], itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  float Kq[3][3];
+#pragma unroll
+  for (int col = 0; col < 3; col++) {
+    // Kq's columns act on (Mxx, Mxy, Myy): gA = -1/2 Mxx, gB = -Mxy, gC = -1/2 Myy
+    const float gA = col == 0 ? -0.5f : 0.f, gB = col == 1 ? -1.f : 0.f, gC = col == 2 ? -0.5f : 0.f;
+    const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
+    const float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
+    const float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+    float GA[2][3], dA0[3], dA1[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      GA[0][i] = da * e.A[0][i] + 0.5f * db * e.A[1][i];
+      GA[1][i] = 0.5f * db * e.A[0][i] + dcc * e.A[1][i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      dA0[j] = 2.f * (GA[0][0] * S3[0][j] + GA[0][1] * S3[1][j] + GA[0][2] * S3[2][j]);
+      dA1[j] = 2.f * (GA[1][0] * S3[0][j] + GA[1][1] * S3[1][j] + GA[1][2] * S3[2][j]);
+    }
+    const float dJ00 = dA0[0], dJ02 = dA0[2], dJ11 = dA1[1], dJ12 = dA1[2];
+    Kq[0][col] = e.in_x ? -cam.focal_x * itz2 * dJ02 : 0.f;
+    Kq[1][col] = e.in_y ? -cam.focal_y * itz2 * dJ12 : 0.f;
+    Kq[2][col] = -cam.focal_x * itz2 * dJ00 - cam.focal_y * itz2 * dJ11 + 2.f * cam.focal_x * e.txc * itz3 * dJ02 + 2.f * cam.focal_y * e.tyc * itz3 * dJ12;
+  }
+  // screen-position chain: (gpx, gpy) -> dm, then gpx = -(qa Mx + qb My), gpy = -(qc My + qb Mx)
+  float Jp[3][2];
+  const float sx = 0.5f * cam.W, sy = 0.5f * cam.H;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    // d(px)/dp_i = sx pw (PV[i][0] - hx pw PV[i][3]),  d(py)/dp_i = sy pw (PV[i][1] - hy pw PV[i][3])
+    Jp[i][0] = PV[i * 4 + 0] * (sx * pw) - PV[i * 4 + 3] * (sx * hx * pw * pw);
+    Jp[i][1] = PV[i * 4 + 1] * (sy * pw) - PV[i * 4 + 3] * (sy * hy * pw * pw);
+  }
+  float4* o = (float4*)rec;
+  float Kp[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    Kp[i][0] = -(Jp[i][0] * qa + Jp[i][1] * qb);      // coefficient of Mx
+    Kp[i][1] = -(Jp[i][0] * qb + Jp[i][1] * qc);      // coefficient of My
+  }
+  o[0] = make_float4(Kp[0][0], Kp[0][1], Kp[1][0], Kp[1][1]);
+  o[1] = make_float4(Kp[2][0], Kp[2][1], Kq[0][0], Kq[0][1]);
+  o[2] = make_float4(Kq[0][2], Kq[1][0], Kq[1][1], Kq[1][2]);
+  o[3] = make_float4(Kq[2][0], Kq[2][1], Kq[2][2], x[0]);
+  o[4] = make_float4(x[1], x[2], 0.f, 0.f);
+}
+
 __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool live, int idx, const float* __restrict__ pose, bool isotropic,
-                                                       const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g, bool world = false) {
+                                                       const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g, bool world = false,
+                                                       bool want_poserec = false) {
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(pose);
@@ -158,6 +219,8 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         sp[2] = make_float4(fmaxf(c2, 0.f), zc, 1.f, zc * zc);
         g.depth[idx] = z;
         o.z = z;
+        if (want_poserec && !world)
+          pose_chain_record(cam, PV, p, rg.x, e, S3, e.c * dinv, -e.b * dinv, e.a * dinv, pw, hx, hy, g.poserec + (size_t)idx * POSEREC_F);
       }
     }
   }
@@ -170,7 +233,7 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
 }
 
 __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, int idx, const SlamIn& in, int32_t* __restrict__ radii,
-                                                      const GeomView& g) {
+                                                      const GeomView& g, bool want_poserec = false) {
   const bool live = idx < P;
   // every parameter of this Gaussian is requested up front (one memory latency for the kernel, not two: the map is
   // almost entirely in view in a SLAM iteration, so nothing is wasted on culled splats)
@@ -184,19 +247,19 @@ __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, 
     for (int k = 0; k < 3; k++) { rg.ls[k] = in.scaling[(size_t)idx * 3 + k]; rg.fd[k] = in.f_dc[(size_t)idx * 3 + k]; }
     rg.op = in.opacity[idx];
   }
-  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g, in.world != 0);
+  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g, in.world != 0, want_poserec);
 }
 
 __global__ void __launch_bounds__(FB)
 slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles,
-                           int vis_only, uint32_t* __restrict__ seen) {
+                           int vis_only, uint32_t* __restrict__ seen, int want_poserec) {
   extern __shared__ uint32_t hist[];
   const int T = cam.gx * cam.gy;
   for (int t = threadIdx.x; t < lds_tiles; t += FB) hist[t] = 0;
   if (lds_tiles) __syncthreads();
   const int idx = blockIdx.x * FB + threadIdx.x;
   const bool live = idx < P;
-  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
+  const Projected pr = slam_project_one(cam, P, idx, in, radii, g, want_poserec != 0);
   const uint32_t r0 = pr.r0, r1 = pr.r1, nblk = pr.nblk;
   const int32_t rad = pr.rad;
   if (vis_only) {      // mm3dgs_slam_visibility: the projection stage alone (workgroup-uniform): no tile counting, no scans
@@ -242,12 +305,12 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
 }
 
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s,
-                                uint32_t* seen, bool visibility_only) {
+                                uint32_t* seen, bool visibility_only, bool want_poserec) {
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
   const int lds_tiles = (T <= MAX_LDS_TILES && !visibility_only) ? T : 0;
   hipLaunchKernelGGL(slam_preprocess_fwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
-                     iv, lds_tiles, visibility_only ? 1 : 0, seen);
+                     iv, lds_tiles, visibility_only ? 1 : 0, seen, want_poserec ? 1 : 0);
 }
 
 // ---- projection + binning in ONE launch (direct bins) -----------------------------------------------------------------------------
@@ -402,22 +465,23 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
 
 __global__ void __launch_bounds__(FB)
 slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
-                        uint32_t rec_cap, int slot_bits) {
+                        uint32_t rec_cap, int slot_bits, int want_poserec) {
   extern __shared__ uint32_t hist[];     // [T]: pairs of this workgroup per tile, then the next slot of each touched tile
   const int T = cam.gx * cam.gy;
   const int tid = threadIdx.x;
   for (int t = tid; t < T; t += FB) hist[t] = 0;
   if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
   const int idx = blockIdx.x * FB + tid;
-  const Projected pr = slam_project_one(cam, P, idx, in, radii, g);
+  const Projected pr = slam_project_one(cam, P, idx, in, radii, g, want_poserec != 0);
   slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
 }
 
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
-                             uint32_t rec_cap, int slot_bits, hipStream_t s) {
+                             uint32_t rec_cap, int slot_bits, hipStream_t s, bool want_poserec) {
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
-  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits);
+  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits,
+                     want_poserec ? 1 : 0);
 }
 
 // Sum of a Gaussian's per-tile gradient records (composite.hip's per-tile combine: one record per (tile, splat) pair, the pairs of a
@@ -1051,6 +1115,13 @@ slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restri
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
                            const uint32_t* __restrict__ ovf) {
   slam_bwd_body<TRACK, DIRECT, WORLD>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+}
+
+// The pose finish alone, over the per-TILE rows the tracking compositor's pose chain wrote (composite.hip): rows[nrows][32] floats.
+void launch_slam_pose_finish(const float* rows, int nrows, const float* pose_in, float* dpose, const PoseAdam& ad, hipStream_t s,
+                             const PoseLossScale* pls, float* loss4, const uint32_t* ovf) {
+  const PoseLossScale none = {nullptr, 0, 0.f, nullptr};
+  hipLaunchKernelGGL(slam_pose_finish_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, pose_in, dpose, ad, pls ? *pls : none, loss4, ovf);
 }
 
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,

@@ -49,27 +49,34 @@ struct PoseLossScale { const double* rows; int nrows; float w_l1; float* loss4; 
 void launch_loss_finish(const LossCfg& cfg, double* sums, const double* partial, hipStream_t s, float* loss4 = nullptr);
 
 void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, hipStream_t s,
-                                uint32_t* seen_only = nullptr, bool visibility_only = false);
+                                uint32_t* seen_only = nullptr, bool visibility_only = false, bool want_poserec = false);
+bool composite_has_pose_chain();
+// the pose finish alone over per-tile pose rows (the tracking compositor's pose chain: composite.hip, GeomView.poserec)
+void launch_slam_pose_finish(const float* rows, int nrows, const float* pose_in, float* dpose, const PoseAdam& ad, hipStream_t s,
+                             const PoseLossScale* pls, float* loss4, const uint32_t* ovf);
 void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, const int32_t* radii, GeomView g, BinView b, size_t N_cap,
                                 BwdView bw, const SlamGrads& out, float* dpose, const PoseAdam& ad, const MapAdam& ma, hipStream_t s,
                                 const PoseLossScale* pls = nullptr, float* loss4 = nullptr, bool direct = false, const uint32_t* overflow_flag = nullptr);
 // dl_planes: 6, or 4 when the caller guarantees that the silhouette / depth^2 planes of dL are zero AND need not be read
 // (the mapping loop's loss kernel does not even write them)
+// pose_chain (tracking only): apply GeomView.poserec per (block, splat) and write the tile's pose-gradient row to dsub[tile][32] instead of
+// gradient records
 void launch_composite_bwd_slam(const CamDev& cam, bool tracking, GeomView g, ImageView iv, BinView b, size_t N_cap, const float* dL,
-                               float* dsub, hipStream_t s, const TrackLoss* tl = nullptr, int dl_planes = 6);
+                               float* dsub, hipStream_t s, const TrackLoss* tl = nullptr, int dl_planes = 6, bool pose_chain = false);
 // sort + forward compositing of the 6-channel SLAM bundle in one launch (lists <= 2048 per tile stay in LDS)
 void launch_sort_composite_fwd6(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean, hipStream_t s,
                                 const TrackLoss* tl = nullptr, int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX);
 // the same + the backward compositor of a tracking iteration (masked-L1 loss, deferred normalisation) in that launch
 void launch_sort_composite_fwd_bwd_track(const CamDev& cam, GeomView g, ImageView iv, BinView b, size_t N_cap, float* out, int clean,
-                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX);
+                                         hipStream_t s, const TrackLoss& tl, int direct_blocks, float* dsub, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX,
+                                         bool pose_chain = false);
 // backward projection + map Adam of one mapping iteration and projection + binning of the next one (its pose: next_pose) in one launch
 void launch_slam_bwd_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, size_t N_cap,
                              BwdView bw, const SlamGrads& out, const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap,
                              int slot_bits, hipStream_t s);
 // projection + binning in one launch (direct bins: every tile owns bin_cap pairs at tile * bin_cap)
 void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, uint32_t bin_cap,
-                             uint32_t rec_cap, int slot_bits, hipStream_t s);
+                             uint32_t rec_cap, int slot_bits, hipStream_t s, bool want_poserec = false);
 // the map's Adam step from gradient arrays (the multi-GPU window: all-reduced gradients) + projection + binning of the next view in one launch
 void launch_slam_adam_project(const CamDev& cam, int P, const SlamIn& in, int32_t* radii, GeomView g, ImageView iv, BinView b, const SlamGrads& gr,
                               const MapAdam& ma, const float* next_pose, uint32_t bin_cap, uint32_t rec_cap, int slot_bits, hipStream_t s);

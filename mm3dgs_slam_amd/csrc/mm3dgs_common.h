@@ -32,6 +32,7 @@
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#define POSEREC_F 20   // GeomView.poserec: Kp[3][2] | Kq[3][3] | x[3] | 2 unused = five float4
 struct GeomView {
   float* splat;       // [P][12]
   float* depth;       // [P]
@@ -41,11 +42,15 @@ struct GeomView {
   uint32_t* block_tiles;  // [ceil(P/256)+1]
   uint32_t* blkoff;   // [P]  workgroup-local exclusive scan of the 4x4 blocks in each splat's block rectangle
   uint32_t* block_blk;    // [ceil(P/256)+1]  blocks per preprocess workgroup -> exclusive prefix
+  float* poserec;         // [P][POSEREC_F] (round 6, tracking): the linear map from a splat's screen-space gradient moments to dL/d(camera-space mean)
+                          // and its world position -- written by the projection stage of mm3dgs_slam_track, applied per (block, splat) by the
+                          // tracking compositor (composite.hip), so that a tracking iteration writes no gradient records at all
 };
+
 static inline size_t geom_bytes_impl(int P) {
   size_t p = (size_t)P;
   return align_up(p * SPLAT_F * 4, 256) + align_up(p * 4, 256) + align_up(p * 8, 256) + align_up(p, 256) +
-         2 * (align_up(p * 4, 256) + align_up(((p + 255) / 256 + 1) * 4, 256));
+         2 * (align_up(p * 4, 256) + align_up(((p + 255) / 256 + 1) * 4, 256)) + align_up(p * POSEREC_F * 4, 256);
 }
 static inline GeomView geom_view(void* base, int P) {
   size_t p = (size_t)P;
@@ -58,7 +63,8 @@ static inline GeomView geom_view(void* base, int P) {
   g.tileoff = (uint32_t*)c; c += align_up(p * 4, 256);
   g.block_tiles = (uint32_t*)c; c += align_up(((p + 255) / 256 + 1) * 4, 256);
   g.blkoff = (uint32_t*)c;  c += align_up(p * 4, 256);
-  g.block_blk = (uint32_t*)c;
+  g.block_blk = (uint32_t*)c; c += align_up(((p + 255) / 256 + 1) * 4, 256);
+  g.poserec = (float*)c;
   return g;
 }
 

@@ -623,6 +623,49 @@ def test_tracking_iteration_in_one_compositor_launch_matches_the_separate_launch
     assert torch.equal(la, lb) and torch.equal(oa, ob)
 
 
+@pytest.mark.parametrize("pearson,white", [(False, False), (True, False), (False, True)])
+def test_tracking_pose_chain_matches_the_record_path(pearson, white, monkeypatch):
+    """Round 6: mm3dgs_slam_track applies the pose chain per (block, splat) inside the tracking compositor (GeomView.poserec: the projection writes
+    every splat's linear map from its gradient moments to dL/d(camera-space mean); the compositor leaves one pose row per tile) -- no gradient
+    records, no per-tile combine, no backward-projection launch.  MM3DGS_NO_POSE_CHAIN=1 keeps the record path, the one the float64 oracle
+    comparisons run on (mm3dgs_slam_backward): the pose GRADIENT of an iteration (read back as Adam's first moment after one step with the
+    learning rates at 0: m = 0.1 g) must agree to float32 rounding of two summation orders, and so must a 12-step trajectory.  Masked L1 (the
+    fused sort + forward + backward launch), + Pearson (separate compositor launches, dL3 != 0), white background (the general loop instance:
+    four lanes per entry)."""
+    from mm3dgs_slam_amd import _lib
+    from mm3dgs_slam_amd.fused import FusedEngine, _loss_cfg
+    cfg, g, R, pose0, color, depth = _setup(P=20000, H=120, W=168, seed=4, white=white)
+    with torch.no_grad():
+        r0 = R.render(g, pose0)
+        gt, ref = r0["render"].contiguous(), r0["depth"][0].contiguous()
+    out = {}
+    for no_chain in ("1", "0"):
+        monkeypatch.setenv("MM3DGS_NO_POSE_CHAIN", no_chain)
+        eng = FusedEngine(R)
+        eng.forward(pose0, g)
+        assert eng.check_capacity()
+        res = []
+        for lr, n in ((0.0, 1), (0.002, 12)):
+            pose = (pose0 + torch.tensor([0.0, 0.004, -0.003, 0.002, 0.01, -0.008, 0.012], device=DEV)).contiguous()
+            m, v = torch.zeros(7, device=DEV), torch.zeros(7, device=DEV)
+            step = torch.zeros(1, dtype=torch.int32, device=DEV)
+            lcfg = _loss_cfg(eng.H, eng.W, 1.0, 0.0, 0.05 if pearson else 0.0, 1, 1 if pearson else 0, 1, 0.99)
+            ad = _lib.Mm3dgsPoseAdam()
+            ad.pose, ad.m, ad.v, ad.step = pose.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr()
+            ad.lr_q, ad.lr_t, ad.beta1, ad.beta2, ad.eps = lr, lr, 0.9, 0.999, 1e-8
+            eng.track_loop(n, pose, g, lcfg, gt, ref if pearson else None, ad)
+            torch.cuda.synchronize()
+            assert eng.check_capacity() and int(step) == n
+            res.append((pose.clone(), (m / 0.1).clone(), eng.loss.clone()))
+        out[no_chain] = res
+    (p1a, ga, la), (p12a, _, _) = out["1"]
+    (p1b, gb, lb), (p12b, _, _) = out["0"]
+    assert torch.equal(p1a, p1b) and float(ga.abs().max()) > 0
+    assert pu.rel_l2(gb, ga) < 2e-6, (ga, gb)
+    assert torch.equal(la, lb)
+    assert (p12a - p12b).abs().max() < 2e-6, (p12a, p12b)
+
+
 def test_fused_path_with_huge_splats_matches_torch_graph():
     """Same for the native SLAM path: a map whose Gaussians each cover dozens of tiles (wave-cooperative gather of the
     dense gradient records, block rectangles far larger than a tile)."""
