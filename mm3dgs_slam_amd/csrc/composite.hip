@@ -572,9 +572,14 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   float behind_dot = 0.f;  // (colour accumulated behind the current list position) . dL
 
   // entries behind `todo` receive no gradient: their records are zero
+  // SLAM modes (round 6): the record of a list entry sits at the entry's own position, NLIST * start + L * len + k -- LIST-major.  A row's walk
+  // writes consecutive records (whole cache lines leave the L2 once, instead of one 64-byte write per 40-byte record: the compositor's WRITE_SIZE
+  // was 1.6x its record bytes), the zeroed tail is one contiguous span, and the list entries need not carry an index.  The per-tile combine finds a
+  // pair's records by recomputing its list positions from the sorted bin (below).  Generic mode: Gaussian-major records, index in the entry.
+  const size_t rbase = (size_t)NLIST * start + (size_t)L * len;
   if constexpr (!POSE)
   for (uint32_t e = todo + q; e < count; e += 16) {
-    zero_record<NV>(dsub + (size_t)list[e].y * RECF);
+    zero_record<NV>(dsub + (MODE == 0 ? (size_t)list[e].y : rbase + e) * RECF);
   }
   float pacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // POSE: this lane's share of the tile's pose row (lanes 0-7 of a row: dR rows 0, 1; lanes 8-15: dR row 2, dt)
   if constexpr (MODE != 0 && BWD_TWO_PHASE) {
@@ -730,7 +735,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
               pacc[3] = __builtin_fmaf(mb, hi ? dm0 : x0, pacc[3]); pacc[4] = __builtin_fmaf(mb, hi ? dm1 : x1, pacc[4]); pacc[5] = __builtin_fmaf(mb, hi ? dm2 : x2, pacc[5]);
             } else
             if (on2 && !(MM3DGS_BWD2_PROBE & 2)) {
-              float* const o = dsub + ((MM3DGS_BWD2_PROBE & 32) ? (size_t)lane : ((MM3DGS_BWD2_PROBE & 64) ? ((size_t)NLIST * start + (size_t)L * len + (size_t)(todo - 1u - (base + (uint32_t)ent))) : (size_t)idx)) * RECF;
+              float* const o = dsub + ((MM3DGS_BWD2_PROBE & 32) ? (size_t)lane : rbase + (size_t)(todo - 1u - (base + (uint32_t)ent))) * RECF;
               if constexpr (MODE == 1) {      // [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy]
                 if (MM3DGS_BWD2_PROBE & 16) { if (part == 0) { const f4u v0 = {M0 + Mx + Mxx + c0, c1 + c2 + cz + My, Mxy, Myy}; *(f4u*)o = v0; } } else {
                 if (part == 0) { const f4u v0 = {M0, Mx, Mxx, c0}; *(f4u*)o = v0; }
@@ -805,8 +810,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
     auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti_in, const int j) {
-      const uint32_t ti = MODE == 0 ? ti_in : __float_as_uint(Cc.z);
       const uint32_t step = base + (uint32_t)j;               // wave-uniform
+      const size_t ti = MODE == 0 ? (size_t)ti_in : rbase + (size_t)(todo - 1u - step);      // (SLAM modes: list-major records)
       const bool row_on = step < todo;                        // this row still has an entry at this step
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
@@ -873,7 +878,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
         }
       }
       // this row is the only writer of the (block, splat) record: up to 12 of its lanes store 48 contiguous bytes
-      if (my_slot >= 0 && row_on && !PROBE(cam, 0)) my_rec[(size_t)ti * RECF] = tot;
+      if (my_slot >= 0 && row_on && !PROBE(cam, 0)) my_rec[ti * RECF] = tot;
     };
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
@@ -944,49 +949,61 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // (Also measured and rejected in round 5: four lanes per pair, one per 16-byte chunk of a record, so that one load instruction fetches a record
     // with adjacent lanes -- a third of the cache-line requests, but a lane group then walks four pairs one after the other: mapping launch 58.6 us
     // against 58.1, fused tracking kernel 69.2 against 67.1.  The pass is a latency chain per pair, not a request-rate limit: one pair per lane it is.)
-    auto combine = [&](const unsigned long long pl, const uint32_t tr) {
-      uint32_t mask = (uint32_t)pl & 0xffffu;
-      const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-      while (mask) {
-        // a few records in flight (a pair lists ~4 blocks on average: one round for most)
-        constexpr int UR = 4;
-        float4 ra[UR], rb[UR], rc[UR];
-        bool on[UR];
-#pragma unroll
-        for (int u = 0; u < UR; u++) {
-          on[u] = mask != 0u;
-          const int L = on[u] ? __ffs((int)mask) - 1 : 0;
-          mask &= mask - 1u;
-          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
-          const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? (size_t)rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
-          ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
-          rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < UR; u++) {
-          a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
-          a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
-          if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
-        }
-      }
-      if (tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
-        float* o = dtile + (size_t)tr * RECF;
-        const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
-        *(f4u*)o = q0;
-        if (MODE == 1) { const f4u q1 = {a1.x, a1.y, a1.z, a1.w}; *(f4u*)(o + 4) = q1; const f2u q2 = {a2.x, a2.y}; *(f2u*)(o + 8) = q2; }
-        else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
-      }
-    };
+    // Round 6: the block records are LIST-major (record of the k-th entry of block list L = NLIST * start + L * len + k), so a pair's records are found
+    // through its list positions -- the rank of the pair among the bin's entries that list block L, in SORTED order.  The sort left the bin in sorted
+    // order over the keys (block mask | per-tile record << 32); every wave walks all of it in 64-entry chunks, keeps the sixteen running list lengths
+    // (ballots: wave-uniform counters), and sums the records of the chunks it owns (chunk c: wave c % 4), each lane one pair, the pair's blocks in
+    // ascending order, four records in flight -- the order of the sums is what it was.
+    const unsigned long long* __restrict__ sorted = b.keys + start;
+    unsigned long long w_first = 0ull;
+    if (!PROBE(cam, 5) && (uint32_t)lane < len) w_first = sorted[lane];      // requested before the barrier: lands while the wave waits for the tile's slowest wave
+    __syncthreads();
     if (!PROBE(cam, 5)) {      // (probe builds, bit 5: timing without the combine)
-      unsigned long long pl_first = 0ull;
-      uint32_t tr_first = 0xffffffffu;
-      if ((uint32_t)tid < len) { pl_first = b.payload[start + tid]; tr_first = b.trec[start + tid]; }
-      __syncthreads();
-      if ((uint32_t)tid < len) combine(pl_first, tr_first);
-      for (uint32_t e = (uint32_t)tid + 256u; e < len; e += 256u) combine(b.payload[start + e], b.trec[start + e]);
-    } else {
-      __syncthreads();
+      uint32_t run[NLIST];
+#pragma unroll
+      for (int Lq = 0; Lq < NLIST; Lq++) run[Lq] = 0u;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const uint32_t nchunks = (len + 63u) >> 6;
+      for (uint32_t c = 0; c < nchunks; c++) {
+        const uint32_t i = c * 64u + (uint32_t)lane;
+        const unsigned long long wd = c == 0 ? w_first : (i < len ? sorted[i] : 0ull);
+        const uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u, tr = (uint32_t)(wd >> 32);
+        const bool mine = (c & 3u) == (uint32_t)wv;      // wave-uniform
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+#pragma unroll
+        for (int g4 = 0; g4 < NLIST; g4 += 4) {
+          unsigned long long bal[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) bal[u] = __ballot((mask >> (g4 + u)) & 1u);
+          if (mine && (bal[0] | bal[1] | bal[2] | bal[3]) != 0ull) {
+            float4 ra[4], rb[4], rc[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              on[u] = (mask >> (g4 + u)) & 1u;
+              const size_t rec = (size_t)NLIST * start + (size_t)(g4 + u) * len + (size_t)(run[g4 + u] + (uint32_t)__popcll(bal[u] & lt));
+              const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
+              ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
+              rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
+              a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
+              if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) run[g4 + u] += (uint32_t)__popcll(bal[u]);
+        }
+        if (mine && i < len && tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
+          float* o = dtile + (size_t)tr * RECF;
+          const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
+          *(f4u*)o = q0;
+          if (MODE == 1) { const f4u q1 = {a1.x, a1.y, a1.z, a1.w}; *(f4u*)(o + 4) = q1; const f2u q2 = {a2.x, a2.y}; *(f2u*)(o + 8) = q2; }
+          else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
+        }
+      }
     }
   }
 }

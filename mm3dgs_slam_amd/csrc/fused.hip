@@ -326,7 +326,7 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
 // than `cap` pairs drops the excess and the sort flags the overflow; a workgroup with more than rec_cap records flags it
 // here and lists none of the splats that do not fit (both sticky, like a packed bin that runs out of capacity).
 struct PairCtx {           // what a lane needs to emit the pairs of ITS Gaussian (broadcast lane by lane for huge splats)
-  MaskConsts mc; BlkRect br; uint32_t rec0; uint32_t khi, idbits; int minx, miny, w, area;   // rec0: first record (absolute)
+  MaskConsts mc; BlkRect br; uint32_t khi, idbits; int minx, miny, w, area;
   uint32_t trec0;            // per-tile record of the splat's first pair (absolute; pair k of the tile rectangle, row-major: trec0 + k); ~0u: none
 };
 __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, int ttx, int tty, uint32_t* hist, int gx, uint32_t cap, const BinView& b,
@@ -336,11 +336,11 @@ __device__ __forceinline__ uint32_t emit_pair(const PairCtx& c, int k, int ttx, 
   uint32_t mask = 0;
   if (slot < cap) {
     mask = have_mask ? mask_in : tile_block_mask_in_rect(c.mc, ttx, tty, c.br);
-    const uint32_t rec_local = c.rec0 + (uint32_t)((tty * 4 - c.br.by0) * c.br.bw + (ttx * 4 - c.br.bx0));
     const size_t at = (size_t)t * cap + slot;
     b.keys[at] = ((unsigned long long)c.khi << 32) | (unsigned long long)(c.idbits | slot);
-    b.payload[at] = (unsigned long long)mask | ((unsigned long long)(uint32_t)min(c.br.bw, 0xffff) << 16) | ((unsigned long long)rec_local << 32);
-    b.trec[at] = c.trec0 == 0xffffffffu ? 0xffffffffu : c.trec0 + (uint32_t)k;
+    // payload (round 6): block mask | the pair's per-tile gradient record << 32 -- the block records themselves are addressed by list position
+    // (composite.hip), so neither the block rectangle's width nor a first block record travels any more
+    b.payload[at] = (unsigned long long)mask | ((unsigned long long)(c.trec0 == 0xffffffffu ? 0xffffffffu : c.trec0 + (uint32_t)k) << 32);
   }
   return mask;
 }
@@ -360,28 +360,21 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   c.area = c.w * ((int)(pr.r1 >> 16) - c.miny);
   c.khi = __float_as_uint(pr.z);
   c.idbits = (uint32_t)idx << slot_bits;
-  {   // workgroup-local exclusive scan of the gradient records (4x4 blocks of the block rectangles) + the workgroup's pairs
-    __shared__ uint32_t wtot[FB / 64], wtot2[FB / 64];
-    const uint32_t x = wave_scan_incl(pr.nblk), x2 = wave_scan_incl((uint32_t)c.area);
-    if (lane == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
+  {   // workgroup-local exclusive scan of the workgroup's pairs (round 6: the block records are addressed by list position, composite.hip -- the scan
+      // of the splats' 4x4 blocks, the per-workgroup record spans and their overflow case are gone)
+    __shared__ uint32_t wtot2[FB / 64];
+    const uint32_t x2 = wave_scan_incl((uint32_t)c.area);
+    if (lane == 63) wtot2[wvi] = x2;
     __syncthreads();                      // (also orders the histogram clear before sweep 1)
-    uint32_t pre = 0, pre2 = 0;
-    for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
-    const uint32_t local = pre + x - pr.nblk;
-    if (live) g.blkoff[idx] = local;
-    const uint32_t base = (uint32_t)blockIdx.x * rec_cap;
-    c.rec0 = base + local;
-    if (local + pr.nblk > rec_cap) { c.br.bw = 0; c.br.bh = 0; }     // does not fit: listed nowhere (clip_mask_to_rect), flagged below
+    uint32_t pre2 = 0;
+    for (int q = 0; q < wvi; q++) pre2 += wtot2[q];
     // per-tile records: this workgroup's pairs own [w * trec_cap, (w + 1) * trec_cap); a Gaussian's pairs are contiguous in it
     const uint32_t plocal = pre2 + x2 - (uint32_t)c.area;
     if (live) g.tileoff[idx] = plocal;
     c.trec0 = plocal + (uint32_t)c.area <= cam.trec_cap ? (uint32_t)blockIdx.x * cam.trec_cap + plocal : 0xffffffffu;
     if (tid == FB - 1) {
-      const uint32_t tot = pre + x;
-      g.block_blk[blockIdx.x] = base;     // first record of this workgroup's splats (read by the backward projection)
       g.block_tiles[blockIdx.x] = pre2 + x2;  // pairs of this workgroup (summed into num_rendered by the sort)
-      if (tot > rec_cap || pre2 + x2 > cam.trec_cap) iv.hdr->overflow = 1u;
-      if (tot > iv.hdr->max_group_records) atomicMax(&iv.hdr->max_group_records, tot);   // (rare: the maximum is sticky)
+      if (pre2 + x2 > cam.trec_cap) iv.hdr->overflow = 1u;
     }
   }
   // sweep 1: count (a rectangle of more than 32 tiles is spread over the wave).  Round 4: the block masks of a lane's OWN pairs (the first

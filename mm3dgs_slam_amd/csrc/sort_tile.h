@@ -225,16 +225,15 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       const unsigned long long pl = have ? spl[i] : 0ull;
       const uint32_t id = have ? ((uint32_t)sk[i] >> slot_bits) : 0u;
       const uint32_t m4 = ((uint32_t)pl >> (4 * wv)) & 0xfu;
-      const uint32_t bw = (uint32_t)(pl >> 16) & 0xffffu, recT = (uint32_t)(pl >> 32);
+      // the bin in SORTED order (block mask | per-tile record << 32) over the keys, which nobody reads again: the backward compositor's per-tile
+      // combine walks it and recomputes every entry's list positions (= its block records, addressed by list position: composite.hip)
+      if (have && ((base >> 6) & 3) == wv) b.keys[start + (uint32_t)i] = pl;
 #pragma unroll
       for (int bq = 0; bq < 4; bq++) {
         const int L = 4 * wv + bq;
         const bool on = (m4 >> bq) & 1u;
         const unsigned long long bal = __ballot(on);
-        if (on) {
-          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
-          sub[(size_t)L * len + cnt[bq] + __popcll(bal & lt)] = make_uint2(id, rec);
-        }
+        if (on) sub[(size_t)L * len + cnt[bq] + __popcll(bal & lt)] = make_uint2(id, 0u);
         cnt[bq] += (uint32_t)__popcll(bal);
       }
     }
@@ -261,8 +260,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       id = low >> slot_bits;
       const unsigned long long pl = b.payload[start + (low & slot_mask)];
       mask = (uint32_t)(pl & 0xffffu);
-      bw = (uint32_t)(pl >> 16) & 0xffffu;
-      recT = (uint32_t)(pl >> 32);
+      b.keys[start + (uint32_t)i] = pl;      // the bin in sorted order (mask | per-tile record << 32): see the fast path above
     } else if (have) {
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
       const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
@@ -281,10 +279,8 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       else mask = 0;   // only on capacity overflow (flagged in the header)
       // the compositor's per-tile combine (SLAM modes) finds every pair of the bin by its position: mask, block-rectangle width, first
       // block record, and the pair's per-tile record = its Gaussian-major pair index
-      if (write_pair_index) {   // (SLAM entry points)
-        b.payload[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)min(bw, 0xffffu) << 16) | ((unsigned long long)recT << 32);
-        b.trec[start + (uint32_t)i] = pidx < N_cap ? pidx : 0xffffffffu;
-      }
+      if (write_pair_index)     // (SLAM entry points) the bin in sorted order: block mask | per-tile record (= the Gaussian-major pair index) << 32
+        b.keys[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)(pidx < N_cap ? pidx : 0xffffffffu) << 32);
     }
     unsigned long long bal[NLIST];
 #pragma unroll

@@ -14,7 +14,7 @@ v = re.search(r'"value": ([0-9.]+)', open("/tmp/ks_ab.out").read())
 row = {}
 for r in csv.DictReader(open(f)):
     n = r["Name"].split("(")[0]
-    for key, pat in (("bwd", "composite_bwd_kernel<6, 1>"), ("track", "fwd_bwd_track"), ("fwd", "sort_composite_fwd_kernel"), ("bproj", "slam_bwd_project"), ("ssim", "ssim_maps_kernel<false>"),
+    for key, pat in (("bwd", "composite_bwd_kernel<6, 1"), ("track", "fwd_bwd_track"), ("fwd", "sort_composite_fwd_kernel"), ("bproj", "slam_bwd_project"), ("ssim", "ssim_maps_kernel<false>"),
                      ("pbin", "slam_project_bin"), ("tbwd", "slam_preprocess_bwd_kernel<true, true"), ("fin", "pose_finish")):
         if pat in n and key not in row:
             row[key] = float(r["AverageNs"]) / 1e3

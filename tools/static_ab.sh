@@ -65,7 +65,7 @@ if not f:
     print(sys.argv[1], "no trace:", open("/tmp/sk.out").read()[-400:]); sys.exit(0)
 rows = [r for r in csv.DictReader(open(f[0]))]
 out = []
-for key in ("composite_bwd_kernel<6, 1>", "sort_composite_fwd_kernel", "sort_composite_fwd_bwd_track", "slam_preprocess_bwd"):
+for key in ("composite_bwd_kernel<6, 1", "sort_composite_fwd_kernel", "sort_composite_fwd_bwd_track", "slam_preprocess_bwd"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]][-50:]
     if d: out.append(f"{key.split('<')[0][-24:]} {sum(d) / len(d):6.2f}")
 print(f"{sys.argv[1]:10s}", " | ".join(out))
