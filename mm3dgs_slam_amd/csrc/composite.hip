@@ -955,10 +955,17 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // (ballots: wave-uniform counters), and sums the records of the chunks it owns (chunk c: wave c % 4), each lane one pair, the pair's blocks in
     // ascending order, four records in flight -- the order of the sums is what it was.
     const unsigned long long* __restrict__ sorted = b.keys + start;
-    unsigned long long w_first = 0ull;
-    if (!PROBE(cam, 5) && (uint32_t)lane < len) w_first = sorted[lane];      // requested before the barrier: lands while the wave waits for the tile's slowest wave
+    // the first four chunks' words are requested before the barrier (they depend on nothing the rows compute, the main loop's registers are dead): they
+    // land while the wave waits for the tile's slowest wave, and a tile of up to 256 pairs -- nearly every tile of a SLAM map -- needs no load after it
+    unsigned long long wpre[4] = {0ull, 0ull, 0ull, 0ull};
+    if (!PROBE(cam, 5)) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) if ((uint32_t)(c * 64 + lane) < len) wpre[c] = sorted[c * 64 + lane];
+    }
     __syncthreads();
     if (!PROBE(cam, 5)) {      // (probe builds, bit 5: timing without the combine)
+      // wave-private scratch in the (now free) staging memory: the lane's sixteen list positions of the chunk, as u16
+      uint32_t* const pos16 = (uint32_t*)(smem_raw + (size_t)wv * 2048) + lane * (NLIST / 2);      // (two positions per word)
       uint32_t run[NLIST];
 #pragma unroll
       for (int Lq = 0; Lq < NLIST; Lq++) run[Lq] = 0u;
@@ -966,37 +973,53 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
       const uint32_t nchunks = (len + 63u) >> 6;
       for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t i = c * 64u + (uint32_t)lane;
-        const unsigned long long wd = c == 0 ? w_first : (i < len ? sorted[i] : 0ull);
-        const uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u, tr = (uint32_t)(wd >> 32);
+        unsigned long long wd = c == 0 ? wpre[0] : (c == 1 ? wpre[1] : (c == 2 ? wpre[2] : wpre[3]));
+        if (c >= 4) wd = i < len ? sorted[i] : 0ull;
+        uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u;
+        const uint32_t tr = (uint32_t)(wd >> 32);
         const bool mine = (c & 3u) == (uint32_t)wv;      // wave-uniform
+        uint32_t pos[NLIST];
+#pragma unroll
+        for (int Lq = 0; Lq < NLIST; Lq++) {
+          const unsigned long long bal = __ballot((mask >> Lq) & 1u);
+          pos[Lq] = run[Lq] + (uint32_t)__popcll(bal & lt);
+          run[Lq] += (uint32_t)__popcll(bal);
+        }
+        if (!mine) continue;
+        // (list positions fit 16 bits: a tile's span holds at most 8191 pairs -- direct bins --; longer packed-bin lists take the slow path below)
+        const bool wide = len > 0xffffu;
+        if (!wide) {
+#pragma unroll
+          for (int Lq = 0; Lq < NLIST; Lq += 2) pos16[Lq >> 1] = pos[Lq] | (pos[Lq + 1] << 16);
+        }
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+        while (__ballot(mask != 0u) != 0ull) {      // a pair lists ~4 blocks on average: one round for most
+          constexpr int UR = 4;
+          float4 ra[UR], rb[UR], rc[UR];
+          bool on[UR];
 #pragma unroll
-        for (int g4 = 0; g4 < NLIST; g4 += 4) {
-          unsigned long long bal[4];
+          for (int u = 0; u < UR; u++) {
+            on[u] = mask != 0u;
+            const int Lq = on[u] ? __ffs((int)mask) - 1 : 0;
+            mask &= mask - 1u;
+            uint32_t pq;
+            if (!wide) { const uint32_t w2 = pos16[Lq >> 1]; pq = (Lq & 1) ? (w2 >> 16) : (w2 & 0xffffu); }
+            else { pq = 0u;
 #pragma unroll
-          for (int u = 0; u < 4; u++) bal[u] = __ballot((mask >> (g4 + u)) & 1u);
-          if (mine && (bal[0] | bal[1] | bal[2] | bal[3]) != 0ull) {
-            float4 ra[4], rb[4], rc[4];
-            bool on[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              on[u] = (mask >> (g4 + u)) & 1u;
-              const size_t rec = (size_t)NLIST * start + (size_t)(g4 + u) * len + (size_t)(run[g4 + u] + (uint32_t)__popcll(bal[u] & lt));
-              const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
-              ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
-              rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
-              a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
-              if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
-            }
+              for (int t = 0; t < NLIST; t++) pq = Lq == t ? pos[t] : pq; }
+            const size_t rec = (size_t)NLIST * start + (size_t)Lq * len + (size_t)pq;
+            const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
+            ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
+            rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) run[g4 + u] += (uint32_t)__popcll(bal[u]);
+          for (int u = 0; u < UR; u++) {
+            a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
+            a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
+            if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
+          }
         }
-        if (mine && i < len && tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
+        if (i < len && tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
           float* o = dtile + (size_t)tr * RECF;
           const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
           *(f4u*)o = q0;
