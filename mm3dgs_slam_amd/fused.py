@@ -42,6 +42,11 @@ def _p(t):
 class FusedEngine:
     """Owns the reusable device buffers of the fused render (state, output, gradients) for one Renderer."""
     MIN_PAIRS = 65536      # floor of the binning capacity (pairs)
+    # longest tile list (seen so far) up to which the engine asks for the one-launch sort + compositing kernels and direct bins: they sort lists of up to
+    # 2048 splats in LDS (1024: run sort + rank merge; 2048: bitonic), anything longer through global memory -- correct, but a tile that does holds its
+    # whole launch up, and from there on the three-launch path with its 16 K-entry LDS tier is the better one.  (1400 until round 6: a dense map -- the
+    # UTMM-shaped configuration grown to 320 k Gaussians, 600 .. 840 pairs per tile on average -- crossed it and fell back to three launches per render.)
+    FAST_PATH_MAX_LIST = 2048
     DIRECT_BINS = True     # size the binning state as tiles x (per-tile capacity) so that projection + binning are one launch
 
     def __init__(self, renderer):
@@ -116,7 +121,7 @@ class FusedEngine:
         T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         per_tile = int(self.max_tile_len * 1.5) + 128
         slot_bits = min(13, 32 - max(int(P - 1).bit_length(), 1)) if P > 0 else 0
-        if self.DIRECT_BINS and self.max_tile_len <= 1400 and slot_bits >= 10 and int(per_tile * 1.25) + 1 <= (1 << slot_bits) - 1:
+        if self.DIRECT_BINS and self.max_tile_len <= self.FAST_PATH_MAX_LIST and slot_bits >= 10 and int(per_tile * 1.25) + 1 <= (1 << slot_bits) - 1:
             want = max(want, T * per_tile)
             # ... and every projection workgroup (256 Gaussians) 16 * n_cap / workgroups gradient records
             want = max(want, ((P + 255) // 256) * (int(getattr(self, "max_group_records", 0) * 1.5) + 1024) // 16 + 1)
@@ -139,7 +144,7 @@ class FusedEngine:
 
     def _flags(self):
         """STATE_CLEAN | SHORT_LISTS (hint from the last header check) | DIRECT_BINS (the capacity was sized per tile)."""
-        return _lib.FWD_STATE_CLEAN | (_lib.FWD_SHORT_LISTS if self.max_tile_len <= 1400 else 0) | (_lib.FWD_DIRECT_BINS if self.direct else 0)
+        return _lib.FWD_STATE_CLEAN | (_lib.FWD_SHORT_LISTS if self.max_tile_len <= self.FAST_PATH_MAX_LIST else 0) | (_lib.FWD_DIRECT_BINS if self.direct else 0)
 
     def inputs(self, pose, g):
         si = _lib.Mm3dgsSlamInputs()

@@ -605,7 +605,7 @@ def test_tracking_iteration_in_one_compositor_launch_matches_the_separate_launch
         monkeypatch.setenv("MM3DGS_NO_FUSED_TRACK", no_fuse)
         eng = FusedEngine(R)
         eng.forward(pose0, g)
-        assert eng.check_capacity() and eng.max_tile_len <= 1400
+        assert eng.check_capacity() and eng.max_tile_len <= eng.FAST_PATH_MAX_LIST
         pose = (pose0 + torch.tensor([0.0, 0.004, -0.003, 0.002, 0.01, -0.008, 0.012], device=DEV)).contiguous()
         m, v = torch.zeros(7, device=DEV), torch.zeros(7, device=DEV)
         step = torch.zeros(1, dtype=torch.int32, device=DEV)
