@@ -78,6 +78,10 @@ def parse():
                          "scene (trajectory_desk, amp 1.6) at the full iteration budget, untimed, until the map has this many Gaussians.  -1: the configuration's "
                          "stated size; 0: no growth phase (round 4's lines: the bounded trajectory on the frame-0 map)")
     ap.add_argument("--grow-max-frames", type=int, default=160)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="--gpus N > 1 (or --window-batch / --force-collectives).  weak (the driver's contract): every rank renders --map-iters views per frame, "
+                         "each optimiser step sums N views, `value` counts those views as frame-equivalents.  strong: the frame's --map-iters views IN TOTAL are "
+                         "split over the ranks -- ceil(map-iters / N) optimiser steps of N views each -- and `value` is plain frames per second")
     ap.add_argument("--optimizer", choices=("auto", "allreduce", "reduce_scatter"), default="auto",
                     help="multi-GPU window: all-reduce + replicated Adam, or reduce-scatter -> Adam on 1 / N of the elements -> all-gather of the parameters "
                          "(auto: the latter from 500 k Gaussians on; window_parallel.py)")
@@ -402,6 +406,10 @@ def main():
     extras = world == 1 and rank == 0 and not args.force_collectives
     steady = args.steady_frames if extras else 0
 
+    strong = args.scaling == "strong"
+    views_total = args.map_iters
+    if strong:      # the frame's mapping views in total, split over the ranks (and the window batch): fewer optimiser steps of more views each
+        args.map_iters = -(-args.map_iters // max(world * args.window_batch, 1))
     c3 = args.workload == "c3"
     if c3:
         args.height, args.width = 330, 640
@@ -502,6 +510,8 @@ def main():
     views_per_frame = args.track_iters + args.map_iters
     vps = world * args.window_batch
     frame_equiv = (args.track_iters + args.map_iters * vps) / views_per_frame
+    if strong:      # a frame is a frame: its views_total mapping views were rendered by all ranks together
+        frame_equiv = 1.0
     value = args.steps * frame_equiv / elapsed
     passes = 1 if args.render_mode == "fused" else 2
     renders = args.steps * views_per_frame
@@ -510,7 +520,7 @@ def main():
     out = {
         "metric": "SLAM frames/sec (track+map), " + ("UT-MM-shaped 640x330 RGB-D + IMU" if c3 else ("Replica-room0-shaped 1200x680" if c4 else "TUM fr1/desk-shaped 640x480")), "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"UT-MM-shaped synthetic RGB-D + IMU {W}x{H} (configs/UTMM.yml: intrinsics x 1/2, isotropic Gaussians, pose prediction "
                                 f"by IMU dead-reckoning over synthetic 100 Hz samples, Pearson depth term and IMU relative-pose residual (weights 1.0 / 0.1) "
                                 f"in the tracking loss), {P_now} Gaussians, " if c3 else
@@ -523,7 +533,8 @@ def main():
                                f"render_mode={args.render_mode}, "
                                f"binning={args.policy}; also in this line: `steady_state` = the {steady} frames that follow the timed region of "
                                f"the same run, `full_seed` = a second run seeded like the reference (one Gaussian per valid frame-0 pixel)",
-                   "gaussians": P_now, "image": [H, W], "iterations_per_frame": views_per_frame,
+                   "gaussians": P_now, "image": [H, W], "iterations_per_frame": views_per_frame, "grown": bool(grow_to),
+                   **({"strong_scaling": f"{views_total} mapping views per frame in total = {args.map_iters} optimiser steps of {vps} view(s); value = frames per second"} if strong else {}),
                    "multi_gpu": ({"description": f"mapping window sharded: {world} rank(s) x {args.window_batch} view(s) per optimiser step, one all-reduce of the "
                                                 f"Gaussian gradients per step; tracking replicated", **(rank_check or {})}
                                  if (vps > 1 or collective) else "single GPU")},
@@ -541,12 +552,12 @@ def main():
     fwd_sort_comp = 24 * N * r_passes + 8 * N + (8 * N + 8 * T_tiles) + N * (28 + 4 * C) + H * W * (4 * C + 8)   # 8d "Forward": sort + ranges + composite read + image write
     fused_track = bool(prof.get("track_fwd_bwd", (0, 0.0))[0])      # the tracking iterations ran sort + forward + backward compositing as one launch
     kernels = {
-        "composite_bwd": ("composite_bwd_kernel<6,1> (mapping; the mapping loss's gradient-image pass runs in its prologue)", bwd_comp + loss_grad_pass,
+        "composite_bwd": ("composite_bwd_kernel<6,1> (mapping; the mapping loss's gradient-image pass runs in its prologue; round 6: two-phase reduction, list-major block records)", bwd_comp + loss_grad_pass,
                           "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite] + 18 HW 4 [folded loss gradient pass: 9 SSIM maps + rgb + gt + depth/sil/ref]",
                           args.map_iters * vps),
-        "composite_bwd_track": ("composite_bwd_kernel<6,2> (tracking; masked-L1 loss folded in)", bwd_comp, "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite]",
+        "composite_bwd_track": ("composite_bwd_kernel<6,2> (tracking; loss folded in; round 6: the pose chain -- one pose row per tile instead of gradient records)", bwd_comp, "N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite; the N(24+4C) gradient-scatter term is contract bytes the pose chain no longer moves]",
                                 args.track_iters),
-        "track_fwd_bwd": ("sort_composite_fwd_bwd_track_kernel (tracking: per-tile sort + block lists + forward + backward compositing in one launch; masked-L1 loss folded in)",
+        "track_fwd_bwd": ("sort_composite_fwd_bwd_track_kernel (tracking: per-tile sort + block lists + forward + backward compositing in one launch; masked-L1 loss folded in; round 6: the pose chain -- one pose row per tile, no gradient records, no backward-projection launch)",
                           fwd_sort_comp + bwd_comp,
                           "24 N r + 8N + 8N + 8T + N(28+4C) + HW(4C+8) [SURVEY 8d forward] + N(28+4C) + HW(4C+8) + N(24+4C) [SURVEY 8d backward composite], r = %d" % r_passes,
                           args.track_iters),
@@ -571,7 +582,7 @@ def main():
                      "timed_launches": n_k, "launches_per_frame": per_frame, "ms_per_frame": dur * 1e3 * per_frame})
     if recs:
         recs.sort(key=lambda r_: -r_["ms_per_frame"])
-        pmc_names = {"composite_bwd_kernel<6,1>": ("composite_bwd_kernel", "<6, 1>"), "composite_bwd_kernel<6,2>": ("composite_bwd_kernel", "<6, 2>"),
+        pmc_names = {"composite_bwd_kernel<6,1>": ("composite_bwd_kernel", "<6, 1"), "composite_bwd_kernel<6,2>": ("composite_bwd_kernel", "<6, 2"),
                      "sort_composite_fwd_kernel<6>": ("sort_composite_fwd_kernel",), "sort_composite_fwd_bwd_track_kernel": ("sort_composite_fwd_bwd_track_kernel",)}
         for r_ in recs:
             for pre, match in pmc_names.items():

@@ -368,14 +368,37 @@ int mm3dgs_profile_read(int kernel, uint64_t* launches, double* total_ms);
 /* what the event pair adds to an interval it brackets (measured on empty kernels: 2 T(1 launch) - T(2 launches)); synchronises the stream */
 double mm3dgs_profile_event_overhead_ms(void* stream);
 
+/* ---- Environment (developer switches) ------------------------------------------------------------------------
+ * The library reads these variables; none is needed in production, all default to "off" / the value given.  They select an alternative
+ * path that the tests hold equal to the default one (bit for bit where noted) or parametrise an A/B experiment.  The first SLAM entry
+ * point of a process prints one line to stderr for every one that is set.
+ *   MM3DGS_NO_DIRECT_BINS=1    packed bins (count, scan, scatter) instead of direct bins in the SLAM entry points          (bit-identical)
+ *   MM3DGS_NO_FUSED_SORT=1     the per-tile sort as launches of its own instead of inside the forward compositor
+ *   MM3DGS_NO_FUSED_SCAN=1     a separate scan_tiles launch on the packed path (also disables direct bins)
+ *   MM3DGS_NO_FUSED_TRACK=1    mm3dgs_slam_track: forward and backward compositor as two launches                            (bit-identical)
+ *   MM3DGS_NO_FOLDED_LOSS=1    the loss kernels as launches of their own instead of folded into the compositors
+ *   MM3DGS_NO_FORWARD_ROWS=1   mm3dgs_slam_map: the standalone mm3dgs_loss instead of the forward compositor's row sums
+ *   MM3DGS_NO_FUSED_PROJECT=1  mm3dgs_slam_map: backward projection and next projection as two launches                       (bit-identical)
+ *   MM3DGS_NO_POSE_CHAIN=1     mm3dgs_slam_track: gradient records + backward projection instead of the compositor's pose chain (ABI 208)
+ *   MM3DGS_NO_TILE_ORDER=1     arithmetic workgroup -> tile map instead of the load-balanced table                           (bit-identical)
+ *   MM3DGS_TILEMAP=0           workgroup b composites tile b (default 1: a contiguous span of tiles per XCD)                 (bit-identical)
+ *   MM3DGS_DIRECT_MAX_TILES=n  largest tile grid that may use direct bins (default 11264)
+ *   MM3DGS_STATS=1             count compositor wave steps into Mm3dgsHeader (adds atomics: not for timing)
+ *   MM3DGS_SLAM_LDS_PAD / MM3DGS_FWD_LDS_PAD / MM3DGS_BWD_LDS_PAD=bytes   never-touched dynamic LDS per workgroup (occupancy experiments)
+ * Read by the Python package, not the library: MM3DGS_LIB=<path> loads a variant build of the library (tools/build_variant.sh).
+ * MM3DGS_EXP (timing probes with a phase removed: INVALID results) exists only in a library built with -DMM3DGS_PROBES. */
 const char* mm3dgs_last_error(void);
 /* ABI version of the library = the version of this header (tests/test_cabi.py holds the two together).
    100: round 1 | 200: double optimiser hyper-parameters, flags in mm3dgs_slam_backward, direct bins, map surgery entry points
    201: Mm3dgsLossConfig grew by the three splatam fields | 202: mm3dgs_propagate_const_vel, per-tile gradient records (binning / scratch sizes grew)
    203: Mm3dgsMapView.dpose_out_or_null, header.tile_order_tiles = image-size key, overflowing iterations are void
    204: mm3dgs_slam_adam_project, MM3DGS_FWD_PROJECTED / MM3DGS_FWD_KEEP_TILE_ORDER
-   205: Mm3dgsHeader.overflow_seen (appended) | 206: Mm3dgsPoseAdam.best (appended) | 207: Mm3dgsHeader.mean_wave_steps (appended) */
-#define MM3DGS_ABI_VERSION 207
+   205: Mm3dgsHeader.overflow_seen (appended) | 206: Mm3dgsPoseAdam.best (appended) | 207: Mm3dgsHeader.mean_wave_steps (appended)
+   208: mm3dgs_geom_bytes grew by the per-Gaussian pose-chain record (80 B; mm3dgs_slam_track's compositor applies it and writes no gradient
+        records); the SLAM modes' block records are addressed by list position and the sorted bin (mask | per-tile record) overwrites the keys:
+        binning_state / backward_scratch keep their sizes, their interior layout is the library's own; image_state must be zero-initialised
+        to at least sizeof(Mm3dgsHeader) before its first use with MM3DGS_FWD_STATE_CLEAN */
+#define MM3DGS_ABI_VERSION 208
 int mm3dgs_version(void);
 
 #ifdef __cplusplus

@@ -202,6 +202,23 @@ int mm3dgs_backward(const Mm3dgsCamera* cam, int P, int M, int C, const float* m
   return check_launch("backward");
 }
 
+// ---- developer switches (environment) ---------------------------------------------------------------------------------------
+// Every switch the library reads is listed in include/mm3dgs.h ("Environment").  They exist for the bit-identity / equivalence tests and for same-box
+// A/Bs; one left set in a user's environment silently changes which kernels run -- so the first SLAM entry point of a process says which are set.
+static void warn_env_once() {
+  static const bool done = [] {
+    static const char* const names[] = {"MM3DGS_NO_DIRECT_BINS", "MM3DGS_NO_FUSED_SORT", "MM3DGS_NO_FUSED_SCAN", "MM3DGS_NO_FUSED_TRACK", "MM3DGS_NO_FOLDED_LOSS",
+                                        "MM3DGS_NO_FORWARD_ROWS", "MM3DGS_NO_FUSED_PROJECT", "MM3DGS_NO_TILE_ORDER", "MM3DGS_NO_POSE_CHAIN", "MM3DGS_TILEMAP",
+                                        "MM3DGS_DIRECT_MAX_TILES", "MM3DGS_STATS", "MM3DGS_SLAM_LDS_PAD", "MM3DGS_FWD_LDS_PAD", "MM3DGS_BWD_LDS_PAD"};
+    for (const char* n : names) {
+      const char* v = getenv(n);
+      if (v && *v) fprintf(stderr, "mm3dgs: developer switch %s=%s is set in the environment: it changes which kernels run (include/mm3dgs.h, \"Environment\")\n", n, v);
+    }
+    return true;
+  }();
+  (void)done;
+}
+
 // ---- fused SLAM iteration ----------------------------------------------------------------------------------------
 static SlamIn slam_in(const Mm3dgsSlamInputs* in) {
   SlamIn s;
@@ -210,6 +227,7 @@ static SlamIn slam_in(const Mm3dgsSlamInputs* in) {
   return s;
 }
 static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in) {
+  warn_env_once();
   if (!cam || !in) return fail(-1, "NULL argument");
   if (cam->image_height <= 0 || cam->image_width <= 0) return fail(-1, "bad image size");
   if (P < 0) return fail(-1, "P < 0");

@@ -85,7 +85,7 @@ __device__ __forceinline__ void composite_fwd_body(int tile, const CamDev& cam, 
   uint32_t id_nxt = CH + q < count ? list[CH + q].x : 0u;
   int cur = 0;
 
-  const uint32_t mean_steps = iv.hdr->mean_wave_steps;
+  const uint32_t mean_steps = wave_mean_steps(cam, iv);
   wave_prio_by_steps(maxcount, mean_steps);
   for (uint32_t base = 0; base < maxcount; base += CH, cur ^= 1) {
     // issue the gathers for the following chunks before touching this one; they land while it is composited
@@ -597,7 +597,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     const bool z45_wave = __ballot(dL[4] != 0.f || dL[5] != 0.f || Tf_bg != 0.f) == 0ull;      // see the one-phase loop below
     if (!z45_wave) t5[lane] = dL[5];
     const uint32_t first_step = todo - min(todo, last_contributor);
-    const uint32_t mean_steps_b = iv.hdr->mean_wave_steps;
+    const uint32_t mean_steps_b = wave_mean_steps(cam, iv);
     const float X0 = pxf - (float)(q & 3), Y0 = pyf - (float)(q >> 2);      // pixel centre of the block's corner (exact)
     uint32_t n_visit = 0;
     // chunk c of a row holds its list entries todo-1-(16c+q): entry order == traversal order (back to front); lane q parks entry q and keeps
@@ -795,7 +795,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   // traversal:  step >= first_step  with the per-lane constant below -- one compare against a scalar instead of a subtraction and a compare per
   // step.  (todo >= last_contributor unless the list was clamped to `count`; then first_step = 0: every listed splat counts.)
   const uint32_t first_step = todo - min(todo, last_contributor);
-  const uint32_t mean_steps_b = iv.hdr->mean_wave_steps;
+  const uint32_t mean_steps_b = wave_mean_steps(cam, iv);
   auto run_chunks = [&](auto z45_tag) {
   constexpr bool Z45 = decltype(z45_tag)::value && MODE != 0;   // (SLAM modes have C == 6)
   for (uint32_t base = 0; base < maxtodo; base += CH, cur ^= 1) {

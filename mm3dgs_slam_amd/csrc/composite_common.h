@@ -86,6 +86,11 @@ __device__ __forceinline__ void wave_prio_by_steps(uint32_t steps, uint32_t mean
   else if (16u * steps >= 18u * mean_steps) __builtin_amdgcn_s_setprio(1);
 }
 __device__ __forceinline__ void wave_prio_reset() { __builtin_amdgcn_s_setprio(0); }
+// the reference length, honoured only while image_state's workgroup -> tile table is valid for this image (the word is written with the table:
+// a state buffer that never saw tile_order_kernel, a generic entry point, another image size leave it stale -- ADVICE round 5); 0 = no priorities
+__device__ __forceinline__ uint32_t wave_mean_steps(const CamDev& cam, const ImageView& iv) {
+  return (cam.tile_table && iv.hdr->tile_order_tiles == tile_order_key(cam.H, cam.W)) ? iv.hdr->mean_wave_steps : 0u;
+}
 // (Re-deciding the priority every chunk from what is LEFT of the walk against what is left of a mean walk -- longest-remaining-first -- measured no better:
 // sort + forward 31.9 against 31.5 us, the other two unchanged, the hand-held sweep the same; round 5.)
 

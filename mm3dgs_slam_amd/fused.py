@@ -724,6 +724,20 @@ class FusedMapper(Mapper):
                 n += 1
             return n
 
+        try:
+            self._map_loop_body(eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, piggyback, splatam, dens, run_length)
+        except BaseException:
+            #  an exception after sharded optimiser steps -- a failing check, a prune that raises, a collective error -- must not
+            # leave every rank with fresh Adam moments for its own slice only: SLAM.run goes on to write the map.  Gather them if the
+            # process group still answers; if it does not, say so in the state the writers look at.
+            if multi and getattr(self, "_moments_stale", False):
+                try:
+                    self._sync_moments(eng)
+                except Exception:      # noqa: BLE001 -- the original exception is the one to report
+                    self.window_incoherent = True
+            raise
+
+    def _map_loop_body(self, eng, g, m, lcfg, num_iter, multi, pop, view_of, prune_at, piggyback, splatam, dens, run_length):
         with torch.no_grad():
             iteration = 0
             prepared = None      # (first iteration, views, table) of a run whose host side was built while the GPU was still busy
@@ -970,6 +984,8 @@ class FusedMapper(Mapper):
         P = int(g._xyz.shape[0])
         n = 14 * P
         S, lo, hi = w.shard_bounds(n)
+        self._shard_buffers(eng, P)      # (sized at the last sharded step: the map may have changed size since -- ADVICE round 5)
+        assert eng._shard_S == (S, w.world) and eng.pflat.numel() >= w.world * S
         groups = self._flat_groups(P)
         for key in ("exp_avg", "exp_avg_sq"):
             for group, p, st, a, b in groups:
