@@ -104,16 +104,18 @@ __device__ __forceinline__ void pose_chain_record(const CamDev& cam, const float
                                                   float* __restrict__ rec) {
   // covariance chain: (gA, gB, gC) = d/d(conic) -> dm, column by column (unit inputs through slam_bwd_body's expressions)
   const float a = e.a, b = e.b, c = e.c;
-  const float det = a * c - b * b, id2 = 1.f / (det * det);
+  const float det = a * c - b * b, idet = 1.f / det;
   const float tz = e.t[2], itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
   float Kq[3][3];
 #pragma unroll
   for (int col = 0; col < 3; col++) {
     // Kq's columns act on (Mxx, Mxy, Myy): gA = -1/2 Mxx, gB = -Mxy, gC = -1/2 Myy
     const float gA = col == 0 ? -0.5f : 0.f, gB = col == 1 ? -1.f : 0.f, gC = col == 2 ? -0.5f : 0.f;
-    const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
-    const float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
-    const float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+    // (G2 as 1/det [[gC, -gB/2], [-gB/2, gA]] + kappa adj(Sigma2): see slam_bwd_body)
+    const float kappa = -(c * gA - b * gB + a * gC) * idet * idet;
+    const float da = gC * idet + kappa * c;
+    const float db = -gB * idet - 2.f * (kappa * b);
+    const float dcc = gA * idet + kappa * a;
     float GA[2][3], dA0[3], dA1[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -633,10 +635,16 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
         ewa_project(cam, Vi, p, S3, e);
       }
       const float a = e.a, b = e.b, c = e.c;
-      const float det = a * c - b * b, id2 = 1.f / (det * det);
-      const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
-      const float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
-      const float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+      // (round 6, the bisected "d_scaling excess" of VERDICT round 5): G2 = dL/dSigma2 from dL/dconic as 1/det [[gC, -gB/2], [-gB/2, gA]] + kappa adj(Sigma2),
+      // kappa = -(c gA - b gB + a gC) / det^2 -- NOT the expanded closed form (-c^2 gA + b c gB - b^2 gC) / det^2 etc.: for a thin rotated ellipse (a c / det ~ 50)
+      // each expanded entry cancels ~75-fold on its own, and the log-scale gradient of the long axis is v^T G2 v along the axis where G2 cancels ~50-fold again:
+      // independent 2e-6 errors of the entries came out as 2e-4 (measured, /tmp-style CPU probe in float32 numpy: tools/cov_chain_probe.py).  In this form the
+      // cancelling part is ONE scalar times adj(Sigma2), whose quadratic form along the long axis is small by construction: 2e-4 -> 1.5e-5 on the same splat.
+      const float det = a * c - b * b, idet = 1.f / det;
+      const float kappa = -(c * gA - b * gB + a * gC) * idet * idet;
+      const float da = gC * idet + kappa * c;
+      const float db = -gB * idet - 2.f * (kappa * b);
+      const float dcc = gA * idet + kappa * a;
       const float G2[2][2] = {{da, 0.5f * db}, {0.5f * db, dcc}};
       float GA[2][3], dS[3][3], dA[2][3];
 #pragma unroll

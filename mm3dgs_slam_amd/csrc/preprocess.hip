@@ -253,11 +253,13 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
       ewa_project(cam, V, p, S3, e);
       float a = e.a, b = e.b, c = e.c;
       float det = a * c - b * b;
-      float id2 = 1.f / (det * det);
+      float idet = 1.f / det;
       // conic = (c, -b, a)/det  ->  d/d(a,b,c)
-      float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
-      float db = (2.f * b * c * gA - (det + 2.f * b * b) * gB + 2.f * a * b * gC) * id2;
-      float dcc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+      // (G2 as 1/det [[gC, -gB/2], [-gB/2, gA]] + kappa adj(Sigma2), not the expanded closed form: fused.hip slam_bwd_body says why)
+      float kappa = -(c * gA - b * gB + a * gC) * idet * idet;
+      float da = gC * idet + kappa * c;
+      float db = -gB * idet - 2.f * (kappa * b);
+      float dcc = gA * idet + kappa * a;
       float G2[2][2] = {{da, 0.5f * db}, {0.5f * db, dcc}};
       // GA = G2 * A (2x3)
       float GA[2][3];
