@@ -159,11 +159,19 @@ typedef struct Mm3dgsSlamInputs {
                              the full view matrix -- the covariance is rotated into the view, the pose gradient also flows through that
                              rotation, and the depth bundle takes the reference's literal z' = (w2c^T [x; 1])_z of :207-214 (the
                              transposed matrix: third COLUMN of R, no translation)                          */
+  /* ABI 209 (appended): an ACTIVE spherical-harmonics degree above 0 -- a map resumed from a checkpoint starts at its maximal degree
+   * (slam/gaussian_model.py:363), and slam/renderer.py:179-193 then hands the rasterizer shs = cat(f_dc, f_rest) with sh_degree = the active
+   * degree and campos = 0 in the shipped mode (means pre-transformed: the viewing direction is the camera-space mean, normalised).  NULL / 0:
+   * degree 0 (colour = SH_C0 f_dc + 0.5, no direction).  world_means = 1 with sh_degree > 0 is not supported (error -2).        */
+  const float* f_rest;    /* [P, n_rest, 3] GaussianModel._features_rest (n_rest = (max_sh_degree + 1)^2 - 1) or NULL    */
+  int32_t sh_degree;      /* active degree 0..3; its (sh_degree + 1)^2 - 1 first rows of f_rest are used            */
+  int32_t n_rest;         /* rows of f_rest per Gaussian                                                            */
 } Mm3dgsSlamInputs;
 
 typedef struct Mm3dgsSlamGrads {
   float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation; /* all or none (tracking) */
   float* max_radii2D; float* grad_accum; float* denom; /* [P] updated in place when max_radii2D != NULL          */
+  float* d_f_rest;        /* ABI 209 (appended): [P, n_rest, 3] with the other d_* when Mm3dgsSlamInputs.sh_degree > 0 (rows beyond the active degree: 0) */
 } Mm3dgsSlamGrads;
 
 /* Optional: the map's Adam step applied inside the backward projection kernel (no gradient round trip through HBM, one
@@ -179,6 +187,9 @@ typedef struct Mm3dgsMapAdam {
    * the Gaussians seen by >= 2 window keyframes plus the new ones, slam/mapper.py:931-936; a zero gradient still decays the moments,
    * as `p.grad[~mask] = 0` followed by optimizer.step() does).  NULL: every Gaussian. */
   const uint8_t* opt_mask;
+  /* ABI 209 (appended): the sixth group, f_rest [P, n_rest, 3] (lr = feature_lr / 20, slam/gaussian_model.py:143-195), stepped in the kernel when
+   * Mm3dgsSlamInputs.sh_degree > 0 (rows beyond the active degree take a zero gradient: moments decay, as torch's Adam does it); NULL otherwise */
+  float* rest_param; float* rest_exp_avg; float* rest_exp_avg_sq; double rest_lr;
 } Mm3dgsMapAdam;
 
 typedef struct Mm3dgsPoseAdam { /* torch.optim.Adam on (q; lr_q) and (t; lr_t); pose == NULL: no step */
@@ -397,8 +408,9 @@ const char* mm3dgs_last_error(void);
    208: mm3dgs_geom_bytes grew by the per-Gaussian pose-chain record (80 B; mm3dgs_slam_track's compositor applies it and writes no gradient
         records); the SLAM modes' block records are addressed by list position and the sorted bin (mask | per-tile record) overwrites the keys:
         binning_state / backward_scratch keep their sizes, their interior layout is the library's own; image_state must be zero-initialised
-        to at least sizeof(Mm3dgsHeader) before its first use with MM3DGS_FWD_STATE_CLEAN */
-#define MM3DGS_ABI_VERSION 208
+        to at least sizeof(Mm3dgsHeader) before its first use with MM3DGS_FWD_STATE_CLEAN
+   209: Mm3dgsSlamInputs.f_rest / sh_degree / n_rest, Mm3dgsSlamGrads.d_f_rest, Mm3dgsMapAdam.rest_* (all appended): native loops at an active SH degree > 0 */
+#define MM3DGS_ABI_VERSION 209
 int mm3dgs_version(void);
 
 #ifdef __cplusplus

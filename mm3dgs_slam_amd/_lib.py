@@ -32,17 +32,20 @@ class Mm3dgsHeader(C.Structure):
 
 class Mm3dgsSlamInputs(C.Structure):
     _fields_ = [("pose", C.c_void_p), ("xyz", C.c_void_p), ("f_dc", C.c_void_p), ("opacity", C.c_void_p),
-                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("isotropic", C.c_int32), ("world_means", C.c_int32)]
+                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("isotropic", C.c_int32), ("world_means", C.c_int32),
+                ("f_rest", C.c_void_p), ("sh_degree", C.c_int32), ("n_rest", C.c_int32)]
 
 
 class Mm3dgsSlamGrads(C.Structure):
     _fields_ = [("d_xyz", C.c_void_p), ("d_f_dc", C.c_void_p), ("d_opacity", C.c_void_p), ("d_scaling", C.c_void_p),
-                ("d_rotation", C.c_void_p), ("max_radii2D", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p)]
+                ("d_rotation", C.c_void_p), ("max_radii2D", C.c_void_p), ("grad_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("d_f_rest", C.c_void_p)]
 
 
 class Mm3dgsMapAdam(C.Structure):
     _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("lr", C.c_double * 5),
-                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32), ("opt_mask", C.c_void_p)]
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32), ("opt_mask", C.c_void_p),
+                ("rest_param", C.c_void_p), ("rest_exp_avg", C.c_void_p), ("rest_exp_avg_sq", C.c_void_p), ("rest_lr", C.c_double)]
 
 
 class Mm3dgsPoseAdam(C.Structure):

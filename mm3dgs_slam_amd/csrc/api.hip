@@ -224,6 +224,8 @@ static SlamIn slam_in(const Mm3dgsSlamInputs* in) {
   SlamIn s;
   s.pose = in->pose; s.xyz = in->xyz; s.f_dc = in->f_dc; s.opacity = in->opacity; s.scaling = in->scaling;
   s.rotation = in->rotation; s.isotropic = in->isotropic; s.world = in->world_means;
+  s.sh_deg = (in->f_rest && in->sh_degree > 0) ? in->sh_degree : 0;
+  s.f_rest = s.sh_deg ? in->f_rest : nullptr; s.n_rest = s.sh_deg ? in->n_rest : 0;
   return s;
 }
 static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in) {
@@ -234,6 +236,12 @@ static int check_slam(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInputs* in
   if (!cam->bg || !cam->projmatrix) return fail(-1, "camera device pointers missing");
   if (!in->pose) return fail(-1, "pose is NULL");
   if (P > 0 && (!in->xyz || !in->f_dc || !in->opacity || !in->scaling || !in->rotation)) return fail(-1, "NULL Gaussian parameter");
+  if (in->sh_degree < 0 || in->sh_degree > 3) return fail(-2, "sh_degree %d outside 0..3", in->sh_degree);
+  if (in->sh_degree > 0) {
+    if (P > 0 && !in->f_rest) return fail(-2, "sh_degree %d needs the f_rest rows", in->sh_degree);
+    if (in->n_rest < (in->sh_degree + 1) * (in->sh_degree + 1) - 1 || in->n_rest > 15) return fail(-2, "n_rest = %d does not hold sh_degree %d (or exceeds 15)", in->n_rest, in->sh_degree);
+    if (in->world_means) return fail(-2, "an active SH degree > 0 is native in the transform_means_python mode only");
+  }
   return 0;
 }
 
@@ -347,6 +355,9 @@ static int map_adam_dev(const Mm3dgsMapAdam* map_adam, MapAdam& ma) {
   ma.eps = (float)map_adam->eps;
   ma.bc2s = (float)sqrt(1.0 - pow(map_adam->beta2, (double)map_adam->step));
   ma.opt_mask = map_adam->opt_mask;
+  ma.rp = map_adam->rest_param; ma.rm = map_adam->rest_exp_avg; ma.rv = map_adam->rest_exp_avg_sq;
+  if (ma.rp && (!ma.rm || !ma.rv)) return fail(-2, "map Adam: the f_rest group has a NULL moment pointer");
+  ma.rest_step_size = (float)(map_adam->rest_lr / (1.0 - pow(map_adam->beta1, (double)map_adam->step)));
   ma.on = 1;
   return 0;
 }
@@ -380,6 +391,8 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     if (grads->max_radii2D && (!grads->grad_accum || !grads->denom)) return fail(-2, "statistics outputs must be all set or all NULL");
     sg.d_xyz = grads->d_xyz; sg.d_f_dc = grads->d_f_dc; sg.d_opacity = grads->d_opacity; sg.d_scaling = grads->d_scaling;
     sg.d_rotation = grads->d_rotation; sg.max_radii2D = grads->max_radii2D; sg.grad_accum = grads->grad_accum; sg.denom = grads->denom;
+    sg.d_f_rest = (all && in->sh_degree > 0) ? grads->d_f_rest : nullptr;
+    if (all && in->sh_degree > 0 && !grads->d_f_rest) return fail(-2, "sh_degree > 0: the gradient outputs need d_f_rest too");
   }
   PoseAdam pa = {};
   if (pose_adam && pose_adam->pose) {
@@ -395,7 +408,11 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
   memset(&ma, 0, sizeof(ma));
   if (map_adam)
     if (int rc2 = map_adam_dev(map_adam, ma)) return rc2;
-  const bool tracking = sg.d_xyz == nullptr && !ma.on;
+  const bool sh = in->sh_degree > 0 && in->f_rest;
+  if (sh && ma.on && !ma.rp) return fail(-2, "sh_degree > 0: the map Adam state needs the f_rest group");
+  // (an active SH degree > 0: the pose gradient runs through the colours' viewing direction, so even a tracking iteration needs the colour sums of
+  //  the mapping-layout records)
+  const bool tracking = sg.d_xyz == nullptr && !ma.on && !sh;
   if (tl && !tracking && !tl->dmaps) return fail(-1, "internal: a loss folded into the mapping backward needs the SSIM maps");
   if (pose_chain && !tracking) return fail(-1, "internal: the pose chain is a tracking-mode path");
   if (!compositor_done)
@@ -409,7 +426,7 @@ static int slam_backward_impl(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamIn
     return check_launch("slam_backward");
   }
   // mapping run, direct bins, in-kernel Adam, no pose step: this launch also projects and bins the NEXT iteration's view
-  const bool fuse = fuse_next_pose && !tracking && ma.on && db_bwd.on && !dL_dpose && !pa.pose && !sg.d_xyz;
+  const bool fuse = fuse_next_pose && !tracking && ma.on && db_bwd.on && !dL_dpose && !pa.pose && !sg.d_xyz && !sh;
   if (fused_out) *fused_out = fuse;
   if (fuse) {
     ProfScope ps(MM3DGS_PROF_PREPROCESS_BWD, s);
@@ -478,7 +495,8 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   // without SSIM every loss term is per pixel: fold the loss into the compositors (two launches and the gradient image
   // round trip less per iteration); needs the sort + forward-composite kernel (its workgroup = one 16x16 loss tile)
   const int no_fold = env_flag("MM3DGS_NO_FOLDED_LOSS", 0);   // read per call: tests compare both paths in one process
-  const bool fold = !no_fold && !loss_is_variant(loss_cfg) && loss_cfg->w_ssim == 0.f && slam_fused_sort(fwd_flags) && cam->image_height > 0 && cam->image_width > 0;
+  const bool sh = in->sh_degree > 0 && in->f_rest;      // (active SH degree > 0: standalone loss kernels, mapping-mode compositor, no pose chain -- see slam_backward_impl)
+  const bool fold = !no_fold && !sh && !loss_is_variant(loss_cfg) && loss_cfg->w_ssim == 0.f && slam_fused_sort(fwd_flags) && cam->image_height > 0 && cam->image_width > 0;
   TrackLoss tl = {};
   if (fold) {
     tl.cfg = loss_cfg_dev(loss_cfg);
@@ -499,7 +517,7 @@ int mm3dgs_slam_track(int n_iter, const Mm3dgsCamera* cam, int P, const Mm3dgsSl
   // pose row per tile: no gradient records, no per-tile combine, no backward-projection launch (three launches per iteration).  The shipped mode only
   // (means pre-transformed: the world-frame mode's pose gradient also runs through the covariance rotation); MM3DGS_NO_POSE_CHAIN keeps the record path
   // (read per call: tests compare both in one process)
-  const bool pose_chain = composite_has_pose_chain() && !in->world_means && backward_scratch && !env_flag("MM3DGS_NO_POSE_CHAIN", 0) &&
+  const bool pose_chain = composite_has_pose_chain() && !in->world_means && !sh && backward_scratch && !env_flag("MM3DGS_NO_POSE_CHAIN", 0) &&
                           bwd_bytes_impl(P, N_capacity) >= (size_t)tiles_x(cam->image_width) * tiles_y(cam->image_height) * 32 * sizeof(float);
   if (n_iter > 0) slam_refresh_tile_order(cam, image_state, fwd_flags, stream);
   for (int it = 0; it < n_iter; it++) {

@@ -155,9 +155,12 @@ __device__ __forceinline__ void pose_chain_record(const CamDev& cam, const float
   o[4] = make_float4(x[1], x[2], 0.f, 0.f);
 }
 
+// SH (ABI 209): an active degree above 0 -- colour = sum_k basis_k(dir) sh_k + 0.5, clamped at 0, with dir = the normalised CAMERA-space mean: the
+// shipped mode hands the rasterizer pre-transformed means and campos = 0 (slam/renderer.py:117-124,142-153,179-193); rest = this Gaussian's f_rest rows
+template <bool SH = false>
 __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool live, int idx, const float* __restrict__ pose, bool isotropic,
                                                        const RawGaussian& rg, int32_t* __restrict__ radii, const GeomView& g, bool world = false,
-                                                       bool want_poserec = false) {
+                                                       bool want_poserec = false, const float* __restrict__ rest = nullptr, int sh_deg = 0) {
   const float* PV = cam.proj;
   const float Vi[16] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f};
   const PoseDev ps = load_pose(pose);
@@ -206,6 +209,17 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         o.r1 = (uint32_t)maxx | ((uint32_t)maxy << 16);
         const float* fd = fd_raw;
         float c0 = SH_C0F * fd[0] + 0.5f, c1 = SH_C0F * fd[1] + 0.5f, c2 = SH_C0F * fd[2] + 0.5f;
+        if constexpr (SH) {
+          const float inv = 1.f / sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+          float bb[16];
+          sh_basis(sh_deg, p[0] * inv, p[1] * inv, p[2] * inv, bb);
+          const int nb = (sh_deg + 1) * (sh_deg + 1);
+          c0 = bb[0] * fd[0]; c1 = bb[0] * fd[1]; c2 = bb[0] * fd[2];
+#pragma unroll
+          for (int k = 1; k < 16; k++)
+            if (k < nb) { c0 += bb[k] * rest[(k - 1) * 3]; c1 += bb[k] * rest[(k - 1) * 3 + 1]; c2 += bb[k] * rest[(k - 1) * 3 + 2]; }
+          c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+        }
         o.cl = (c0 < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u);
         g.clamped[idx] = (uint8_t)o.cl;
         // (the depth the tiles are SORTED by is the view depth p[2] in both modes; zc is the value the depth bundle composites)
@@ -234,6 +248,7 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
   return o;
 }
 
+template <bool SH = false>
 __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, int idx, const SlamIn& in, int32_t* __restrict__ radii,
                                                       const GeomView& g, bool want_poserec = false) {
   const bool live = idx < P;
@@ -249,9 +264,11 @@ __device__ __forceinline__ Projected slam_project_one(const CamDev& cam, int P, 
     for (int k = 0; k < 3; k++) { rg.ls[k] = in.scaling[(size_t)idx * 3 + k]; rg.fd[k] = in.f_dc[(size_t)idx * 3 + k]; }
     rg.op = in.opacity[idx];
   }
-  return slam_project_vals(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g, in.world != 0, want_poserec);
+  return slam_project_vals<SH>(cam, live, idx, in.pose, in.isotropic != 0, rg, radii, g, in.world != 0, want_poserec,
+                               SH ? in.f_rest + (size_t)(live ? idx : 0) * (size_t)in.n_rest * 3 : nullptr, in.sh_deg);
 }
 
+template <bool SH>
 __global__ void __launch_bounds__(FB)
 slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, int lds_tiles,
                            int vis_only, uint32_t* __restrict__ seen, int want_poserec) {
@@ -261,7 +278,7 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
   if (lds_tiles) __syncthreads();
   const int idx = blockIdx.x * FB + threadIdx.x;
   const bool live = idx < P;
-  const Projected pr = slam_project_one(cam, P, idx, in, radii, g, want_poserec != 0);
+  const Projected pr = slam_project_one<SH>(cam, P, idx, in, radii, g, want_poserec != 0);
   const uint32_t r0 = pr.r0, r1 = pr.r1, nblk = pr.nblk;
   const int32_t rad = pr.rad;
   if (vis_only) {      // mm3dgs_slam_visibility: the projection stage alone (workgroup-uniform): no tile counting, no scans
@@ -311,8 +328,12 @@ void launch_slam_preprocess_fwd(const CamDev& cam, int P, const SlamIn& in, int3
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
   const int lds_tiles = (T <= MAX_LDS_TILES && !visibility_only) ? T : 0;
-  hipLaunchKernelGGL(slam_preprocess_fwd_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
-                     iv, lds_tiles, visibility_only ? 1 : 0, seen, want_poserec ? 1 : 0);
+  if (in.sh_deg > 0)
+    hipLaunchKernelGGL(slam_preprocess_fwd_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
+                       iv, lds_tiles, visibility_only ? 1 : 0, seen, 0);
+  else
+    hipLaunchKernelGGL(slam_preprocess_fwd_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)lds_tiles * 4, s, cam, P, in, radii, g,
+                       iv, lds_tiles, visibility_only ? 1 : 0, seen, want_poserec ? 1 : 0);
 }
 
 // ---- projection + binning in ONE launch (direct bins) -----------------------------------------------------------------------------
@@ -458,6 +479,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   }
 }
 
+template <bool SH>
 __global__ void __launch_bounds__(FB)
 slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radii, GeomView g, ImageView iv, BinView b, uint32_t cap,
                         uint32_t rec_cap, int slot_bits, int want_poserec) {
@@ -467,7 +489,7 @@ slam_project_bin_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ radi
   for (int t = tid; t < T; t += FB) hist[t] = 0;
   if (blockIdx.x == 0 && tid == 0) iv.hdr->bin_cap = cap;
   const int idx = blockIdx.x * FB + tid;
-  const Projected pr = slam_project_one(cam, P, idx, in, radii, g, want_poserec != 0);
+  const Projected pr = slam_project_one<SH>(cam, P, idx, in, radii, g, want_poserec != 0);
   slam_bin_pairs(cam, P, idx, pr, g, iv, b, cap, rec_cap, slot_bits, hist);
 }
 
@@ -475,8 +497,11 @@ void launch_slam_project_bin(const CamDev& cam, int P, const SlamIn& in, int32_t
                              uint32_t rec_cap, int slot_bits, hipStream_t s, bool want_poserec) {
   if (P <= 0) return;
   const int T = cam.gx * cam.gy;
-  hipLaunchKernelGGL(slam_project_bin_kernel, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits,
-                     want_poserec ? 1 : 0);
+  if (in.sh_deg > 0)
+    hipLaunchKernelGGL(slam_project_bin_kernel<true>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits, 0);
+  else
+    hipLaunchKernelGGL(slam_project_bin_kernel<false>, dim3((P + FB - 1) / FB), dim3(FB), (size_t)T * 4, s, cam, P, in, radii, g, iv, b, bin_cap, rec_cap, slot_bits,
+                       want_poserec ? 1 : 0);
 }
 
 // Sum of a Gaussian's per-tile gradient records (composite.hip's per-tile combine: one record per (tile, splat) pair, the pairs of a
@@ -534,7 +559,9 @@ __device__ __forceinline__ void gather_tile_records(int area, uint32_t first, co
 // ---------------------------------------------------------------------------------------------------------------------
 #define NPOSE 12  // dR (9, row-major) | dt (3)
 // stepped: (the map's in-kernel Adam, ma.on) the lane's parameters AFTER the step -- what the next iteration's projection reads
-template <bool TRACK, bool DIRECT, bool WORLD = false>
+// SH (ABI 209, active degree > 0; mapping-layout records -- the colour sums -- also when only the pose gradient is wanted): d/d(f_rest), the
+// direction's share of d/d(mean) (into dm: the means and the pose), the sixth Adam group
+template <bool TRACK, bool DIRECT, bool WORLD = false, bool SH = false>
 __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const SlamIn& in, const int32_t* __restrict__ radii, const GeomView& g,
                                               uint32_t N_cap, const float* __restrict__ dsub, float* __restrict__ posepartial, const SlamGrads& out,
                                               const MapAdam& ma, RawGaussian* stepped, const uint32_t* __restrict__ ovf) {
@@ -598,6 +625,11 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
     // while the chain rule below is evaluated
     constexpr int AG_OFF[5] = {0, 3, 6, 7, 10}, AG_N[5] = {3, 3, 1, 3, 4};
     float ap[14], am[14], av[14];
+    float shb[16], shg[3] = {0.f, 0.f, 0.f};      // (SH) basis values at this Gaussian's direction, clamp-masked colour gradient: zero for an invisible Gaussian
+    if constexpr (SH) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) shb[k] = 0.f;
+    }
     if (ma.on) {
 #pragma unroll
       for (int gq = 0; gq < 5; gq++)
@@ -701,6 +733,28 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
 #pragma unroll
       for (int i = 0; i < 3; i++) dm[i] += PV[i * 4 + 0] * dhx + PV[i * 4 + 1] * dhy + PV[i * 4 + 3] * dhw;
       if (!world) dm[2] += dz_tot;          // transform mode: the depth bundle's z IS the camera-space z
+      if constexpr (SH) {
+        // colour = clamp(sum_k b_k(dir) sh_k + 0.5), dir = p / |p|: the basis values weight the coefficient gradients, the basis' direction
+        // derivative runs through the normalisation into dm (and from there into the means and the pose)
+        static_assert(!TRACK && !WORLD, "the SH path runs on mapping-layout records, pre-transformed means");
+        const float pinv = 1.f / sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+        const float ux = p[0] * pinv, uy = p[1] * pinv, uz = p[2] * pinv;
+        sh_basis(in.sh_deg, ux, uy, uz, shb);
+        float gbx[16], gby[16], gbz[16];
+        sh_basis_grad(in.sh_deg, ux, uy, uz, gbx, gby, gbz);
+        const int nb = (in.sh_deg + 1) * (in.sh_deg + 1);
+        shg[0] = (cl_bits & 1) ? 0.f : dc0; shg[1] = (cl_bits & 2) ? 0.f : dc1; shg[2] = (cl_bits & 4) ? 0.f : dc2;
+        const float* rest = in.f_rest + (size_t)idx * (size_t)in.n_rest * 3;
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+        for (int k = 1; k < 16; k++)
+          if (k < nb) {
+            const float tk = rest[(k - 1) * 3] * shg[0] + rest[(k - 1) * 3 + 1] * shg[1] + rest[(k - 1) * 3 + 2] * shg[2];
+            ddx += gbx[k] * tk; ddy += gby[k] * tk; ddz += gbz[k] * tk;
+          }
+        const float dot = ux * ddx + uy * ddy + uz * ddz;
+        dm[0] += (ddx - ux * dot) * pinv; dm[1] += (ddy - uy * dot) * pinv; dm[2] += (ddz - uz * dot) * pinv;
+      }
       // pose: means_cam = R x + t
       cg[0] = dm[0] * x0; cg[1] = dm[0] * x1; cg[2] = dm[0] * x2;
       cg[3] = dm[1] * x0; cg[4] = dm[1] * x1; cg[5] = dm[1] * x2;
@@ -718,7 +772,7 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
 #pragma unroll
         for (int j = 0; j < 3; j++) dxyz[j] = ps.R[0][j] * dm[0] + ps.R[1][j] * dm[1] + ps.R[2][j] * dm[2] + (world ? dz_tot * ps.R[j][2] : 0.f);
         const uint32_t cl = cl_bits;
-        dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;
+        dfd[0] = (cl & 1) ? 0.f : SH_C0F * dc0;      // (SH_C0 = the degree-0 basis value)
         dfd[1] = (cl & 2) ? 0.f : SH_C0F * dc1;
         dfd[2] = (cl & 4) ? 0.f : SH_C0F * dc2;
         const float o = 1.f / (1.f + expf(-op_raw));
@@ -767,6 +821,18 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
       out.d_scaling[(size_t)idx * 3] = dls[0]; out.d_scaling[(size_t)idx * 3 + 1] = dls[1]; out.d_scaling[(size_t)idx * 3 + 2] = dls[2];
       out.d_rotation[(size_t)idx * 4] = dqr[0]; out.d_rotation[(size_t)idx * 4 + 1] = dqr[1];
       out.d_rotation[(size_t)idx * 4 + 2] = dqr[2]; out.d_rotation[(size_t)idx * 4 + 3] = dqr[3];
+      if constexpr (SH) {
+        if (out.d_f_rest) {
+          float* o = out.d_f_rest + (size_t)idx * (size_t)in.n_rest * 3;
+          const int nb = (in.sh_deg + 1) * (in.sh_deg + 1);
+#pragma unroll
+          for (int k = 1; k < 16; k++)
+            if (k - 1 < in.n_rest) {
+              const float bk = k < nb ? shb[k] : 0.f;
+              o[(k - 1) * 3] = bk * shg[0]; o[(k - 1) * 3 + 1] = bk * shg[1]; o[(k - 1) * 3 + 2] = bk * shg[2];
+            }
+        }
+      }
     }
     if (ma.on) {
       // the map's Adam step for this Gaussian (every Gaussian, visible or not: zero gradients still decay the moments)
@@ -787,6 +853,27 @@ __device__ __forceinline__ void slam_bwd_body(const CamDev& cam, int P, const Sl
           ap[q] = ap[q] - ma.step_size[gq] * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
           ma.p[gq][off] = ap[q];
         }
+      if constexpr (SH) {
+        if (ma.rp) {      // the sixth group: every f_rest row steps (zero gradient beyond the active degree / for an invisible Gaussian: the moments decay)
+          const int nb = (in.sh_deg + 1) * (in.sh_deg + 1);
+          const size_t base = (size_t)idx * (size_t)in.n_rest * 3;
+#pragma unroll
+          for (int k = 1; k < 16; k++)
+            if (k - 1 < in.n_rest) {
+              const float bk = k < nb ? keepg * shb[k] : 0.f;
+#pragma unroll
+              for (int ch = 0; ch < 3; ch++) {
+                const size_t off = base + (size_t)(k - 1) * 3 + ch;
+                const float gr = bk * shg[ch];
+                const float m0 = ma.rm[off], v0 = ma.rv[off];
+                const float mi = m0 + (gr - m0) * ma.omb1;
+                const float vi = v0 * ma.beta2 + gr * gr * ma.omb2;
+                ma.rm[off] = mi; ma.rv[off] = vi;
+                ma.rp[off] = ma.rp[off] - ma.rest_step_size * (mi / (sqrtf(vi) / ma.bc2s + ma.eps));
+              }
+            }
+        }
+      }
       }
       if (stepped) {      // AG layout: xyz 0-2 | f_dc 3-5 | opacity 6 | scaling 7-9 | rotation 10-13
 #pragma unroll
@@ -1110,12 +1197,12 @@ __global__ void __launch_bounds__(1024) slam_pose_finish_kernel(const float* __r
 // The backward projection of an iteration that needs the pose gradient (every tracking iteration; mapping views under bundle adjustment).
 // (The pose finish in the LAST workgroup of this launch -- a ticket counter -- was measured and rejected: 25 .. 32 us against 9.1 + 6.8 for the two
 // launches; the finish stays a one-workgroup launch of its own, slam_pose_finish_kernel.)
-template <bool TRACK, bool DIRECT, bool WORLD>
+template <bool TRACK, bool DIRECT, bool WORLD, bool SH = false>
 __global__ void __launch_bounds__(SLAM_BWD_FB)
 slam_preprocess_bwd_kernel(CamDev cam, int P, SlamIn in, const int32_t* __restrict__ radii, GeomView g, BinView bn, uint32_t N_cap,
                            const float* __restrict__ dsub, float* __restrict__ posepartial, SlamGrads out, MapAdam ma,
                            const uint32_t* __restrict__ ovf) {
-  slam_bwd_body<TRACK, DIRECT, WORLD>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
+  slam_bwd_body<TRACK, DIRECT, WORLD, SH>(cam, P, in, radii, g, N_cap, dsub, posepartial, out, ma, nullptr, ovf);
 }
 
 // The pose finish alone, over the per-TILE rows the tracking compositor's pose chain wrote (composite.hip): rows[nrows][32] floats.
@@ -1133,12 +1220,17 @@ void launch_slam_preprocess_bwd(const CamDev& cam, int P, const SlamIn& in, cons
   float* partial = want_pose ? bw.campartial : nullptr;
   const PoseLossScale none = {nullptr, 0, 0.f, nullptr};
   if (P > 0) {
-    const bool map = out.d_xyz || ma.on;
+    const bool map = out.d_xyz || ma.on || in.sh_deg > 0;      // (an active SH degree > 0 runs on mapping-layout records even when only the pose gradient is wanted)
+    if (in.sh_deg > 0) {
+      auto ksh = direct ? slam_preprocess_bwd_kernel<false, true, false, true> : slam_preprocess_bwd_kernel<false, false, false, true>;
+      hipLaunchKernelGGL(ksh, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
+    } else {
     auto kern = in.world ? (map ? (direct ? slam_preprocess_bwd_kernel<false, true, true> : slam_preprocess_bwd_kernel<false, false, true>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, true> : slam_preprocess_bwd_kernel<true, false, true>))
                          : (map ? (direct ? slam_preprocess_bwd_kernel<false, true, false> : slam_preprocess_bwd_kernel<false, false, false>)
                                 : (direct ? slam_preprocess_bwd_kernel<true, true, false> : slam_preprocess_bwd_kernel<true, false, false>));
     hipLaunchKernelGGL(kern, dim3((P + SLAM_BWD_FB - 1) / SLAM_BWD_FB), dim3(SLAM_BWD_FB), 0, s, cam, P, in, radii, g, b, ncap, bw.dsub, partial, out, ma, ovf);
+    }
   }
   if (want_pose) {
     // (rows = workgroups of the launch above; the partial-row region is sized for 256-lane workgroups writing double rows, i.e. it holds

@@ -6,14 +6,17 @@ struct SlamIn {
   const float* pose; const float* xyz; const float* f_dc; const float* opacity; const float* scaling; const float* rotation;
   int isotropic;
   int world;     // Mm3dgsSlamInputs.world_means
+  const float* f_rest; int sh_deg; int n_rest;      // active SH degree > 0 (ABI 209): rows [P][n_rest][3]; sh_deg == 0: unused
 };
 struct SlamGrads {
   float* d_xyz; float* d_f_dc; float* d_opacity; float* d_scaling; float* d_rotation;
   float* max_radii2D; float* grad_accum; float* denom;
+  float* d_f_rest;
 };
 // Adam scalars as torch.optim.Adam applies them: formed in double on the host, rounded once to float.
 //   omb1 = 1 - beta1 (lerp weight), beta2, omb2 = 1 - beta2, step_size = lr / (1 - beta1^t) per group, bc2s = sqrt(1 - beta2^t)
-struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; const uint8_t* opt_mask; };
+struct MapAdam { float* p[5]; float* m[5]; float* v[5]; float step_size[5]; float omb1, beta2, omb2, eps, bc2s; int on; const uint8_t* opt_mask;
+                 float* rp; float* rm; float* rv; float rest_step_size; };      // (the sixth group: f_rest, active SH degree > 0)
 struct PoseAdam { float* pose; float* m; float* v; int* step; double lr_q, lr_t, beta1, beta2; float eps; const float* prior; float prior_w_t, prior_w_q; float* best; };
 struct AdamGroup { float* p; const float* g; float* m; float* v; unsigned long long n; float step_size; };
 struct AdamArgs { AdamGroup grp[8]; int ngroups; float omb1, beta2, omb2, eps, bc2s; };

@@ -87,16 +87,22 @@ class FusedEngine:
         # transform_means_python: false (world-frame means, pose gradient through the view matrix) runs natively too: Mm3dgsSlamInputs.world_means
         # (with the reference's literal depth bundle; this repository's optional `fix_depth_transpose` only exists in the torch-graph renderer)
         fixed_depth = (not pipe["transform_means_python"]) and pipe.get("fix_depth_transpose", False)
-        ok = (not pipe["compute_cov3D_python"] and not fixed_depth and gaussians.active_sh_degree == 0 and str(cfg["device"]).startswith("cuda"))
+        # round 6 (ABI 209): an ACTIVE degree above 0 (a map resumed from a checkpoint, slam/gaussian_model.py:363) runs natively too -- the kernels evaluate
+        # the SH colour at the normalised camera-space mean (what slam/renderer.py:179-193 hands the rasterizer in the shipped mode: means pre-transformed,
+        # campos = 0), step f_rest as a sixth Adam group and carry the direction's share of the pose / mean gradients -- in the shipped mode with the
+        # kernel's own SH evaluation; `convert_SHs_python` (directions taken from the WORLD means in Python) and the world-frame mode stay on the torch-graph loops
+        sh_native = gaussians.active_sh_degree == 0 or (pipe["transform_means_python"] and not pipe["convert_SHs_python"] and gaussians.active_sh_degree <= 3
+                                                        and int(gaussians._features_rest.shape[1]) <= 15)
+        ok = (not pipe["compute_cov3D_python"] and not fixed_depth and sh_native and str(cfg["device"]).startswith("cuda"))
         if not ok and str(cfg["device"]).startswith("cuda"):
             # (the fallback is ~30x slower and used to be silent)
             why = ", ".join(w for w, bad in (("pipeline.compute_cov3D_python: true", pipe["compute_cov3D_python"]),
                                              ("pipeline.fix_depth_transpose", fixed_depth),
-                                             (f"active SH degree {gaussians.active_sh_degree} > 0", gaussians.active_sh_degree != 0)) if bad)
+                                             (f"active SH degree {gaussians.active_sh_degree} > 0 with convert_SHs_python / world-frame means", not sh_native)) if bad)
             if why not in FusedEngine._warned:
                 FusedEngine._warned.add(why)
                 import warnings
-                warnings.warn(f"mm3dgs: this configuration ({why}) is outside the native SLAM loops (covariances from scales + rotations, active SH degree 0); "
+                warnings.warn(f"mm3dgs: this configuration ({why}) is outside the native SLAM loops (covariances from scales + rotations; an active SH degree > 0 only in the shipped mode with the kernel's SH evaluation); "
                               "tracking and mapping run the torch-graph loops around the generic HIP rasterizer -- correct, but about 30x slower")
         return ok
 
@@ -141,6 +147,19 @@ class FusedEngine:
             v = lambda i, shape: self.flat[o[i]:o[i + 1]].view(shape)
             self.grads = dict(xyz=v(0, (P, 3)), f_dc=v(1, (P, 1, 3)), opacity=v(2, (P, 1)), scaling=v(3, (P, 3)), rotation=v(4, (P, 4)))
             self.stat_delta = (torch.zeros(P, device=self.dev), v(5, (P, 1)), v(6, (P, 1)))   # max radii | accum | denom
+            self._rest_rows = None
+
+    def rest_grad(self, g):
+        """Gradient buffer of the f_rest rows [P, n_rest, 3] for a model at an active SH degree > 0 (None at degree 0): what
+        Mm3dgsSlamGrads.d_f_rest points at whenever the other gradient outputs are set."""
+        if int(getattr(g, "active_sh_degree", 0)) <= 0:
+            return None
+        shape = tuple(g._features_rest.shape)
+        if getattr(self, "_rest_rows", None) is None or tuple(self._rest_rows.shape) != shape:
+            self._rest_rows = torch.zeros(shape, device=self.dev)
+            if self.grads is not None:
+                self.grads["f_rest"] = self._rest_rows
+        return self._rest_rows
 
     def _flags(self):
         """STATE_CLEAN | SHORT_LISTS (hint from the last header check) | DIRECT_BINS (the capacity was sized per tile)."""
@@ -153,12 +172,16 @@ class FusedEngine:
         si.scaling, si.rotation = g._scaling.data_ptr(), g._rotation.data_ptr()
         si.isotropic = self.isotropic
         si.world_means = 0 if self.r.cfg["pipeline"]["transform_means_python"] else 1
+        deg = int(getattr(g, "active_sh_degree", 0))
+        if deg > 0:      # (ABI 209) the rows the kernels evaluate / step natively
+            si.f_rest, si.sh_degree, si.n_rest = g._features_rest.data_ptr(), deg, int(g._features_rest.shape[1])
         return si
 
     def forward(self, pose, g, need_grads=False):
         P = int(g._xyz.shape[0])
         self._ensure(P, need_grads)
         si = self.inputs(pose, g)
+        self._last_g = g
         flags = self._flags()
         _lib.check(self.lib.mm3dgs_slam_forward(C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
                                                 _p(self.img_state), _p(self.binning), self.n_cap, flags, _stream()))
@@ -214,6 +237,9 @@ class FusedEngine:
             if grads is not None:
                 sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
                 sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
+                rest = self.rest_grad(g)
+                if rest is not None:
+                    sg.d_f_rest = rest.data_ptr()
         flags = self._flags() | (_lib.FWD_KEEP_TILE_ORDER if keep_tile_order else 0) | (_lib.FWD_PROJECTED if projected else 0)
         self._views_keepalive = views      # the device work is asynchronous
         _lib.check(self.lib.mm3dgs_slam_map(len(views), arr, C.byref(self.cam), P, C.byref(si), _p(self.out), _p(self.radii), _p(self.geom),
@@ -310,6 +336,9 @@ class FusedEngine:
         if grads is not None:
             sg.d_xyz, sg.d_f_dc, sg.d_opacity = grads["xyz"].data_ptr(), grads["f_dc"].data_ptr(), grads["opacity"].data_ptr()
             sg.d_scaling, sg.d_rotation = grads["scaling"].data_ptr(), grads["rotation"].data_ptr()
+            rest = self.rest_grad(self._last_g) if getattr(self, "_last_g", None) is not None else None
+            if rest is not None:
+                sg.d_f_rest = rest.data_ptr()
         if stats is not None:
             sg.max_radii2D, sg.grad_accum, sg.denom = (t.data_ptr() for t in stats)
         _lib.check(self.lib.mm3dgs_slam_backward(C.byref(self.cam), self.P, C.byref(si), _p(self.radii), _p(self.geom), _p(self.img_state),
@@ -553,7 +582,8 @@ class FusedMapper(Mapper):
                      curr_gt_depth=None, curr_est_depth=None):
         m = self.cfg["mapping"]
         do_ba = bool(m["do_BA"]) and idx > 0
-        if num_iter == 0 or not FusedEngine.eligible(self.cfg, self.gaussians):
+        sh_window = int(self.gaussians.active_sh_degree) > 0 and self.window is not None      # (the sharded window's flat gradient layout has no f_rest rows)
+        if num_iter == 0 or sh_window or not FusedEngine.eligible(self.cfg, self.gaussians):
             return super().optimize_map(idx, num_iter, keyframe_idx_list, new_gaussians_mask, curr_camera_tensor, curr_gt_color,
                                         curr_gt_depth, curr_est_depth)
         eng = _engine(self.renderer)
@@ -902,6 +932,17 @@ class FusedMapper(Mapper):
             step_val = first if step_val is None else step_val
             ma.param[i], ma.exp_avg[i], ma.exp_avg_sq[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             ma.lr[i] = float(group["lr"])
+        if int(self.gaussians.active_sh_degree) > 0:      # (ABI 209) the sixth group: f_rest, stepped in the kernel at an active SH degree > 0
+            group = next(gr for gr in opt.param_groups if gr["name"] == "f_rest")
+            p = group["params"][0]
+            st = opt.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += n
+            ma.rest_param, ma.rest_exp_avg, ma.rest_exp_avg_sq = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            ma.rest_lr = float(group["lr"])
         b1, b2 = opt.param_groups[0]["betas"]
         ma.beta1, ma.beta2, ma.eps, ma.step = float(b1), float(b2), float(opt.param_groups[0]["eps"]), step_val
         if getattr(self, "_opt_mask", None) is not None:

@@ -32,7 +32,7 @@ sys.path.insert(1, ROOT)
 import make_golden as mg          # noqa: E402  (puts /root/reference first on sys.path, stubs the absent third-party modules)
 
 H, W, N_FRAMES, N_SEED = 48, 64, 5, 2500
-SHORT = {"no_transform": 3, "sh2_python": 3, "white_bg": 3}          # frames of the short variants
+SHORT = {"no_transform": 3, "sh2_python": 3, "white_bg": 3, "sh2_active": 3}          # frames of the short variants
 PREFIX = "g9"
 # --large (round 4): the same runs at 160x120 -- 80 tiles instead of 12, ~18 k Gaussians (one per valid pixel of frame 0, as the reference
 # seeds), 8 frames, keyframes 0 / 2 / 4 / 6 -- so that the native kernels' machinery (direct bins, XCD tile map, load-balanced tile table,
@@ -44,7 +44,7 @@ LARGE = "--large" in sys.argv
 if LARGE:
     sys.argv.remove("--large")
     H, W, N_FRAMES, N_SEED = 120, 160, 8, 16000
-    SHORT = {"no_transform": 4, "sh2_python": 4, "white_bg": 4}
+    SHORT = {"no_transform": 4, "sh2_python": 4, "white_bg": 4, "sh2_active": 4}
     PREFIX = "g9L"
 # --shipped (round 5): 160x120 again, but with the schedule the reference SHIPS and the benchmark times (configs/TUM.yml:32,44-75: 100 tracking /
 # 150 mapping iterations, pruning_interval 50 -- with its no-op Adam steps at mapping iterations 0 and 50 --, min_opacity 0.005, kf_every 5,
@@ -99,6 +99,12 @@ VARIANTS = {
     "no_transform": dict(pipeline={"transform_means_python": False}, tracking={"iters": 8}, mapping=dict(_MAP, iters=12)),
     "sh2_python": dict(pipeline={"convert_SHs_python": True}, tracking={"iters": 8}, mapping=dict(_MAP, iters=12, sh_degree=2)),
     "white_bg": dict(white_background=True, tracking={"iters": 8}, mapping=dict(_MAP, iters=12)),
+    # round 6: an ACTIVE SH degree above 0 with the rasterizer's own SH evaluation -- the state of a map resumed from a checkpoint
+    # (slam/gaussian_model.py:363 load_ply: active_sh_degree = max_sh_degree; oneupSHdegree is never called on the SLAM path): slam/renderer.py:179-193
+    # hands shs = cat(f_dc, f_rest) and sh_degree = 2 to the rasterizer, with the pre-transformed means and campos = 0 of the shipped mode -- f_rest rows
+    # (seeded at zero, slam/mapper.py:644-668) receive gradients and are stepped at feature_lr / 20, and the viewing direction carries gradient into
+    # the means and the tracked pose.  ("_resumed_sh" is the fixture's own key: stripped before the reference's configuration is built)
+    "sh2_active": dict(tracking={"iters": 8}, mapping=dict(_MAP, iters=12, sh_degree=2), _resumed_sh=True),
     "imu": dict(pipeline={"force_isotropic": True},
                 tracking={"iters": 10, "dynamics_model": "imu", "use_depth_estimate_loss": True, "pearson_weight": 0.001, "position_lr": 0.002,
                           "rotation_lr": 0.002},
@@ -172,13 +178,16 @@ def run_reference(name, overrides, frames, gt_poses, imu, tstamps, mono, mono_sc
         ref_renderer.GaussianRasterizer = RefRasterizer                     # the names slam/renderer.py:15-18 binds
         ref_renderer.GaussianRasterizationSettings = RefSettings
         torch.manual_seed(0); random.seed(0); np.random.seed(0)
-        rcfg = default_config(device="cpu", height=H, width=W, **overrides)   # (the TUM.yml schema as a dict: configuration, not code)
+        resumed_sh = bool(overrides.get("_resumed_sh", False))
+        rcfg = default_config(device="cpu", height=H, width=W, **{k: v for k, v in overrides.items() if not k.startswith("_")})   # (the TUM.yml schema as a dict: configuration, not code)
         n_frames = SHORT.get(name, N_FRAMES)
         est = torch.zeros(n_frames, 7)
         use_imu = rcfg["tracking"]["dynamics_model"].lower() == "imu"                      # (slam/SLAM.py:44)
         ns = types.SimpleNamespace(cfg=rcfg, gaussians=ref_gm.GaussianModel(rcfg), n_img=n_frames, estimate_pose_list=est,
                                    gt_pose_list=torch.zeros(n_frames, 7), use_imu=use_imu, tf={"c2i": torch.eye(4)}, tstamps=tstamps)
         ns.gaussians.training_setup()
+        if resumed_sh:      # what load_ply leaves behind (slam/gaussian_model.py:363)
+            ns.gaussians.active_sh_degree = ns.gaussians.max_sh_degree
         ns.renderer = ref_renderer.Renderer(rcfg)
         mapper, tracker = ref_mapper.Mapper(ns), ref_tracker.Tracker(ns)
         per_frame, kf_lists, kf_poses = [], [], None

@@ -35,19 +35,22 @@ class _Frames:
         return self.frames[i][0], self.frames[i][1], self.poses[i]
 
 
-@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "no_transform", "sh2_python", "white_bg"])
+@pytest.mark.parametrize("variant", ["vigs", "vigs_rotfrozen", "splatam", "ba", "imu", "estdepth", "no_transform", "sh2_python", "white_bg", "sh2_active"])
 def test_torch_graph_loops_reproduce_the_reference_classes_end_to_end(variant):
     from mm3dgs_slam_amd.config import default_config
     from mm3dgs_slam_amd.slam import SLAM
     F = np.load(os.path.join(HERE, "golden", "g9_frames.npz"))
     G = np.load(os.path.join(HERE, "golden", f"g9_{variant}.npz"))
     overrides = ast.literal_eval(str(G["overrides"]))          # a dict literal written by the generator
+    resumed_sh = bool(overrides.pop("_resumed_sh", False))     # (round 6, `sh2_active`: the reference run raised active_sh_degree like load_ply does, slam/gaussian_model.py:363)
     cfg = default_config(device="cpu", height=int(F["H"]), width=int(F["W"]), **overrides)
     n = G["est_poses"].shape[0]                                            # (the renderer-branch variants run 3 of the 5 frames)
     seq = _Frames(F["color"][:n], F["depth"][:n], F["gt_poses"][:n], F["imu"][:n], F["tstamps"][:n])
     use_imu = cfg["tracking"]["dynamics_model"].lower() == "imu"
     torch.manual_seed(0); random.seed(0); np.random.seed(0)
     slam = SLAM(cfg, seq, rasterizer_cls=RefRasterizer, render_mode="reference", native_loops=False)
+    if resumed_sh:
+        slam.gaussians.active_sh_degree = slam.gaussians.max_sh_degree
     want_kf = [[int(v) for v in s.split(",")] for s in G["keyframes"]]
     from mm3dgs_slam_amd.pose_utils import get_camera_from_tensor
     aligned = True      # the two maps still have the same rows
