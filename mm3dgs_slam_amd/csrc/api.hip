@@ -644,6 +644,7 @@ int mm3dgs_slam_adam_project(const Mm3dgsCamera* cam, int P, const Mm3dgsSlamInp
                              int32_t* radii, void* geom_state, void* image_state, void* binning_state, size_t N_capacity, int fwd_flags, void* stream) {
   int rc = check_slam(cam, P, in);
   if (rc) return rc;
+  if (in->sh_degree > 0) return fail(-2, "mm3dgs_slam_adam_project has no SH form: step with mm3dgs_adam, the next mm3dgs_slam_map call projects");
   if (!grads || !adam || !geom_state || !image_state || !binning_state || (P > 0 && !radii)) return fail(-1, "NULL argument");
   if (!grads->d_xyz || !grads->d_f_dc || !grads->d_opacity || !grads->d_scaling || !grads->d_rotation) return fail(-2, "all five gradient arrays are needed");
   hipStream_t s = (hipStream_t)stream;
