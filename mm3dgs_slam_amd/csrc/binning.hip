@@ -221,12 +221,12 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
 // ---- 4. per-tile sort (body in sort_tile.h) --------------------------------------------------------------------------
 template <int CAP, bool GLOBAL_TAIL>
 __global__ void __launch_bounds__(256)
-sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean, int write_pair_index) {
+sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean) {
   __shared__ unsigned long long sk[CAP];
   __shared__ SortShared sh;
   const int tile = blockIdx.x;
   if (tile >= T) return;
-  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, 0, 0, 0, DIRECT_SLOT_BITS_MAX, write_pair_index);
+  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh);
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)
@@ -248,10 +248,10 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
                        ncap, lds_tiles);
   if (scatter_only) return;   // the caller sorts inside its compositing launch
   if (cam.sort_single) {
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, true>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean, cam.bg_extras);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, true>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean);
   } else {
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean, cam.bg_extras);
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap, 0, cam.bg_extras);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap, 0);
   }
 }
 

@@ -192,7 +192,7 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, PROBE_WORD(cam), direct_blocks, direct_cap, slot_bits, 1);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, PROBE_WORD(cam), direct_blocks, direct_cap, slot_bits);
   if (PROBE(cam, 1)) return;   // (-DMM3DGS_PROBES builds only: sort phase alone, timing)
   __syncthreads();   // lists (global) and their lengths (sh.run) are visible to the whole workgroup
   composite_fwd_body<C>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, has_tl ? &tl : nullptr, red, &sh);
@@ -506,7 +506,6 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   // immediate offsets).  (The caller's LDS block is shared with the scratch of the folded mapping-loss gradient pass, which
   // runs first, and -- in the fused tracking kernel -- with the sort keys and the forward compositor's staging buffers.)
   float4 (*stg)[4][3][STG_N] = (float4 (*)[4][3][STG_N])smem_raw;
-  uint32_t (*stgi)[4][64] = (uint32_t (*)[4][64])(smem_raw + sizeof(float4) * 2 * 4 * 3 * STG_N);
   constexpr uint32_t CH = 16;   // list entries staged per row and chunk
 
   const size_t pix = (size_t)py * cam.W + px, HW = (size_t)cam.H * cam.W;
@@ -579,7 +578,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
   const size_t rbase = (size_t)NLIST * start + (size_t)L * len;
   if constexpr (!POSE)
   for (uint32_t e = todo + q; e < count; e += 16) {
-    zero_record<NV>(dsub + (MODE == 0 ? (size_t)list[e].y : rbase + e) * RECF);
+    zero_record<NV>(dsub + (rbase + e) * RECF);
   }
   float pacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // POSE: this lane's share of the tile's pose row (lanes 0-7 of a row: dR rows 0, 1; lanes 8-15: dR row 2, dt)
   if constexpr (MODE != 0 && BWD_TWO_PHASE) {
@@ -781,7 +780,6 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     stg[0][wv][0][slane] = r0.A;
     stg[0][wv][1][slane] = r0.B;
     if (C > 2) stg[0][wv][2][slane] = r0.C;
-    if constexpr (MODE == 0) stgi[0][wv][lane] = e0.y;
   }
   uint2 ent_nxt = CH + q < todo ? list[todo - 1u - (CH + q)] : make_uint2(0u, 0u);
   int cur = 0;
@@ -803,15 +801,12 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     if constexpr (MODE != 0) rec_n.C.z = __uint_as_float(ent_nxt.y);
     const uint2 ent_nn = base + 2 * CH + q < todo ? list[todo - 1u - (base + 2 * CH + q)] : make_uint2(0u, 0u);
     const float4 (*wS)[STG_N] = stg[cur][wv];
-    const int r16i = row * 16;
     const int r16 = row * STG_ROW;
-    const uint32_t* wI = stgi[cur][wv];
-    auto pair_of = [&](int j) { return MODE == 0 ? wI[r16i + j] : 0u; };
     __builtin_amdgcn_wave_barrier();
     const int cnt = __builtin_amdgcn_readfirstlane((int)min(CH, maxtodo - base));
-    auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const uint32_t ti_in, const int j) {
+    auto splat_bwd = [&](const float4& A, const float4& B, const float4& Cc, const int j) {
       const uint32_t step = base + (uint32_t)j;               // wave-uniform
-      const size_t ti = MODE == 0 ? (size_t)ti_in : rbase + (size_t)(todo - 1u - step);      // (SLAM modes: list-major records)
+      const size_t ti = rbase + (size_t)(todo - 1u - step);      // list-major records (every mode since round 6)
       const bool row_on = step < todo;                        // this row still has an entry at this step
       const float dx = A.x - pxf, dy = A.y - pyf;
       const float power = splat_power(dx, dy, A.z, A.w, B.x);
@@ -883,23 +878,19 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // two register sets used alternately: the next splat's LDS reads are in flight while the current one is evaluated,
     // without any register-to-register copies
     float4 A0 = wS[0][r16], B0 = wS[1][r16], C0 = wS[2][r16];
-    uint32_t t0 = pair_of(0);
     for (int j = 0; j < cnt; j += 2) {
       const int j1 = j + 1 < cnt ? j + 1 : j;
       const float4 A1 = wS[0][r16 + j1], B1 = wS[1][r16 + j1], C1 = wS[2][r16 + j1];
-      const uint32_t t1 = pair_of(j1);
-      splat_bwd(A0, B0, C0, t0, j);
+      splat_bwd(A0, B0, C0, j);
       if (j + 1 < cnt) {
         const int j2 = j + 2 < cnt ? j + 2 : j1;
         A0 = wS[0][r16 + j2]; B0 = wS[1][r16 + j2]; C0 = wS[2][r16 + j2];
-        t0 = pair_of(j2);
-        splat_bwd(A1, B1, C1, t1, j1);
+        splat_bwd(A1, B1, C1, j1);
       }
     }
     stg[cur ^ 1][wv][0][slane] = rec_n.A;
     stg[cur ^ 1][wv][1][slane] = rec_n.B;
     if (C > 2) stg[cur ^ 1][wv][2][slane] = rec_n.C;
-    if constexpr (MODE == 0) stgi[cur ^ 1][wv][lane] = ent_nxt.y;
     ent_nxt = ent_nn;
   }
   };
@@ -933,8 +924,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     __syncthreads();
     if (tid < 12) dsub[(size_t)tile * 32 + tid] = (float)((wtot[tid] + wtot[12 + tid]) + (wtot[24 + tid] + wtot[36 + tid]));
   }
-  if constexpr (MODE != 0 && !POSE) {
-    // ---- per-tile combine (SLAM modes): one record per (tile, splat) pair = the sum of the pair's block records, in ascending
+  if constexpr (!POSE) {
+    // ---- per-tile combine (every mode since round 6; generic mode: records of 6 + C floats): one record per (tile, splat) pair = the sum of the pair's block records, in ascending
     // block order (deterministic).  The backward projection then reads ONE record per pair (contiguous per Gaussian) instead of one
     // per listed 4x4 block: a quarter of the bytes on the kernel that the counters show to be bandwidth bound on exactly them
     // (148 MB per mapping launch, 56 MB of it block records).  The block records were written by this workgroup's own waves a
@@ -1009,22 +1000,35 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
               for (int t = 0; t < NLIST; t++) pq = Lq == t ? pos[t] : pq; }
             const size_t rec = (size_t)NLIST * start + (size_t)Lq * len + (size_t)pq;
             const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? rec * RECF : (size_t)0);      // (probe builds, bit 4: timing without the record gather)
+            // (a record shorter than the twelve floats read: the rest belongs to the next record -- or, behind the last one, to the per-tile region --
+            //  and is never stored)
             ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
-            rc[u] = MODE == 1 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rc[u] = NV > 8 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int u = 0; u < UR; u++) {
             a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
             a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
-            if (MODE == 1) { a2.x += on[u] ? rc[u].x : 0.f; a2.y += on[u] ? rc[u].y : 0.f; }
+            if (NV > 8) a2.x += on[u] ? rc[u].x : 0.f;
+            if (NV > 9) a2.y += on[u] ? rc[u].y : 0.f;
+            if (NV > 10) a2.z += on[u] ? rc[u].z : 0.f;
+            if (NV > 11) a2.w += on[u] ? rc[u].w : 0.f;
           }
         }
         if (i < len && tr != 0xffffffffu && !PROBE(cam, 11)) {      // (probe builds, bit 11: combine without its stores)
+          // exactly NV floats, in the widest pieces (mapping: 4 + 4 + 2, tracking: 4 + 2 + 1, generic: 4 + ...): the next record is another lane's
           float* o = dtile + (size_t)tr * RECF;
-          const f4u q0 = {a0.x, a0.y, a0.z, a0.w};
+          const float v[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+          const f4u q0 = {v[0], v[1], v[2], v[3]};
           *(f4u*)o = q0;
-          if (MODE == 1) { const f4u q1 = {a1.x, a1.y, a1.z, a1.w}; *(f4u*)(o + 4) = q1; const f2u q2 = {a2.x, a2.y}; *(f2u*)(o + 8) = q2; }
-          else { const f2u q1 = {a1.x, a1.y}; *(f2u*)(o + 4) = q1; o[6] = a1.z; }
+          constexpr int F1 = NV >= 8 ? 8 : 4;      // floats stored after the second piece
+          if constexpr (NV >= 8) { const f4u q1 = {v[4], v[5], v[6], v[7]}; *(f4u*)(o + 4) = q1; }
+          constexpr int F2 = NV - F1 >= 4 ? F1 + 4 : (NV - F1 >= 2 ? F1 + 2 : F1);
+          if constexpr (NV - F1 >= 4) { const f4u q2 = {v[F1], v[F1 + 1], v[F1 + 2], v[F1 + 3]}; *(f4u*)(o + F1) = q2; }
+          else if constexpr (NV - F1 >= 2) { const f2u q2 = {v[F1], v[F1 + 1]}; *(f2u*)(o + F1) = q2; }
+          constexpr int F3 = NV - F2 >= 2 ? F2 + 2 : F2;
+          if constexpr (NV - F2 >= 2) { const f2u q3 = {v[F2], v[F2 + 1]}; *(f2u*)(o + F2) = q3; }
+          if constexpr (NV - F3 >= 1) o[F3] = v[F3];
         }
       }
     }
@@ -1068,7 +1072,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
-  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits, 1);
+  sort_tile_body<2048, true>(tile, cam.gx, 0, g, iv, b, N_cap, clean, (unsigned long long*)smem, sh, 0, direct_blocks, direct_cap, slot_bits);
   __syncthreads();
   composite_fwd_body<6>(tile, cam, g, iv, b, N_cap, out, (float4 (*)[4][3][STG_N])smem, sh.run, &tl, red, &sh);
   __syncthreads();   // out / final_T / n_contrib of the tile are written, the staging memory is free

@@ -10,7 +10,6 @@
 #include "mm3dgs_common.h"
 
 #include "mm3dgs_math.h"
-#include "gather_records.h"
 #include "composite_common.h"
 
 // SH rows as float4s: a lane's [M,3] coefficient row is 12 M contiguous bytes (192 B at degree 3), so with scalar accesses
@@ -183,7 +182,55 @@ void launch_preprocess_fwd(const CamDev& cam, int P, int M, int C, const float* 
 // Camera gradients: 27 values per Gaussian (view rows 0..3 x cols 0..2, proj rows 0..3 x cols {0,1,3}, campos)
 // are reduced wave -> workgroup in registers/LDS, one partial row per workgroup is written, and a single-wave
 // finishing kernel adds the rows in double precision in a fixed order (deterministic, no atomics).
+// Sum of a Gaussian's per-tile gradient records (generic mode: 6 + C floats at a packed stride of `recf` floats).  Every lane of the wave must call
+// it.  Rectangles of up to 16 tiles are summed by their own lane, four records in flight, in ascending pair order; a bigger one is read by the whole
+// wave (lane-strided, then a fixed-order reduction) -- deterministic either way.  (fused.hip's gather_tile_records is the SLAM modes' instance.)
+__device__ __forceinline__ void gather_pair_records(int area, uint32_t first, const float* __restrict__ dtile, int recf, float4& acc0, float4& acc1,
+                                                    float4& acc2) {
+  const int lane = threadIdx.x & 63;
+  const bool big = area > 16;
+  const int n_own = big ? 0 : area;
+  for (int k0 = 0; __ballot(k0 < n_own) != 0ull; k0 += 4) {
+    float4 a[4], b4[4], c4[4];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      on[u] = k0 + u < n_own;
+      const float* r = dtile + (on[u] ? (size_t)(first + (uint32_t)(k0 + u)) * recf : (size_t)0);
+      a[u] = ld4u(r); b4[u] = ld4u(r + 4); c4[u] = ld4u(r + 8);      // (a shorter record: the caller drops what belongs to the next one)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      acc0.x += on[u] ? a[u].x : 0.f; acc0.y += on[u] ? a[u].y : 0.f; acc0.z += on[u] ? a[u].z : 0.f; acc0.w += on[u] ? a[u].w : 0.f;
+      acc1.x += on[u] ? b4[u].x : 0.f; acc1.y += on[u] ? b4[u].y : 0.f; acc1.z += on[u] ? b4[u].z : 0.f; acc1.w += on[u] ? b4[u].w : 0.f;
+      acc2.x += on[u] ? c4[u].x : 0.f; acc2.y += on[u] ? c4[u].y : 0.f; acc2.z += on[u] ? c4[u].z : 0.f; acc2.w += on[u] ? c4[u].w : 0.f;
+    }
+  }
+  for (unsigned long long bigs = __ballot(big); bigs; bigs &= bigs - 1ull) {
+    const int src = __ffsll((long long)bigs) - 1;
+    const int sarea = __builtin_amdgcn_readlane(area, src);
+    const uint32_t sfirst = (uint32_t)__builtin_amdgcn_readlane((int)first, src);
+    float v[12];
+#pragma unroll
+    for (int f = 0; f < 12; f++) v[f] = 0.f;
+    for (int k = lane; k < sarea; k += 64) {
+      const float* r = dtile + (size_t)(sfirst + (uint32_t)k) * recf;
+#pragma unroll
+      for (int f = 0; f < 12; f++) v[f] += f < recf ? r[f] : 0.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 12; f++) v[f] = wave_sum(v[f]);
+    if (lane == src) {
+      acc0 = make_float4(v[0], v[1], v[2], v[3]); acc1 = make_float4(v[4], v[5], v[6], v[7]); acc2 = make_float4(v[8], v[9], v[10], v[11]);
+    }
+  }
+}
+
 #define NCAM 27
+// (developer timing probes, variant builds only -- results INVALID: -DMM3DGS_PPB_PROBE=<bits>  1: no record gather | 2: no dL/dSH store | 4: no SH row load)
+#ifndef MM3DGS_PPB_PROBE
+#define MM3DGS_PPB_PROBE 0
+#endif
 template <int MV>
 __global__ void __launch_bounds__(PP_BLOCK)
 preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__ means3D,
@@ -208,24 +255,23 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   // fixed order (deterministic).  A Gaussian covering more than 32 tiles is summed by the whole wave.
   float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0, acc2 = acc0;
   {
-    // one round of independent loads, then the shared gather (gather_records.h: small splats per lane, big ones through the
-    // wave's flat work list)
-    uint32_t goff = 0, r0 = 0, r1 = 0, rec_first = 0;
+    // one round of independent loads, then the sum of this Gaussian's per-tile records (composite.hip's per-tile combine wrote one record per
+    // (tile, splat) pair at the pair's Gaussian-major index: a Gaussian's pairs -- its tile rectangle, row-major -- are one contiguous span, and so
+    // are the spans of consecutive Gaussians).  Round 6: before, this kernel walked the (4x4 block, splat) records of every pair through their block
+    // masks -- four times the records, 640 of its 990 us at 1080p / 3 M Gaussians (profiles/r06_c5_probes.txt).
+    uint32_t first = 0;
     int area = 0;
-    float4 sA = make_float4(0.f, 0.f, 0.f, 0.f), sB = sA;
     if (idx < P) {
-      r0 = g.rect[(size_t)idx * 2]; r1 = g.rect[(size_t)idx * 2 + 1];
-      const uint32_t toff = g.tileoff[idx], boff = g.blkoff[idx], btile = g.block_tiles[idx >> 8], bblk = g.block_blk[idx >> 8];
-      const float4* spl = (const float4*)(g.splat + (size_t)idx * SPLAT_F);
-      sA = spl[0]; sB = spl[1];
+      const uint32_t r0 = g.rect[(size_t)idx * 2], r1 = g.rect[(size_t)idx * 2 + 1];
+      const uint32_t toff = g.tileoff[idx], btile = g.block_tiles[idx >> 8];
       if (r1 != r0) {   // <=> radii > 0
         area = ((int)(r1 & 0xffff) - (int)(r0 & 0xffff)) * ((int)(r1 >> 16) - (int)(r0 >> 16));
-        goff = btile + toff;
-        rec_first = bblk + boff;
+        first = btile + toff;
+        if ((size_t)first + (size_t)area > (size_t)N_cap) area = 0;      // beyond the capacity (flagged by the forward): nothing was written
       }
     }
-    // (records packed at their real size: 6 moments / opacity terms + C colour gradients)
-    gather_records<3, 0, PP_BLOCK>(area, goff, r0, r1, sA, sB, rec_first, dsub, bn, N_cap, acc0, acc1, acc2, 0ull, GENERIC_RECF(C));
+    if (!(MM3DGS_PPB_PROBE & 1))
+    gather_pair_records(area, first, dsub + (size_t)NLIST * (size_t)N_cap * SPLAT_F, GENERIC_RECF(C), acc0, acc1, acc2);
     // a record shorter than 12 floats: what the last float4 picked up past its end belongs to the next record
     if (C < 6) { if (C < 3) { acc2.x = 0.f; } if (C < 4) acc2.y = 0.f; if (C < 5) acc2.z = 0.f; acc2.w = 0.f; if (C < 2) acc1.w = 0.f; if (C < 1) acc1.z = 0.f; }
   }
@@ -343,7 +389,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         float ux = vx * inv, uy = vy * inv, uz = vz * inv;
         int deg = cam.sh_degree;
         int nb = (deg + 1) * (deg + 1);
-        if (!skip_g && dshs) {
+        if (!skip_g && dshs && !((MM3DGS_PPB_PROBE & 2) && gc0 != 123.f)) {
           float bb[16];
           sh_basis(deg, ux, uy, uz, bb);
           float* o = dshs + (size_t)idx * M * 3;
@@ -360,7 +406,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
             for (int k = nb; k < M; k++) { o[k * 3] = 0.f; o[k * 3 + 1] = 0.f; o[k * 3 + 2] = 0.f; }
           }
         }
-        if (deg > 0) {
+        if (deg > 0 && !((MM3DGS_PPB_PROBE & 4) && gc0 != 123.f)) {
           float bx[16], by[16], bz[16];
           sh_basis_grad(deg, ux, uy, uz, bx, by, bz);
           const float* sh = shs + (size_t)idx * M * 3;

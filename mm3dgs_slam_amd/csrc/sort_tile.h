@@ -102,7 +102,7 @@ __device__ __forceinline__ unsigned long long wave_bitonic_sort64(unsigned long 
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX, int write_pair_index = 0) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX) {
   const uint32_t slot_mask = (1u << slot_bits) - 1u;
   uint32_t (*wcnt)[NLIST] = sh.wcnt;
   uint32_t (*pre)[NLIST] = sh.pre;
@@ -254,7 +254,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
   for (int base = 0; base < len; base += 256) {
     const int i = base + tid;
     const bool have = i < len;
-    uint32_t id = 0, mask = 0, recT = 0, bw = 0;
+    uint32_t id = 0, mask = 0;
     if (have && direct) {
       const uint32_t low = (uint32_t)(in_lds ? sk[i] : gk[i]);
       id = low >> slot_bits;
@@ -265,22 +265,17 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       id = (uint32_t)(in_lds ? sk[i] : gk[i]);
       const float4* sp = (const float4*)(g.splat + (size_t)id * SPLAT_F);
       const float4 A = sp[0], B = sp[1];
-      // pair index of (Gaussian, tile) in Gaussian-major order (-> submask), and the splat's first gradient record
+      // pair index of (Gaussian, tile) in Gaussian-major order = the pair's per-tile gradient record (a Gaussian's pairs are contiguous: the backward
+      // projection reads them as one span)
       const uint32_t r0 = g.rect[(size_t)id * 2], r1 = g.rect[(size_t)id * 2 + 1];
       const int minx = r0 & 0xffff, miny = r0 >> 16, rw = (int)(r1 & 0xffff) - minx;
       const uint32_t pidx = g.block_tiles[id >> 8] + g.tileoff[id] + (uint32_t)((tty - miny) * rw + (ttx - minx));
       const BlkRect br = block_rect(A, B, r0, r1);
-      const uint32_t rec0 = g.block_blk[id >> 8] + g.blkoff[id];
       mask = tile_block_mask_in_rect(mask_consts(A, B), ttx, tty, br);
-      bw = (uint32_t)br.bw;
-      // entry = {splat id, gradient record of (splat, block)}: row-major position of the block in the splat's rectangle
-      recT = rec0 + (uint32_t)((tty * 4 - br.by0) * br.bw + (ttx * 4 - br.bx0));
-      if (pidx < N_cap && (size_t)rec0 + (size_t)br.bw * br.bh <= (size_t)NLIST * N_cap) b.submask[pidx] = (uint16_t)mask;
-      else mask = 0;   // only on capacity overflow (flagged in the header)
-      // the compositor's per-tile combine (SLAM modes) finds every pair of the bin by its position: mask, block-rectangle width, first
-      // block record, and the pair's per-tile record = its Gaussian-major pair index
-      if (write_pair_index)     // (SLAM entry points) the bin in sorted order: block mask | per-tile record (= the Gaussian-major pair index) << 32
-        b.keys[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)(pidx < N_cap ? pidx : 0xffffffffu) << 32);
+      // the bin in sorted order over the keys, which nobody reads again: block mask | per-tile record << 32.  The backward compositor's per-tile
+      // combine walks it and recomputes every entry's list positions (= its block records, addressed by list position: composite.hip) -- every
+      // mode since round 6 (the generic entry points used to address block records through a per-entry index into a Gaussian-major array)
+      b.keys[start + (uint32_t)i] = (unsigned long long)mask | ((unsigned long long)(pidx < N_cap ? pidx : 0xffffffffu) << 32);
     }
     unsigned long long bal[NLIST];
 #pragma unroll
@@ -303,10 +298,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
       const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
       for (int L = 0; L < NLIST; L++)
-        if ((mask >> L) & 1u) {
-          const uint32_t rec = recT + (uint32_t)((L >> 3) * 2 + ((L >> 1) & 1)) * bw + (uint32_t)(((L >> 2) & 1) * 2 + (L & 1));
-          sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = make_uint2(id, rec);
-        }
+        if ((mask >> L) & 1u) sub[(size_t)L * len + pre[wv][L] + __popcll(bal[L] & lt)] = make_uint2(id, 0u);
     }
     __syncthreads();
     if (tid < NLIST) run[tid] = pre[3][tid] + wcnt[3][tid];
