@@ -81,6 +81,9 @@ void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, in
 // Spatially coherent Gaussian order (SLAM maps) turns ~2.3 global atomics per Gaussian into a few per workgroup.
 // A Gaussian whose rectangle covers more than 32 tiles is spread over the whole wave (rectangle broadcast with
 // readlane) so that one huge splat does not serialise a wave for thousands of iterations.
+// (Measured and rejected in round 6: the pair's Gaussian-major index in the key's low word and payload[pair] = id | block mask written HERE, so that the
+//  sort's emission reads one word per sorted entry instead of gathering five arrays by id: the per-pair mask arithmetic runs at a few lanes per wave in
+//  this sweep -- scatter 105 -> 209 us at 1080p / 3 M Gaussians for 406 -> 340 us of sort.)
 template <bool WRITE>
 __device__ __forceinline__ void sweep_rect(uint32_t* cnt, int gx, int minx, int miny, int w, int area, unsigned long long key,
                                            unsigned long long* keys, uint32_t N_cap, int lane) {
@@ -221,12 +224,12 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
 // ---- 4. per-tile sort (body in sort_tile.h) --------------------------------------------------------------------------
 template <int CAP, bool GLOBAL_TAIL>
 __global__ void __launch_bounds__(256)
-sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean) {
+sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean, int ex) {      // (ex: the probe word of -DMM3DGS_PROBES builds, else 0)
   __shared__ unsigned long long sk[CAP];
   __shared__ SortShared sh;
   const int tile = blockIdx.x;
   if (tile >= T) return;
-  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh);
+  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, ex);
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)
@@ -248,10 +251,10 @@ void launch_scatter_sort(const CamDev& cam, int P, GeomView g, ImageView iv, Bin
                        ncap, lds_tiles);
   if (scatter_only) return;   // the caller sorts inside its compositing launch
   if (cam.sort_single) {
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, true>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, true>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean, (int)PROBE_WORD(cam));
   } else {
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean);
-    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap, 0);
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_SMALL, false>), dim3(T), dim3(256), 0, s, T, cam.gx, 0, g, iv, b, ncap, clean, (int)PROBE_WORD(cam));
+    hipLaunchKernelGGL((sort_tiles_kernel<SORT_CAP_LARGE, true>), dim3(T), dim3(256), 0, s, T, cam.gx, SORT_CAP_SMALL, g, iv, b, ncap, 0, (int)PROBE_WORD(cam));
   }
 }
 

@@ -942,48 +942,102 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     // against 58.1, fused tracking kernel 69.2 against 67.1.  The pass is a latency chain per pair, not a request-rate limit: one pair per lane it is.)
     // Round 6: the block records are LIST-major (record of the k-th entry of block list L = NLIST * start + L * len + k), so a pair's records are found
     // through its list positions -- the rank of the pair among the bin's entries that list block L, in SORTED order.  The sort left the bin in sorted
-    // order over the keys (block mask | per-tile record << 32); every wave walks all of it in 64-entry chunks, keeps the sixteen running list lengths
-    // (ballots: wave-uniform counters), and sums the records of the chunks it owns (chunk c: wave c % 4), each lane one pair, the pair's blocks in
-    // ascending order, four records in flight -- the order of the sums is what it was.
+    // order over the keys (block mask | per-tile record << 32); it is walked in 64-entry chunks (chunk c: wave c % 4), the sixteen running list lengths
+    // come from ballots, and a wave sums the records of the chunks it owns, each lane one pair, the pair's blocks in ascending order, four records in
+    // flight -- the order of the sums is what it was.
     const unsigned long long* __restrict__ sorted = b.keys + start;
-    // the first four chunks' words are requested before the barrier (they depend on nothing the rows compute, the main loop's registers are dead): they
-    // land while the wave waits for the tile's slowest wave, and a tile of up to 256 pairs -- nearly every tile of a SLAM map -- needs no load after it
-    unsigned long long wpre[4] = {0ull, 0ull, 0ull, 0ull};
+    // Round 6, second half: the scan is DISTRIBUTED.  Chunk c belongs to wave c % 4.  Before the barrier (phase A) a wave counts, for each of ITS chunks,
+    // how many entries list each of the sixteen blocks, and leaves the counts in its own slice of the staging memory (free once its main loop is done);
+    // after it (phase B) lanes 0-15 of every wave run over all chunks' counts -- a few dozen LDS bytes -- and the wave recomputes the ballots of its
+    // own chunks only.  Every wave used to ballot through ALL chunks for the running list lengths: 2 300 vector instructions per wave on a 1080p tile
+    // of a 3 M-Gaussian map (18 chunks), a fifth of the pass there (profiles/r06_c5_probes.txt).  Tiles beyond COMB_DIST_CHUNKS chunks keep that form.
+    // The words of a wave's first WPRE chunks are requested before the barrier (they depend on nothing the rows compute, the main loop's registers are
+    // dead): a tile of up to 256 WPRE pairs -- every tile of a SLAM map -- needs no load after it.
+    constexpr int WPRE = (MODE == 0 && C > 4) ? 4 : 8;      // (the 11 / 12-float generic records leave registers for four)
+    constexpr uint32_t COMB_OWN_MAX = 16;                    // own chunks whose counts fit the wave's scratch: tiles of up to 4096 pairs
+    constexpr uint32_t COMB_DIST_CHUNKS = 4 * COMB_OWN_MAX;
+    constexpr size_t WSLICE = (MODE != 0 && BWD_TWO_PHASE) ? (size_t)Bwd2Lds<(MODE == 0 ? 1 : MODE)>::SLICE : sizeof(float4) * 3 * STG_N;   // a wave's private piece of the staging memory
+    static_assert(WSLICE >= COMB_OWN_MAX * NLIST + 64 * (NLIST / 2) * 4, "a wave's slice holds its chunk counts and its list positions");
+    const uint32_t nchunks = (len + 63u) >> 6;
+    const bool dist = nchunks <= COMB_DIST_CHUNKS;          // workgroup-uniform
+    unsigned char* const cnt_mine = smem_raw + (size_t)wv * WSLICE;      // u8[own chunk][list]
+    unsigned long long wpre[WPRE];
+#pragma unroll
+    for (int k = 0; k < WPRE; k++) wpre[k] = 0ull;
+    auto own_word = [&](uint32_t k, uint32_t i) -> unsigned long long {      // word of this wave's k-th chunk (entry i of the bin)
+      unsigned long long wd = 0ull;
+#pragma unroll
+      for (int t = 0; t < WPRE; t++) wd = k == (uint32_t)t ? wpre[t] : wd;
+      if (k >= (uint32_t)WPRE) wd = i < len ? sorted[i] : 0ull;
+      return wd;
+    };
     if (!PROBE(cam, 5)) {
 #pragma unroll
-      for (int c = 0; c < 4; c++) if ((uint32_t)(c * 64 + lane) < len) wpre[c] = sorted[c * 64 + lane];
+      for (int k = 0; k < WPRE; k++) {
+        const uint32_t i = (uint32_t)((4 * k + wv) * 64 + lane);
+        if (i < len) wpre[k] = sorted[i];
+      }
+      if (dist) {      // phase A
+        for (uint32_t k = 0, c = (uint32_t)wv; c < nchunks; k++, c += 4u) {
+          const uint32_t i = c * 64u + (uint32_t)lane;
+          const unsigned long long wd = own_word(k, i);
+          const uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u;
+          unsigned long long mine = 0ull;
+#pragma unroll
+          for (int Lq = 0; Lq < NLIST; Lq++) {
+            const unsigned long long bal = __ballot((mask >> Lq) & 1u);
+            mine = lane == Lq ? bal : mine;
+          }
+          if (lane < NLIST) cnt_mine[k * NLIST + (uint32_t)lane] = (unsigned char)__popcll(mine);
+        }
+      }
     }
     __syncthreads();
     if (!PROBE(cam, 5)) {      // (probe builds, bit 5: timing without the combine)
-      // wave-private scratch in the (now free) staging memory: the lane's sixteen list positions of the chunk, as u16
-      uint32_t* const pos16 = (uint32_t*)(smem_raw + (size_t)wv * 2048) + lane * (NLIST / 2);      // (two positions per word)
-      uint32_t run[NLIST];
-#pragma unroll
-      for (int Lq = 0; Lq < NLIST; Lq++) run[Lq] = 0u;
+      // wave-private scratch behind the counts: the lane's sixteen list positions of the chunk, as u16
+      uint32_t* const pos16 = (uint32_t*)(cnt_mine + COMB_OWN_MAX * NLIST) + lane * (NLIST / 2);      // (two positions per word)
       const unsigned long long lt = (1ull << lane) - 1ull;
-      const uint32_t nchunks = (len + 63u) >> 6;
-      for (uint32_t c = 0; c < nchunks; c++) {
-        const uint32_t i = c * 64u + (uint32_t)lane;
-        unsigned long long wd = c == 0 ? wpre[0] : (c == 1 ? wpre[1] : (c == 2 ? wpre[2] : wpre[3]));
-        if (c >= 4) wd = i < len ? sorted[i] : 0ull;
-        uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u;
-        const uint32_t tr = (uint32_t)(wd >> 32);
-        const bool mine = (c & 3u) == (uint32_t)wv;      // wave-uniform
-        uint32_t pos[NLIST];
-#pragma unroll
-        for (int Lq = 0; Lq < NLIST; Lq++) {
-          const unsigned long long bal = __ballot((mask >> Lq) & 1u);
-          pos[Lq] = run[Lq] + (uint32_t)__popcll(bal & lt);
-          run[Lq] += (uint32_t)__popcll(bal);
-        }
-        if (!mine) continue;
-        // (list positions fit 16 bits: a tile's span holds at most 8191 pairs -- direct bins --; longer packed-bin lists take the slow path below)
-        const bool wide = len > 0xffffu;
-        if (!wide) {
+      const bool wide = len > 0xffffu;      // (list positions fit 16 bits: a direct-bin span holds at most 8191 pairs; longer packed-bin lists take the slow path)
+      // sum of the pair's block records (its blocks in ascending order, four records in flight) and the store of its per-tile record
+      auto finish_chunk = [&](const uint32_t i, uint32_t mask, const uint32_t tr, const uint32_t (&pos)[NLIST]) {
+        if (!wide && MODE != 0) {
 #pragma unroll
           for (int Lq = 0; Lq < NLIST; Lq += 2) pos16[Lq >> 1] = pos[Lq] | (pos[Lq + 1] << 16);
         }
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+        if constexpr (MODE == 0) {
+          // generic mode (long lists: a 1080p tile of a 3 M-Gaussian map holds ~1100 pairs, ~4500 block records): the lanes visit the sixteen lists in
+          // LOCKSTEP, four at a time.  The entries of one chunk that list block L hold CONSECUTIVE positions of list L, so the lanes that read in a step
+          // read one contiguous span of records and the load unit merges them into a few cache-line requests; with every lane following its own lowest
+          // set bit (the SLAM form below: one round trip for most pairs) each 16-byte piece of each record is a request of its own, and at this size the
+          // pass is bound by the L2's request rate: 111 M of them.  Same summation order (ascending block), same sums.  (The SLAM modes lose with this form, also
+          // on the 775-pair tiles of configs[3]: mapping backward 221 - 233 -> 248 - 266 us -- four dependent round trips per chunk instead of one or two.)
+#pragma unroll
+          for (int g4 = 0; g4 < NLIST; g4 += 4) {
+            if (__ballot((mask >> g4) & 0xfu) == 0ull) continue;
+            float4 ra[4], rb[4], rc[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int Lq = g4 + u;
+              on[u] = (mask >> Lq) & 1u;
+              const size_t rec = (size_t)NLIST * start + (size_t)Lq * len + (size_t)pos[Lq];
+              const float* r = dsub + ((on[u] && !PROBE(cam, 4)) ? rec * RECF : (size_t)0);
+              ra[u] = ld4u(r); rb[u] = ld4u(r + 4);
+              rc[u] = NV > 8 ? ld4u(r + 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              a0.x += on[u] ? ra[u].x : 0.f; a0.y += on[u] ? ra[u].y : 0.f; a0.z += on[u] ? ra[u].z : 0.f; a0.w += on[u] ? ra[u].w : 0.f;
+              a1.x += on[u] ? rb[u].x : 0.f; a1.y += on[u] ? rb[u].y : 0.f; a1.z += on[u] ? rb[u].z : 0.f; a1.w += on[u] ? rb[u].w : 0.f;
+              if (NV > 8) a2.x += on[u] ? rc[u].x : 0.f;
+              if (NV > 9) a2.y += on[u] ? rc[u].y : 0.f;
+              if (NV > 10) a2.z += on[u] ? rc[u].z : 0.f;
+              if (NV > 11) a2.w += on[u] ? rc[u].w : 0.f;
+            }
+          }
+          mask = 0u;
+        }
         while (__ballot(mask != 0u) != 0ull) {      // a pair lists ~4 blocks on average: one round for most
           constexpr int UR = 4;
           float4 ra[UR], rb[UR], rc[UR];
@@ -1029,6 +1083,46 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
           constexpr int F3 = NV - F2 >= 2 ? F2 + 2 : F2;
           if constexpr (NV - F2 >= 2) { const f2u q3 = {v[F2], v[F2 + 1]}; *(f2u*)(o + F2) = q3; }
           if constexpr (NV - F3 >= 1) o[F3] = v[F3];
+        }
+      };
+      if (dist) {
+        // phase B: lane L < 16 carries the running length of list L over the chunks in order; at one of its own chunks the wave takes the sixteen
+        // lengths out of those lanes and adds each entry's rank inside the chunk
+        uint32_t acc = 0u;
+        for (uint32_t c = 0; c < nchunks; c++) {
+          const uint32_t w = c & 3u, k = c >> 2;
+          const uint32_t cv = lane < NLIST ? (uint32_t)smem_raw[(size_t)w * WSLICE + k * NLIST + (uint32_t)lane] : 0u;
+          if (w == (uint32_t)wv) {      // wave-uniform
+            const uint32_t i = c * 64u + (uint32_t)lane;
+            const unsigned long long wd = own_word(k, i);
+            const uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u;
+            uint32_t pos[NLIST];
+#pragma unroll
+            for (int Lq = 0; Lq < NLIST; Lq++) {
+              const unsigned long long bal = __ballot((mask >> Lq) & 1u);
+              pos[Lq] = (uint32_t)__builtin_amdgcn_readlane((int)acc, Lq) + (uint32_t)__popcll(bal & lt);
+            }
+            finish_chunk(i, mask, (uint32_t)(wd >> 32), pos);
+          }
+          acc += cv;
+        }
+      } else {
+        // (a tile of more than 4096 pairs: every wave ballots through all chunks for the running list lengths)
+        uint32_t run[NLIST];
+#pragma unroll
+        for (int Lq = 0; Lq < NLIST; Lq++) run[Lq] = 0u;
+        for (uint32_t c = 0; c < nchunks; c++) {
+          const uint32_t i = c * 64u + (uint32_t)lane;
+          const unsigned long long wd = i < len ? sorted[i] : 0ull;
+          const uint32_t mask = i < len ? ((uint32_t)wd & 0xffffu) : 0u;
+          uint32_t pos[NLIST];
+#pragma unroll
+          for (int Lq = 0; Lq < NLIST; Lq++) {
+            const unsigned long long bal = __ballot((mask >> Lq) & 1u);
+            pos[Lq] = run[Lq] + (uint32_t)__popcll(bal & lt);
+            run[Lq] += (uint32_t)__popcll(bal);
+          }
+          if ((c & 3u) == (uint32_t)wv) finish_chunk(i, mask, (uint32_t)(wd >> 32), pos);      // wave-uniform
         }
       }
     }

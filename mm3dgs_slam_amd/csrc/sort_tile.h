@@ -93,6 +93,50 @@ __device__ __forceinline__ unsigned long long wave_bitonic_sort64(unsigned long 
   else return key;
 }
 
+// ---- LDS bitonic sort with its short-distance steps in registers (round 6) ---------------------------------------------------------------------
+// Lists beyond the rank sort's reach (1024 < len <= CAP keys in LDS).  The classic network, n = len rounded up to a power of two, padding = +inf:
+// stage k = 2 .. n, steps j = k/2 .. 1, comparator (i, i ^ j) ascending where (i & k) == 0.  Every step at a distance below 64 stays inside a block
+// of 64 consecutive keys -- one wave's registers (wave_bitonic_sort64's DPP / permlane exchanges): stages 2 .. 64 are one pass over the array, and
+// stage k > 64 is log2(k) - 6 passes through LDS + one register pass.  n = 2048: 21 passes over the keys instead of the 66 of the all-LDS network
+// (bitonic_any_len, still the in-place global-memory form).  Measured at 1080p / 3 M Gaussians (tiles of ~1100 pairs): the sort kernel's time does not
+// move -- nor does it with this network taking over from the rank sort at 512, 256 or 128 keys: at these lengths both cost ~6 us of a CU per tile,
+// vector instructions, 200 of the kernel's 400 us.  (A descending block is sorted as the ascending sort of the complemented keys.)
+__device__ __forceinline__ void bitonic_lds_regs(unsigned long long* sk, int len, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  int n = 64;
+  while (n < len) n <<= 1;
+  for (int i = len + tid; i < n; i += 256) sk[i] = ~0ull;
+  __syncthreads();
+  const int nblk = n >> 6;
+  for (int blk = wv; blk < nblk; blk += 4) {
+    const bool up = (blk & 1) == 0;      // stage 64's direction
+    unsigned long long key = sk[blk * 64 + lane];
+    key = up ? key : ~key;
+    key = wave_bitonic_sort64(key, lane);
+    sk[blk * 64 + lane] = up ? key : ~key;
+  }
+  __syncthreads();
+  for (int k = 128; k <= n; k <<= 1) {
+    for (int j = k >> 1; j >= 64; j >>= 1) {
+      for (int p = tid; p < (n >> 1); p += 256) {
+        const int i = (p / j) * (2 * j) + (p % j), l = i + j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = sk[i], c = sk[l];
+        if ((a > c) == up) { sk[i] = c; sk[l] = a; }
+      }
+      __syncthreads();
+    }
+    for (int blk = wv; blk < nblk; blk += 4) {
+      const bool up = ((blk * 64) & k) == 0;
+      unsigned long long key = sk[blk * 64 + lane];
+      key = up ? key : ~key;
+      key = bitonic_step64<64, 32>(key, lane);      // half-cleaners at distances 32 .. 1, ascending
+      sk[blk * 64 + lane] = up ? key : ~key;
+    }
+    __syncthreads();
+  }
+}
+
 #define RANK_SORT_MAX 1024  // lists up to this length are rank-sorted (needs 2 * RANK_SORT_MAX <= CAP keys of LDS)
 
 // Handles a tile with lo < len <= CAP in LDS (sk[CAP]); when GLOBAL_TAIL it also sorts len > CAP in place in global
@@ -205,7 +249,7 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
   } else if (in_lds) {
     for (int i = tid; i < len; i += 256) sk[i] = gk[i];
     __syncthreads();
-    if (len > 1) bitonic_any_len([&](int i) -> unsigned long long& { return sk[i]; }, len, tid, 256);
+    bitonic_lds_regs(sk, len, tid);      // (the padding stays inside sk[CAP]: CAP is a power of two)
   } else {
     __syncthreads();
     bitonic_any_len([&](int i) -> unsigned long long& { return gk[i]; }, len, tid, 256);
