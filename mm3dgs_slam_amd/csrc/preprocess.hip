@@ -275,6 +275,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     // a record shorter than 12 floats: what the last float4 picked up past its end belongs to the next record
     if (C < 6) { if (C < 3) { acc2.x = 0.f; } if (C < 4) acc2.y = 0.f; if (C < 5) acc2.z = 0.f; acc2.w = 0.f; if (C < 2) acc1.w = 0.f; if (C < 1) acc1.z = 0.f; }
   }
+  float shg0 = 0.f, shg1 = 0.f, shg2 = 0.f, shu0 = 0.f, shu1 = 0.f, shu2 = 1.f;      // (MV == 16) clamp-masked colour gradient and viewing direction of this lane's Gaussian: zero gradient when culled
   if (idx < P) {
     float dmean[3] = {0.f, 0.f, 0.f};
     float gnx = 0.f, gny = 0.f;
@@ -389,7 +390,8 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         float ux = vx * inv, uy = vy * inv, uz = vz * inv;
         int deg = cam.sh_degree;
         int nb = (deg + 1) * (deg + 1);
-        if (!skip_g && dshs && !((MM3DGS_PPB_PROBE & 2) && gc0 != 123.f)) {
+        if (MV == 16) { shg0 = gc0; shg1 = gc1; shg2 = gc2; shu0 = ux; shu1 = uy; shu2 = uz; }      // stored by the whole wave below
+        if (MV != 16 && !skip_g && dshs && !((MM3DGS_PPB_PROBE & 2) && gc0 != 123.f)) {
           float bb[16];
           sh_basis(deg, ux, uy, uz, bb);
           float* o = dshs + (size_t)idx * M * 3;
@@ -464,7 +466,7 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
                          y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
         }
       }
-    } else if (!skip_g && shs && dshs) {
+    } else if (MV != 16 && !skip_g && shs && dshs) {
       float* o = dshs + (size_t)idx * M * 3;
       if (MV) {
 #pragma unroll
@@ -476,12 +478,54 @@ preprocess_bwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     // every Gaussian writes its slots (culled ones write zeros): no memset of the outputs is needed
     if (dmeans3D) { dmeans3D[(size_t)idx * 3] = dmean[0]; dmeans3D[(size_t)idx * 3 + 1] = dmean[1]; dmeans3D[(size_t)idx * 3 + 2] = dmean[2]; }
     if (dmeans2D) { dmeans2D[(size_t)idx * 3] = gnx; dmeans2D[(size_t)idx * 3 + 1] = gny; dmeans2D[(size_t)idx * 3 + 2] = 0.f; }
-    if (dcolors) for (int k = 0; k < ne; k++) dcolors[(size_t)idx * ne + k] = dcol[nsh + k];
+    if (dcolors) {      // (static indices: a run-time index into dcol[] sends the array through scratch memory)
+#pragma unroll
+      for (int k = 0; k < MM3DGS_MAX_CHANNELS; k++)
+        if (k < ne) dcolors[(size_t)idx * ne + k] = nsh ? dcol[k + 3 < MM3DGS_MAX_CHANNELS ? k + 3 : 0] : dcol[k];
+    }
     if (!skip_g) {
       if (dopac) dopac[idx] = dop;
       if (dscales && !cov3d) { dscales[(size_t)idx * 3] = ds[0]; dscales[(size_t)idx * 3 + 1] = ds[1]; dscales[(size_t)idx * 3 + 2] = ds[2]; }
       if (drots && !cov3d) { drots[(size_t)idx * 4] = dq[0]; drots[(size_t)idx * 4 + 1] = dq[1]; drots[(size_t)idx * 4 + 2] = dq[2]; drots[(size_t)idx * 4 + 3] = dq[3]; }
       if (dcov3d && cov3d) for (int k = 0; k < 6; k++) dcov3d[(size_t)idx * 6 + k] = dc6[k];
+    }
+  }
+  if constexpr (MV == 16) {
+    // dL/dSH rows of the wave's 64 Gaussians, stored by the wave TOGETHER (round 6).  A lane's row is 192 contiguous bytes, and twelve float4 stores per
+    // lane -- every one of them 64 lanes x 16 bytes in 64 different cache lines -- wrote the 576 MB of a 3 M-Gaussian map at half the rate a streaming
+    // store reaches (140 of this kernel's 990 us at 1080p, profiles/r06_c5_probes.txt).  The rows go through a wave-private LDS tile in two halves of
+    // 24 floats (7 KB per wave: the occupancy is the registers' either way): lane g writes its half row, then lane l stores the float4s l, l + 64, ...
+    // of the tile -- 96-byte runs, six lanes to a row.  Culled Gaussians store zeros (no memset of the output is needed), rows beyond P are skipped.
+    if (!skip_g && shs && dshs && !(MM3DGS_PPB_PROBE & 2)) {
+      constexpr int HROW = 28;      // floats per half row in LDS: 24 + 4 (16-byte aligned rows, the stride spreads the banks)
+      __shared__ __align__(16) float shx[PP_BLOCK / 64][64 * HROW];
+      const int lane = threadIdx.x & 63, wvq = threadIdx.x >> 6;
+      float bb[16];
+      sh_basis(cam.sh_degree, shu0, shu1, shu2, bb);
+      const int nb = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+      const size_t row0 = (size_t)blockIdx.x * PP_BLOCK + (size_t)wvq * 64;      // first Gaussian of this wave
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float4* mine = (float4*)(shx[wvq] + lane * HROW);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int e = 24 * h + 4 * j + c, k = e / 3, ch = e % 3;      // element e of the row = coefficient k, channel ch
+            v[c] = (k < nb ? bb[k] : 0.f) * (ch == 0 ? shg0 : (ch == 1 ? shg1 : shg2));
+          }
+          mine[j] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const int f = lane + 64 * j, r = f / 6, c4 = f % 6;      // float4 c4 of half row r
+          const float4 q = *(const float4*)(shx[wvq] + r * HROW + c4 * 4);
+          if (row0 + (size_t)r < (size_t)P) *(float4*)(dshs + (row0 + (size_t)r) * 48 + 24 * h + c4 * 4) = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   if (want_cam) {
