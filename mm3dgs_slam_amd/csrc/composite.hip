@@ -1012,6 +1012,8 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
           // set bit (the SLAM form below: one round trip for most pairs) each 16-byte piece of each record is a request of its own, and at this size the
           // pass is bound by the L2's request rate: 111 M of them.  Same summation order (ascending block), same sums.  (The SLAM modes lose with this form, also
           // on the 775-pair tiles of configs[3]: mapping backward 221 - 233 -> 248 - 266 us -- four dependent round trips per chunk instead of one or two.)
+          // (Also measured and rejected: the idle lanes of a step reading a record of ZEROS and adding it like the others -- twelve selects per record slot less, but
+          //  two possible base addresses turn the loads' scalar-base addressing into 64-bit vector arithmetic: generic launch + 20 us, SLAM mapping launch + 1.5.)
 #pragma unroll
           for (int g4 = 0; g4 < NLIST; g4 += 4) {
             if (__ballot((mask >> g4) & 0xfu) == 0ull) continue;
