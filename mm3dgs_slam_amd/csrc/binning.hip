@@ -7,9 +7,9 @@
 //      unique => deterministic).  Ordering == (depth, Gaussian index), the order a stable sort on the lineage's
 //      (tile | depth) keys produces.  The same workgroup then splits the tile's list into sixteen depth-ordered lists, one
 //      per 4x4-pixel block: a splat is listed for a block only if the bound of { alpha >= 1/255 } reaches it (conservative,
-//      so compositing the block lists equals compositing the full tile list); every entry carries the index of the
-//      gradient record the backward pass writes for that (splat, block), and submask[pair] says which blocks list a
-//      (Gaussian, tile) pair.  In the SLAM path steps 2-3 are one launch (scatter_scan_kernel) and step 4 runs inside the
+//      so compositing the block lists equals compositing the full tile list); the bin is left in sorted order as
+//      (block mask | per-tile gradient record << 32) per pair -- what the backward compositor's per-tile combine needs to find
+//      the block records of a pair by list position.  In the SLAM path steps 2-3 are one launch (scatter_scan_kernel) and step 4 runs inside the
 //      forward compositing launch (composite.hip).
 // HBM traffic is ~60 B/pair touched, versus 24 B/pair x 6 passes for a global radix sort of 64-bit keys.
 #include "mm3dgs_common.h"

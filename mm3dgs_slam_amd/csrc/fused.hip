@@ -441,9 +441,7 @@ __device__ __forceinline__ void slam_bin_pairs(const CamDev& cam, int P, int idx
   }
   __syncthreads();
   // sweep 2: slots, keys, payloads (~200 instructions per pair).  Every lane emits the first four pairs of its own splat --
-  // all the pairs of nearly every splat of a SLAM map; their block masks also go, as one 64-bit word, where the backward
-  // projection finds them by Gaussian index (the submask region of the binning state, read as u64[P]; pair k = bits
-  // 16k..16k+15).  The pairs beyond the fourth form the wave's flat work list, cut into equal shares: the few 20-90 pixel
+  // all the pairs of nearly every splat of a SLAM map (their block masks were formed above, m64: pair k = bits 16k..16k+15).  The pairs beyond the fourth form the wave's flat work list, cut into equal shares: the few 20-90 pixel
   // splats that grow in a map would otherwise keep one lane busy for dozens of iterations while its wave waits (this kernel
   // went from 19 to 44 us over 100 frames of a run before).
   {   // (running tile coordinates: no division per pair)

@@ -4,15 +4,17 @@
 //                  | clamped[P] (u8, SH clamp bits) | tileoff[P] (u32, workgroup-local exclusive scan of tiles touched)
 //                  | block_tiles[ceil(P/256)+1] (u32, tiles touched per preprocess workgroup -> exclusive prefix)
 //   image_state  : Mm3dgsHeader | tile_count[T] | ranges[T+1] | cursor[T] | subcount[16T] | final_T[H*W] | n_contrib[H*W]
-//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile) | sublist[16*N_cap] (uint2
-//                  {id, pair}: depth-ordered list of each 4x4-pixel block; block L = 4 * (8x8 sub-tile) + (block in the
-//                  sub-tile) of a tile with bin [start,end) owns [16*start + L*len, +subcount[16*tile + L]); pair =
-//                  Gaussian-major index of the (Gaussian, tile) pair) | submask[N_cap] (u16, by pair: which blocks list it)
-//   bwd scratch  : dsub[16*N_cap] (12 floats; one record per (block, splat), written once by the owning 16-lane row of a
-//                  wave -- no atomics).  A Gaussian's records are contiguous AND dense: record index = first record of the
-//                  Gaussian (block_blk[id>>8] + blkoff[id]) + row-major position of the block inside the splat's block
-//                  rectangle (block_rect()), so the consumer's gather touches ~1.1x the useful bytes (2.3x with 16 slots
-//                  per pair).  The list entries carry the record index.
+//   binning_state: keys[N_cap] (u64 = depth_bits<<32 | id; bins are contiguous per tile; after the sort: the bin in sorted order as
+//                  block mask | per-tile record << 32) | sublist[16*N_cap] (uint2 {id, -}: depth-ordered list of each 4x4-pixel block;
+//                  block L = 4 * (8x8 sub-tile) + (block in the sub-tile) of a tile with bin [start,end) owns
+//                  [16*start + L*len, +subcount[16*tile + L])) | payload[N_cap] (direct bins: block mask | per-tile record << 32 by slot)
+//   bwd scratch  : dsub[16*N_cap] (records of up to 12 floats; one per (block, splat), written once by the owning 16-lane row of a
+//                  wave -- no atomics), LIST-major since round 6 in every mode: the record of the k-th entry of block list L of a tile
+//                  is 16*start + L*len + k, a row's walk writes consecutive records
+//                  | dtile[N_cap] (one record per (tile, splat) pair = the sum of the pair's block records, formed by the compositor's
+//                  workgroup after its rows are done (composite.hip, per-tile combine); a Gaussian's pairs -- its tile rectangle,
+//                  row-major -- are contiguous: packed bins at the Gaussian-major pair index block_tiles[id>>8] + tileoff[id] + k,
+//                  direct bins inside the projection workgroup's span)
 //                  | campartial[ceil(P/256)][32]
 // A wave composites one 8x8 sub-tile; each of its four 16-lane rows owns a 4x4 block and walks that block's own list, so a
 // wave iteration evaluates up to four different splats (SLAM splats cover ~40 pixels: with one list per sub-tile 85 % of the
