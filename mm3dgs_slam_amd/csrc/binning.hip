@@ -65,10 +65,6 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_tiles_kernel(int T, int nbloc
   // tiles touched per preprocess workgroup -> exclusive prefix (first pair index of each workgroup's Gaussians)
   uint32_t tot2 = block_excl_scan(g.block_tiles, g.block_tiles, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
   if (threadIdx.x == 0) g.block_tiles[nblocks] = tot2;
-  __syncthreads();
-  // 4x4 blocks per preprocess workgroup -> exclusive prefix (first gradient record of each workgroup's splats)
-  uint32_t tot3 = block_excl_scan(g.block_blk, g.block_blk, nullptr, nblocks, wave_tot, &carry_s, nullptr, false);
-  if (threadIdx.x == 0) g.block_blk[nblocks] = tot3;
 }
 void launch_scan_tiles(int T, int P, GeomView g, ImageView iv, hipStream_t s, int sticky) {
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, T, (P + 255) / 256, g, iv, sticky);
@@ -200,11 +196,6 @@ scatter_scan_kernel(int P, int gx, int T, int nblocks_pre, GeomView g, ImageView
     __syncthreads();
     const uint32_t tot2 = block256_excl_scan_inplace(g.block_tiles, nblocks_pre, wave_tot, nullptr);
     if (tid == 0) g.block_tiles[nblocks_pre] = tot2;
-  }
-  if (blockIdx.x == (gridDim.x > 2 ? 2 : 0)) {
-    __syncthreads();
-    const uint32_t tot3 = block256_excl_scan_inplace(g.block_blk, nblocks_pre, wave_tot, nullptr);
-    if (tid == 0) g.block_blk[nblocks_pre] = tot3;
   }
   if (r1 == r0) dbits = 0;   // culled: depth[] was not written this frame
   const int minx = r0 & 0xffff, miny = r0 >> 16, maxx = r1 & 0xffff, maxy = r1 >> 16;

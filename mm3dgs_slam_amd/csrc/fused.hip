@@ -75,7 +75,7 @@ __device__ __forceinline__ void slam_cov3d(const SlamIn& in, int idx, float mod,
 
 // Projection of one Gaussian (lane): pose transform, activations, EWA, SH degree 0 -> RGB, [z, 1, z^2], tile rectangle, block
 // rectangle.  Writes the splat record, depth, clamp bits, radii and rect; returns what the binning half of the kernels needs.
-struct Projected { uint32_t r0, r1, nblk; float4 sA, sB; BlkRect br; float z; int32_t rad; uint32_t cl; };
+struct Projected { uint32_t r0, r1; float4 sA, sB; BlkRect br; float z; int32_t rad; uint32_t cl; };
 // raw parameters of one Gaussian, as the projection consumes them
 struct RawGaussian { float x[3], q[4], ls[3], fd[3], op; };
 
@@ -172,7 +172,7 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
     for (int i = 0; i < 3; i++) p[i] = ps.R[i][0] * rg.x[0] + ps.R[i][1] * rg.x[1] + ps.R[i][2] * rg.x[2] + ps.t[i];
   }
   Projected o;
-  o.r0 = 0; o.r1 = 0; o.nblk = 0; o.rad = 0; o.z = 0.f; o.cl = 0;
+  o.r0 = 0; o.r1 = 0; o.rad = 0; o.z = 0.f; o.cl = 0;
   o.sA = make_float4(0.f, 0.f, 0.f, 0.f); o.sB = o.sA;
   o.br.bx0 = 0; o.br.by0 = 0; o.br.bw = 0; o.br.bh = 0;
   if (live && p[2] > 0.2f) {
@@ -231,7 +231,6 @@ __device__ __forceinline__ Projected slam_project_vals(const CamDev& cam, bool l
         sp[0] = o.sA;
         sp[1] = o.sB;
         o.br = block_rect(o.sA, o.sB, o.r0, o.r1);
-        o.nblk = (uint32_t)(o.br.bw * o.br.bh);
         sp[2] = make_float4(fmaxf(c2, 0.f), zc, 1.f, zc * zc);
         g.depth[idx] = z;
         o.z = z;
@@ -279,7 +278,7 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
   const int idx = blockIdx.x * FB + threadIdx.x;
   const bool live = idx < P;
   const Projected pr = slam_project_one<SH>(cam, P, idx, in, radii, g, want_poserec != 0);
-  const uint32_t r0 = pr.r0, r1 = pr.r1, nblk = pr.nblk;
+  const uint32_t r0 = pr.r0, r1 = pr.r1;
   const int32_t rad = pr.rad;
   if (vis_only) {      // mm3dgs_slam_visibility: the projection stage alone (workgroup-uniform): no tile counting, no scans
     if (live && seen && rad > 0) seen[idx] += 1u;
@@ -291,14 +290,15 @@ slam_preprocess_fwd_kernel(CamDev cam, int P, SlamIn in, int32_t* __restrict__ r
     {
       __shared__ uint32_t wtot[FB / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-      __shared__ uint32_t wtot2[FB / 64];
-      const uint32_t x = wave_scan_incl((uint32_t)area), x2 = wave_scan_incl(nblk);   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
-      if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
+      // (the second scan -- the 4x4 blocks of every splat's block rectangle, blkoff / block_blk: the first Gaussian-major block record -- left in round 6:
+      //  block records are addressed by list position in every mode)
+      const uint32_t x = wave_scan_incl((uint32_t)area);   // tiles touched
+      if (ln == 63) wtot[wvi] = x;
       __syncthreads();
-      uint32_t pre = 0, pre2 = 0;
-      for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
-      if (live) { g.tileoff[idx] = pre + x - (uint32_t)area; g.blkoff[idx] = pre2 + x2 - nblk; }
-      if (threadIdx.x == FB - 1) { g.block_tiles[blockIdx.x] = pre + x; g.block_blk[blockIdx.x] = pre2 + x2; }
+      uint32_t pre = 0;
+      for (int q = 0; q < wvi; q++) pre += wtot[q];
+      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
+      if (threadIdx.x == FB - 1) g.block_tiles[blockIdx.x] = pre + x;
     }
     uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
     const int lane = threadIdx.x & 63;

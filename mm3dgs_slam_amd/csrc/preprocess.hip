@@ -54,7 +54,7 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
   if (live) { p[0] = means3D[(size_t)idx * 3]; p[1] = means3D[(size_t)idx * 3 + 1]; p[2] = means3D[(size_t)idx * 3 + 2]; }
   float tz = p[0] * V[2] + p[1] * V[6] + p[2] * V[10] + V[14];
   int32_t rad = 0;
-  uint32_t r0 = 0, r1 = 0, nblk = 0;
+  uint32_t r0 = 0, r1 = 0;
   if (live && tz > 0.2f) {
     float hx = p[0] * PV[0] + p[1] * PV[4] + p[2] * PV[8] + PV[12];
     float hy = p[0] * PV[1] + p[1] * PV[5] + p[2] * PV[9] + PV[13];
@@ -115,8 +115,6 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
         sp[0] = sA;
         sp[1] = sB;
         sp[2] = make_float4(col[2], col[3], col[4], col[5]);
-        const BlkRect br = block_rect(sA, sB, r0, r1);
-        nblk = (uint32_t)(br.bw * br.bh);
         g.depth[idx] = e.t[2];
       }
     }
@@ -133,14 +131,15 @@ preprocess_fwd_kernel(CamDev cam, int P, int M, int C, const float* __restrict__
     {  // workgroup-local exclusive scan of tiles touched (this Gaussian's first pair index)
       __shared__ uint32_t wtot[PP_BLOCK / 64];
       const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-      __shared__ uint32_t wtot2[PP_BLOCK / 64];
-      const uint32_t x = wave_scan_incl((uint32_t)area), x2 = wave_scan_incl(nblk);   // tiles touched | 4x4 blocks of the block rectangle (gradient records)
-      if (ln == 63) { wtot[wvi] = x; wtot2[wvi] = x2; }
+      // (the second scan -- the 4x4 blocks of every splat's block rectangle, blkoff / block_blk: the first Gaussian-major block record -- left in round 6:
+      //  block records are addressed by list position in every mode)
+      const uint32_t x = wave_scan_incl((uint32_t)area);   // tiles touched
+      if (ln == 63) wtot[wvi] = x;
       __syncthreads();
-      uint32_t pre = 0, pre2 = 0;
-      for (int q = 0; q < wvi; q++) { pre += wtot[q]; pre2 += wtot2[q]; }
-      if (live) { g.tileoff[idx] = pre + x - (uint32_t)area; g.blkoff[idx] = pre2 + x2 - nblk; }
-      if (threadIdx.x == PP_BLOCK - 1) { g.block_tiles[blockIdx.x] = pre + x; g.block_blk[blockIdx.x] = pre2 + x2; }
+      uint32_t pre = 0;
+      for (int q = 0; q < wvi; q++) pre += wtot[q];
+      if (live) g.tileoff[idx] = pre + x - (uint32_t)area;
+      if (threadIdx.x == PP_BLOCK - 1) g.block_tiles[blockIdx.x] = pre + x;
     }
     uint32_t* cnt = lds_tiles ? hist : iv.tile_count;
     const int lane = threadIdx.x & 63;
