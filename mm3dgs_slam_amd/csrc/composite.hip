@@ -460,6 +460,14 @@ struct SepReduce2 {
 #ifndef MM3DGS_BWD2_PROBE
 #define MM3DGS_BWD2_PROBE 0
 #endif
+// generic mode, three channels (the RGB pass of the reference's rasterizer: configs[4]): the two-phase loop too (round 6); -DMM3DGS_GEN3_ONE_PHASE keeps its
+// one-phase loop (A/B baseline).  Other channel counts of the generic mode stay on the one-phase loop.
+#ifdef MM3DGS_GEN3_ONE_PHASE
+#define GEN3_TWO_PHASE 0
+#else
+#define GEN3_TWO_PHASE BWD_TWO_PHASE
+#endif
+#define BWD_IS_TWO_PHASE(MODE, C) (((MODE) != 0 && BWD_TWO_PHASE) || ((MODE) == 0 && (C) == 3 && GEN3_TWO_PHASE))
 #define TP_STRIDE 65      // float2 per step row of the (u, w) tile: 64 lanes + 1 (the SUB lanes of a phase-2 group read SUB different rows at one column: the odd stride spreads them over the banks)
 template <int MODE>
 struct Bwd2Lds {      // wave-private slice of the workgroup's LDS block (bytes)
@@ -581,9 +589,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     zero_record<NV>(dsub + (rbase + e) * RECF);
   }
   float pacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // POSE: this lane's share of the tile's pose row (lanes 0-7 of a row: dR rows 0, 1; lanes 8-15: dR row 2, dt)
-  if constexpr (MODE != 0 && BWD_TWO_PHASE) {
+  if constexpr (BWD_IS_TWO_PHASE(MODE, C)) {
   if (maxtodo != 0) {   // wave-uniform (a wave without work still takes part in the workgroup's per-tile combine below)
-    using LY = Bwd2Lds<MODE>;
+    using LY = Bwd2Lds<(MODE == 0 ? 1 : MODE)>;      // (generic three-channel instance: the mapping layout -- a float4 of dL per pixel)
     unsigned char* const wbase = smem_raw + (size_t)wv * LY::SLICE;
     float4* const sA = (float4*)(wbase + LY::OFF_A);
     float4* const sB = (float4*)(wbase + LY::OFF_B);
@@ -591,10 +599,14 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     float2* const tp = (float2*)(wbase + LY::OFF_TP);
     float* const t5 = (float*)(wbase + LY::OFF_T5);
     // the pixels' dL for phase 2 (wave-private: a wave only ever reads its own four blocks)
-    if constexpr (MODE == 1) ((float4*)(wbase + LY::OFF_T))[lane] = make_float4(dL[0], dL[1], dL[2], dL[3]);
-    else ((float*)(wbase + LY::OFF_T))[lane] = dL[3];
-    const bool z45_wave = __ballot(dL[4] != 0.f || dL[5] != 0.f || Tf_bg != 0.f) == 0ull;      // see the one-phase loop below
-    if (!z45_wave) t5[lane] = dL[5];
+    bool z45_wave = true;      // (generic: no fifth / sixth channel -- the 8-entry instance, with the background term kept)
+    if constexpr (MODE == 0) ((float4*)(wbase + LY::OFF_T))[lane] = make_float4(dL[0], dL[1], dL[2], 0.f);
+    else {
+      if constexpr (MODE == 1) ((float4*)(wbase + LY::OFF_T))[lane] = make_float4(dL[0], dL[1], dL[C > 3 ? 2 : 0], dL[C > 3 ? 3 : 0]);
+      else ((float*)(wbase + LY::OFF_T))[lane] = dL[C > 3 ? 3 : 0];
+      z45_wave = __ballot(dL[C > 4 ? 4 : 0] != 0.f || dL[C > 5 ? 5 : 0] != 0.f || Tf_bg != 0.f) == 0ull;      // see the one-phase loop below
+      if (!z45_wave) t5[lane] = dL[C > 5 ? 5 : 0];
+    }
     const uint32_t first_step = todo - min(todo, last_contributor);
     const uint32_t mean_steps_b = wave_mean_steps(cam, iv);
     const float X0 = pxf - (float)(q & 3), Y0 = pyf - (float)(q >> 2);      // pixel centre of the block's corner (exact)
@@ -635,19 +647,24 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
             n_visit++;
             const float a_eff = valid ? alpha : 0.f;
             const float G_eff = valid ? G : 0.f;
-            const float r = __builtin_amdgcn_rcpf(1.f - a_eff);
+            float r;
+            if constexpr (MODE == 0) {      // (the reciprocal to within an ulp: see the one-phase loop)
+              const float d = 1.f - a_eff, r0 = __builtin_amdgcn_rcpf(d);
+              r = fmaf(fmaf(-d, r0, 1.f), r0, r0);
+            } else r = __builtin_amdgcn_rcpf(1.f - a_eff);
             Tr *= r;  // transmittance in front of this splat
             const float w = a_eff * Tr;
             // dL/dalpha needs sum_ch (c_ch - behind_ch) dL_ch: ONE running scalar (behind_dot), see the one-phase loop
             float qd = fmaf(B.z, dL[0], 0.f);
             qd = fmaf(B.w, dL[1], qd);
             qd = fmaf(CZ.x, dL[2], qd);
-            qd = fmaf(CZ.y, dL[3], qd);
-            if constexpr (!Z45) { qd = fmaf(1.f, dL[4], qd); qd = fmaf(CZ.y * CZ.y, dL[5], qd); }
+            if constexpr (MODE != 0) qd = fmaf(CZ.y, dL[C > 3 ? 3 : 0], qd);
+            if constexpr (!Z45 && MODE != 0) { qd = fmaf(1.f, dL[C > 4 ? 4 : 0], qd); qd = fmaf(CZ.y * CZ.y, dL[C > 5 ? 5 : 0], qd); }
             const float diff = qd - behind_dot;
             behind_dot = fmaf(a_eff, diff, behind_dot);
-            const float dLa = Z45 ? diff * Tr : diff * Tr - Tf_bg * r;
-            const float u = B.y * dLa * G_eff;
+            const float dLa = (Z45 && MODE != 0) ? diff * Tr : diff * Tr - Tf_bg * r;
+            // (generic: u WITHOUT the opacity -- the record wants sum G dL/dalpha beside the moments of o G dL/dalpha; phase 2 scales the moments)
+            const float u = MODE == 0 ? dLa * G_eff : B.y * dLa * G_eff;
             if (!(MM3DGS_BWD2_PROBE & 4)) *tpw = make_float2(u, w);
             tpw += TP_STRIDE;
           };
@@ -694,12 +711,12 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
                 s0 = s0 + uw.x;
                 s1 = __builtin_fmaf(uw.x, dxv[x], s1);
                 s2 = __builtin_fmaf(uw.x, dxx[x], s2);
-                if constexpr (MODE == 1) {
+                if constexpr (MODE != 2) {
                   const float4 d4 = (MM3DGS_BWD2_PROBE & 8) ? make_float4(X0, Y0, X0, Y0) : ((const float4*)(wbase + LY::OFF_T))[pcol + yy * 4 + x];
                   c0 = __builtin_fmaf(uw.y, d4.x, c0);
                   c1 = __builtin_fmaf(uw.y, d4.y, c1);
                   c2 = __builtin_fmaf(uw.y, d4.z, c2);
-                  cz = __builtin_fmaf(uw.y, d4.w, cz);
+                  if constexpr (MODE == 1) cz = __builtin_fmaf(uw.y, d4.w, cz);
                 } else {
                   cz = __builtin_fmaf(uw.y, ((const float*)(wbase + LY::OFF_T))[pcol + yy * 4 + x], cz);
                 }
@@ -717,8 +734,9 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
               if constexpr (NL == 2) return v + dpp_all<ROW_ROR8>(v);
               else { v = v + dpp_all<ROW_ROR4>(v); return v + dpp_all<ROW_ROR8>(v); }
             };
-            M0 = merge(M0); Mx = merge(Mx); Mxx = merge(Mxx); My = merge(My); Mxy = merge(Mxy); Myy = merge(Myy); cz = merge(cz);
-            if constexpr (MODE == 1) { c0 = merge(c0); c1 = merge(c1); c2 = merge(c2); }
+            M0 = merge(M0); Mx = merge(Mx); Mxx = merge(Mxx); My = merge(My); Mxy = merge(Mxy); Myy = merge(Myy);
+            if constexpr (MODE != 0) cz = merge(cz);
+            if constexpr (MODE != 2) { c0 = merge(c0); c1 = merge(c1); c2 = merge(c2); }
             if constexpr (POSE) {
               // dm = Kp (Mx, My) + Kq (Mxx, Mxy, Myy) + e_z cz;  the pose row collects dm (x) [x; 1]
               // (selects, not products: the lanes without an entry gathered record 0, which may never have been written)
@@ -735,6 +753,11 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
             } else
             if (on2 && !(MM3DGS_BWD2_PROBE & 2)) {
               float* const o = dsub + ((MM3DGS_BWD2_PROBE & 32) ? (size_t)lane : rbase + (size_t)(todo - 1u - (base + (uint32_t)ent))) * RECF;
+              if constexpr (MODE == 0) {      // [Mx My Mxx Mxy | Myy sum(G dL/dalpha) c0 c1 | c2], the moments scaled by the splat's opacity (preprocess_bwd's layout)
+                const float op = sB[r17 + ent].y;
+                if (part == 0) { const f4u v0 = {op * Mx, op * My, op * Mxx, op * Mxy}; *(f4u*)o = v0; o[8] = c2; }
+                if (part == 1) { const f4u v1 = {op * Myy, M0, c0, c1}; *(f4u*)(o + 4) = v1; }
+              } else
               if constexpr (MODE == 1) {      // [M0 Mx Mxx c0 | c1 c2 cz My | Mxy Myy]
                 if (MM3DGS_BWD2_PROBE & 16) { if (part == 0) { const f4u v0 = {M0 + Mx + Mxx + c0, c1 + c2 + cz + My, Mxy, Myy}; *(f4u*)o = v0; } } else {
                 if (part == 0) { const f4u v0 = {M0, Mx, Mxx, c0}; *(f4u*)o = v0; }
@@ -956,7 +979,7 @@ __device__ __forceinline__ void composite_bwd_body(int tile, const CamDev& cam, 
     constexpr int WPRE = (MODE == 0 && C > 4) ? 4 : 8;      // (the 11 / 12-float generic records leave registers for four)
     constexpr uint32_t COMB_OWN_MAX = 16;                    // own chunks whose counts fit the wave's scratch: tiles of up to 4096 pairs
     constexpr uint32_t COMB_DIST_CHUNKS = 4 * COMB_OWN_MAX;
-    constexpr size_t WSLICE = (MODE != 0 && BWD_TWO_PHASE) ? (size_t)Bwd2Lds<(MODE == 0 ? 1 : MODE)>::SLICE : sizeof(float4) * 3 * STG_N;   // a wave's private piece of the staging memory
+    constexpr size_t WSLICE = BWD_IS_TWO_PHASE(MODE, C) ? (size_t)Bwd2Lds<(MODE == 0 ? 1 : MODE)>::SLICE : sizeof(float4) * 3 * STG_N;   // a wave's private piece of the staging memory
     static_assert(WSLICE >= COMB_OWN_MAX * NLIST + 64 * (NLIST / 2) * 4, "a wave's slice holds its chunk counts and its list positions");
     const uint32_t nchunks = (len + 63u) >> 6;
     const bool dist = nchunks <= COMB_DIST_CHUNKS;          // workgroup-uniform
@@ -1139,7 +1162,7 @@ composite_bwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint32_t N
   // (generic mode: 32 KB on purpose -- five workgroups per CU; with the 26 KB the staging buffers need, six fit and the 1080p /
   //  3 M-Gaussian pass ran 14 % slower: every workgroup gathers ~1000 splat records by id, and six of them overflow the L1)
   constexpr size_t MIN_BYTES = MODE == 0 ? 32768 : 0;
-  constexpr size_t STG_BYTES = (MODE != 0 && BWD_TWO_PHASE) ? (size_t)BWD2_BYTES(MODE == 0 ? 1 : MODE) : (size_t)BWD_STG_BYTES;
+  constexpr size_t STG_BYTES = BWD_IS_TWO_PHASE(MODE, C) ? (size_t)BWD2_BYTES(MODE == 0 ? 1 : MODE) : (size_t)BWD_STG_BYTES;
   constexpr size_t NEED = STG_BYTES > LOSS_BYTES ? STG_BYTES : LOSS_BYTES;
   __shared__ __align__(16) unsigned char smem_raw[NEED > MIN_BYTES ? NEED : MIN_BYTES];
   const int T = cam.gx * cam.gy;
