@@ -81,6 +81,17 @@ def main():
             c = collections.Counter(classify(op, text) for op, text in ins[a:b])
             ns = sum(c[k] * NS[k] for k in NS)
             is_bwd = c["dpp"] > 0
+            # round 6: the backward loops are two-phase -- the loop found here (no DPP in it) is PHASE 1 of a backward kernel (lane = pixel: alpha, T, dL/dalpha ->
+            # (u, w) into the wave's LDS tile); phase 2 (lane = (entry, part of the block), once per 8 / 4 entries) is priced in DESIGN.md section 4
+            p1 = (not is_bwd) and (label[1] == "bwd" or "backward" in label[0] or ("tracking kernel" in label[0] and "fwd" in seen))
+            if p1:
+                tag = "bwd ph.1 " + ("gen." if "p1" not in seen else "fast")
+                if "p1b" in seen:
+                    continue
+                seen.add("p1b" if "p1" in seen else "p1")
+                print(f"{label[0]:44s} {tag:>11s} {c['valu']:5d} {c['dpp']:4d} {c['trans']:5d} {c['mad64']:5d} {c['salu']:5d} {c['lds']:4d} {c['vmem']:5d} "
+                      f"{ns:13.1f} {steps['bwd'] * ns / 1024 / 1e3:9.1f}")
+                continue
             if not is_bwd and "fwd" in seen:
                 continue
             seen.add("fwd" if not is_bwd else "bwd")
