@@ -289,6 +289,9 @@ __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const G
     return true;
   }
   // ---- emit the 16 block lists (order preserving) ----
+  // (Measured in round 6 and not kept: packed bins of up to 1024 pairs forming their payloads in the rank loop -- the gathers by id in the order of the
+  //  64-key runs -- and emitting from LDS like the direct bins: the sort kernel's time at 1080p / 3 M Gaussians does not move, 541 - 549 us either way.
+  //  Of its 400 us there, 200 are the sort proper -- vector instructions, ~6 us of a CU per 1100-key tile whichever of the two sorts runs.)
   const int ttx = tile % gx, tty = tile / gx;
   if (tid < NLIST) run[tid] = 0;
   __syncthreads();
