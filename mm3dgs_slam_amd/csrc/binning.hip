@@ -218,9 +218,10 @@ __global__ void __launch_bounds__(256)
 sort_tiles_kernel(int T, int gx, int lo, GeomView g, ImageView iv, BinView b, uint32_t N_cap, int clean, int ex) {      // (ex: the probe word of -DMM3DGS_PROBES builds, else 0)
   __shared__ unsigned long long sk[CAP];
   __shared__ SortShared sh;
+  __shared__ SortEmit em;
   const int tile = blockIdx.x;
   if (tile >= T) return;
-  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, ex);
+  sort_tile_body<CAP, GLOBAL_TAIL>(tile, gx, lo, g, iv, b, N_cap, clean, sk, sh, ex, 0, 0, DIRECT_SLOT_BITS_MAX, &em);
 }
 
 #define SORT_CAP_SMALL 2048   // 16 KB LDS: the common case (SLAM lists are a few hundred entries)

@@ -189,6 +189,9 @@ sort_composite_fwd_kernel(CamDev cam, GeomView g, ImageView iv, BinView b, uint3
   __shared__ SortShared sh;
   __shared__ double red[4][12];
   static_assert(sizeof(smem) >= 2048 * sizeof(unsigned long long), "LDS union too small for the key array");
+  // (round 6: the emission's per-wave counters live behind the sort's words in the staging memory instead of in SortShared -- 26.6 KB of LDS instead of
+  //  27.1: SIX workgroups per CU (160 KB in 1280-byte granules) where the grid has more than one round of them: configs[3], 3225 tiles)
+  static_assert(sizeof(smem) >= 3 * RANK_SORT_MAX * sizeof(unsigned long long) + sizeof(SortEmit), "LDS union too small for the sort's words and the emission's counters");
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;
@@ -1187,7 +1190,7 @@ sort_composite_fwd_bwd_track_kernel(CamDev cam, GeomView g, ImageView iv, BinVie
   __shared__ SortShared sh;
   __shared__ double red[4][12];
   static_assert(TRACK_BWD_BYTES >= sizeof(float4) * 2 * 4 * 3 * STG_N, "LDS union too small for the forward staging buffers");
-  static_assert(TRACK_BWD_BYTES >= 3 * RANK_SORT_MAX * sizeof(unsigned long long), "LDS union too small for the sort's keys, runs and payloads");
+  static_assert(TRACK_BWD_BYTES >= 3 * RANK_SORT_MAX * sizeof(unsigned long long) + sizeof(SortEmit), "LDS union too small for the sort's keys, runs, payloads and the emission's counters");
   const int T = cam.gx * cam.gy;
   const int tile = slam_tile(cam, iv, blockIdx.x, T);
   if (tile >= T) return;

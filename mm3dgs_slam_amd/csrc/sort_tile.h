@@ -4,9 +4,11 @@
 #include "mm3dgs_common.h"
 #include "tile_mask.h"
 
-struct SortShared {            // LDS of one sorting workgroup besides the key array
+struct SortEmit {              // scratch of the barrier-synchronised emission (packed bins, lists beyond the rank sort): only alive inside sort_tile_body
   uint32_t wcnt[4][NLIST];     // per-wave entry counts of a 256-entry chunk, per block list
   uint32_t pre[4][NLIST];      // write cursor of (wave, list) for the chunk
+};
+struct SortShared {            // LDS of one sorting workgroup besides the key array
   uint32_t run[NLIST];         // entries emitted so far per list (the final list lengths)
   uint32_t start, len;         // the tile's bin (for the compositing phase of the same workgroup)
   uint32_t scan_tot[4];        // direct bins: wave totals of the pair count (tile 0's workgroup)
@@ -146,10 +148,13 @@ __device__ __forceinline__ void bitonic_lds_regs(unsigned long long* sk, int len
 template <int CAP, bool GLOBAL_TAIL>
 __device__ __forceinline__ bool sort_tile_body(int tile, int gx, int lo, const GeomView& g, const ImageView& iv, const BinView& b,
                                                uint32_t N_cap, int clean, unsigned long long* sk, SortShared& sh, int ex = 0,
-                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX) {
+                                               int direct_blocks = 0, uint32_t direct_cap = 0, int slot_bits = DIRECT_SLOT_BITS_MAX, SortEmit* emit = nullptr) {
   const uint32_t slot_mask = (1u << slot_bits) - 1u;
-  uint32_t (*wcnt)[NLIST] = sh.wcnt;
-  uint32_t (*pre)[NLIST] = sh.pre;
+  // emit == nullptr: the scratch sits behind the keys | runs | payloads of the rank sort (3 * RANK_SORT_MAX words of `sk`: the caller's LDS block
+  // is at least that + sizeof(SortEmit) -- the fused sort + forward kernel, whose staging memory is; the emission that uses it keeps at most 2048 keys in `sk`)
+  if (!emit) emit = (SortEmit*)(sk + 3 * RANK_SORT_MAX);
+  uint32_t (*wcnt)[NLIST] = emit->wcnt;
+  uint32_t (*pre)[NLIST] = emit->pre;
   uint32_t* run = sh.run;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // direct bins (direct_blocks = number of projection workgroups, 0 = packed bins): the tile's pairs sit in its fixed span,
